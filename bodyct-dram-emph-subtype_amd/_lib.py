@@ -1,0 +1,101 @@
+"""ctypes binding of libdram_hip.so (the C ABI declared in include/dram_hip.h).
+
+The product path has NO fallback: if the library is missing or fails to load,
+``load()`` raises.  ``import torch`` happens first on purpose -- libdram_hip.so needs
+``libamdhip64.so.7`` and must bind to the HIP runtime PyTorch has already loaded
+(same soname), so that torch's streams and device pointers are valid inside it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+import torch  # noqa: F401  (must precede CDLL: loads the HIP runtime we bind to)
+
+from . import _build
+
+P, I, LL, F, D, SZ = c_void_p, c_int, c_longlong, c_float, c_double, c_size_t
+
+
+class DramConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("B", "D", "H", "W", "Cin", "Do", "Ho", "Wo", "Cout", "k", "stride", "pad", "dil")]
+
+
+class DramTensorRef(ctypes.Structure):
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", ctypes.c_int64)]
+
+
+class DramChunkRef(ctypes.Structure):
+    _fields_ = [("tensor", ctypes.c_int32), ("pad", ctypes.c_int32), ("offset", ctypes.c_int64)]
+
+
+DP = ctypes.POINTER(DramConvDesc)
+
+# name -> (restype, argtypes); mirrors include/dram_hip.h one to one
+SIGNATURES = {
+    "dram_version": (I, []),
+    "dram_build_info": (c_char_p, []),
+    "dram_pack_conv_weight": (I, [P, P, P, I, I, I, P]),
+    "dram_conv3d_fwd": (I, [P, P, P, P, P, DP, P]),
+    "dram_conv3d_bwd_data": (I, [P, P, P, P, P, DP, P]),
+    "dram_conv3d_bwd_weight_workspace": (SZ, [DP]),
+    "dram_conv3d_bwd_weight": (I, [P, P, P, DP, P, SZ, P]),
+    "dram_conv_num_mtiles": (I, [DP]),
+    "dram_stem_num_tiles": (I, [I, I, I, I]),
+    "dram_stem_fwd": (I, [P, P, P, P, I, I, I, I, P]),
+    "dram_stem_bwd_weight_workspace": (SZ, [I, I, I, I]),
+    "dram_stem_bwd_weight": (I, [P, P, P, I, I, I, I, P, SZ, P]),
+    "dram_reduce_partials": (I, [P, P, I, I, I, P]),
+    "dram_bn_finalize": (I, [P, D, P, P, P, P, F, F, I, P, P, P, P, I, P]),
+    "dram_bn_apply": (I, [P, P, P, P, I, I, I, I, I, P, I, I, I, I, I, I, P]),
+    "dram_colsum_nparts": (I, [LL, I]),
+    "dram_bn_bwd_reduce": (I, [P, P, P, P, P, P, LL, I, I, P]),
+    "dram_bn_bwd_apply": (I, [P, P, P, P, P, P, P, D, P, LL, I, I, P]),
+    "dram_colsum": (I, [P, P, LL, I, P]),
+    "dram_maxpool_fwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "dram_maxpool_bwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "dram_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "dram_upcat_bwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "dram_head_nblk": (I, [LL]),
+    "dram_head_fwd": (I, [P, P, P, P, I, I, I, P, P, I, I, I, I, I, I, P]),
+    "dram_head_bwd_nparts": (I, [LL]),
+    "dram_head_bwd": (I, [P, P, P, P, P, P, I, I, I, P, P, I, I, I, I, I, I, P]),
+    "dram_segloss_nblk": (I, [LL]),
+    "dram_segloss_fwd": (I, [P, P, P, P, P, I, I, I, P, I, I, I, I, P]),
+    "dram_segloss_bwd": (I, [P, P, P, P, P, I, I, I, P, P, P, I, I, I, I, P]),
+    "dram_upproject_nblk": (I, [LL]),
+    "dram_upproject": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
+    "dram_adam_multi": (I, [P, P, I, F, F, F, F, F, F, F, F, P]),
+    "dram_sgd_multi": (I, [P, P, I, F, F, F, I, F, P]),
+    "dram_add": (I, [P, P, P, LL, P]),
+}
+
+OPT_CHUNK = 16384
+_LIB = None
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True) -> ctypes.CDLL:
+    """Load (building first when the .so is absent and hipcc is present)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        _build.build_library()
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dram_version() != 1:
+        raise RuntimeError("libdram_hip.so ABI version mismatch")
+    _LIB = lib
+    return lib

@@ -1,0 +1,324 @@
+// bn.hip -- BatchNorm3d (+ReLU, + residual) forward/backward, column reductions, add.
+// Replaces nn.BatchNorm3d / nn.ReLU / `out += residual` / downsample_basic_block at
+// reference med3d.py:121-124, :133-142, :153-182, :103-112, :203-204, :227-228 and their
+// autograd backward.  All HBM-bound: float4 (4 channels) per lane, NDHWC rows.
+//
+// Training statistics arrive as per-tile partial sums from the conv epilogue
+// (conv_igemm.hip / stem.hip); dram_reduce_partials folds them in double precision, the
+// caller may all-reduce the [2][C] doubles across ranks (SyncBatchNorm), then
+// dram_bn_finalize produces mean / invstd / fused scale+shift and the running-stat update.
+#include "common.h"
+
+namespace {
+
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, double* __restrict__ sums,
+                                       int nparts, int RC) {
+  // one thread per (r, c); 4-way split of the partial range folded through LDS
+  __shared__ double sm[256];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;  // 0..3
+  double s = 0.0;
+  if (col < RC)
+    for (int p = part; p < nparts; p += 4) s += (double)partial[(long)p * RC + col];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (part == 0 && col < RC) sums[col] = sm[threadIdx.x] + sm[threadIdx.x + 64] + sm[threadIdx.x + 128] + sm[threadIdx.x + 192];
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, float momentum, float eps, int update,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double m, v;
+  if (sums) {
+    m = sums[c] / count;
+    v = sums[C + c] / count - m * m;
+    if (v < 0.0) v = 0.0;
+    if (update) {
+      const double unb = count > 1.0 ? v * (count / (count - 1.0)) : v;
+      rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * m);
+      rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+    }
+  } else {
+    m = (double)rmean[c];
+    v = (double)rvar[c];
+  }
+  const double is = 1.0 / sqrt(v + (double)eps);
+  const float sc = (float)((double)gamma[c] * is);
+  mean[c] = (float)m;
+  invstd[c] = (float)is;
+  scale[c] = sc;
+  shift[c] = (float)((double)beta[c] - m * (double)gamma[c] * is);
+}
+
+// z = act(y*scale + shift + residual)
+template <int RES>  // 0 none, 1 same-shape identity (shortcut A: bn_apply_shortcut_a_kernel)
+__global__ void bn_apply_kernel(const float4* __restrict__ y, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const float* __restrict__ res, int Cr, int rs,
+                                float4* __restrict__ z, int D, int H, int W, int C, long total4, int relu) {
+  const int Q = C >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + 4 * q);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + 4 * q);
+    const float4 v = y[i];
+    float4 o;
+    o.x = v.x * sc.x + sh.x; o.y = v.y * sc.y + sh.y; o.z = v.z * sc.z + sh.z; o.w = v.w * sc.w + sh.w;
+    if (RES == 1) {
+      const float4 rr = reinterpret_cast<const float4*>(res)[i];
+      o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+    }
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    z[i] = o;
+  }
+}
+
+// shortcut type A needs the residual tensor's own dims -> dedicated kernel
+__global__ void bn_apply_shortcut_a_kernel(const float4* __restrict__ y, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, const float* __restrict__ res,
+                                           int Dr, int Hr, int Wr, int Cr, int rs, float4* __restrict__ z, int D,
+                                           int H, int W, int C, long total4, int relu) {
+  const int Q = C >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + 4 * q);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + 4 * q);
+    const float4 v = y[i];
+    float4 o;
+    o.x = v.x * sc.x + sh.x; o.y = v.y * sc.y + sh.y; o.z = v.z * sc.z + sh.z; o.w = v.w * sc.w + sh.w;
+    if (4 * q < Cr) {
+      long vox = i / Q;
+      const int xx = (int)(vox % W); vox /= W;
+      const int yy = (int)(vox % H); vox /= H;
+      const int zz = (int)(vox % D);
+      const long b = vox / D;
+      const long ro = ((((b * Dr + (long)zz * rs) * Hr + (long)yy * rs) * Wr + (long)xx * rs) * Cr) + 4 * q;
+      const float4 rr = *reinterpret_cast<const float4*>(res + ro);
+      o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+    }
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    z[i] = o;
+  }
+}
+
+// Column reductions over rows of an [rows][C] tensor.
+// MODE 0: partial[p][0][c] = sum a          (R = 1)
+// MODE 1: BN backward: g = dz*(z>0); partial[p][0][c] = sum g, partial[p][1][c] = sum g*xhat (R = 2)
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ a, const float* __restrict__ zz,
+                                                        const float* __restrict__ yy, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, float* __restrict__ partial,
+                                                        long rows, int C, int rpb, int relu) {
+  constexpr int R = MODE == 0 ? 1 : 2;
+  __shared__ float4 sm[R][256];
+  const int Q = C >> 2;
+  const int lanes = Q < 256 ? Q : 256;
+  const int rg = 256 / lanes;
+  const int tid = threadIdx.x;
+  const int ql = tid % lanes, grp = tid / lanes;
+  const long r0 = (long)blockIdx.x * rpb;
+  const long r1 = (r0 + rpb < rows) ? r0 + rpb : rows;
+  for (int qb = 0; qb < Q; qb += lanes) {
+    const int q = qb + ql;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (grp < rg && q < Q) {
+      float4 mu, is;
+      if (MODE == 1) {
+        mu = *reinterpret_cast<const float4*>(mean + 4 * q);
+        is = *reinterpret_cast<const float4*>(invstd + 4 * q);
+      }
+      for (long r = r0 + grp; r < r1; r += rg) {
+        const long o = r * C + 4 * q;
+        float4 g = *reinterpret_cast<const float4*>(a + o);
+        if (MODE == 1) {
+          if (relu) {
+            const float4 zv = *reinterpret_cast<const float4*>(zz + o);
+            g.x = zv.x > 0.f ? g.x : 0.f; g.y = zv.y > 0.f ? g.y : 0.f;
+            g.z = zv.z > 0.f ? g.z : 0.f; g.w = zv.w > 0.f ? g.w : 0.f;
+          }
+          const float4 yv = *reinterpret_cast<const float4*>(yy + o);
+          s1.x += g.x * ((yv.x - mu.x) * is.x); s1.y += g.y * ((yv.y - mu.y) * is.y);
+          s1.z += g.z * ((yv.z - mu.z) * is.z); s1.w += g.w * ((yv.w - mu.w) * is.w);
+        }
+        s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+      }
+    }
+    __syncthreads();
+    sm[0][tid] = s0;
+    if (R == 2) sm[R - 1][tid] = s1;
+    __syncthreads();
+    if (grp == 0 && q < Q) {
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) {
+        float4 t = sm[rr][ql];
+        for (int k = 1; k < rg; ++k) {
+          const float4 u = sm[rr][k * lanes + ql];
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        *reinterpret_cast<float4*>(partial + ((long)blockIdx.x * R + rr) * C + 4 * q) = t;
+      }
+    }
+  }
+}
+
+__global__ void bn_bwd_apply_kernel(const float4* __restrict__ dz, const float4* __restrict__ z,
+                                    const float4* __restrict__ y, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const double* __restrict__ sums, double inv_count, float4* __restrict__ dy, int C,
+                                    long total4, int relu) {
+  const int Q = C >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c = 4 * (int)(i % Q);
+    float4 g = dz[i];
+    if (relu) {
+      const float4 zv = z[i];
+      g.x = zv.x > 0.f ? g.x : 0.f; g.y = zv.y > 0.f ? g.y : 0.f;
+      g.z = zv.z > 0.f ? g.z : 0.f; g.w = zv.w > 0.f ? g.w : 0.f;
+    }
+    const float4 yv = y[i];
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+    float4 o;
+#define BN_BWD_1(f, k)                                               \
+  {                                                                   \
+    const float mg = (float)(sums[c + k] * inv_count);                \
+    const float mgx = (float)(sums[C + c + k] * inv_count);           \
+    const float xh = (yv.f - mu.f) * is.f;                            \
+    o.f = ga.f * is.f * (g.f - mg - xh * mgx);                        \
+  }
+    BN_BWD_1(x, 0) BN_BWD_1(y, 1) BN_BWD_1(z, 2) BN_BWD_1(w, 3)
+#undef BN_BWD_1
+    dy[i] = o;
+  }
+}
+
+__global__ void add_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ o,
+                           long n4, const float* __restrict__ as, const float* __restrict__ bs,
+                           float* __restrict__ os, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 u = a[i], v = b[i];
+    o[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+  }
+  // tail (n not a multiple of 4)
+  const long t0 = n4 * 4;
+  for (long i = t0 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    os[i] = as[i] + bs[i];
+}
+
+inline int ew_grid(long total4) {
+  long b = (total4 + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+inline int rows_per_block(long long rows) {
+  long long rpb = (rows + 1023) / 1024;
+  if (rpb < 64) rpb = 64;
+  return (int)rpb;
+}
+
+}  // namespace
+
+extern "C" int dram_reduce_partials(const float* partial, double* sums, int nparts, int R, int C,
+                                    dram_stream_t stream) {
+  if (!partial || !sums || nparts < 1 || R < 1 || C < 1) return DRAM_ERR_BAD_ARG;
+  const int RC = R * C;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((RC + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial,
+                     sums, nparts, RC);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps,
+                                int update_running, float* mean, float* invstd, float* scale, float* shift, int C,
+                                dram_stream_t stream) {
+  if (!gamma || !beta || !mean || !invstd || !scale || !shift || C < 1) return DRAM_ERR_BAD_ARG;
+  if (!sums && (!running_mean || !running_var)) return DRAM_ERR_BAD_ARG;
+  if (sums && count <= 0.0) return DRAM_ERR_BAD_ARG;
+  if (update_running && (!running_mean || !running_var)) return DRAM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count,
+                     gamma, beta, running_mean, running_var, momentum, eps, update_running, mean, invstd, scale,
+                     shift, C);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_bn_apply(const float* y, const float* scale, const float* shift, const float* residual,
+                             int Dr, int Hr, int Wr, int Cr, int rs, float* z, int B, int D, int H, int W, int C,
+                             int relu, dram_stream_t stream) {
+  if (!y || !scale || !shift || !z || B < 1 || D < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
+  const long total4 = (long)B * D * H * W * (C >> 2);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid(total4);
+  if (!residual) {
+    hipLaunchKernelGGL((bn_apply_kernel<0>), dim3(grid), dim3(256), 0, s, (const float4*)y, scale, shift, nullptr, 0,
+                       1, (float4*)z, D, H, W, C, total4, relu);
+  } else if (rs == 1 && Cr == C && Dr == D && Hr == H && Wr == W) {
+    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(grid), dim3(256), 0, s, (const float4*)y, scale, shift, residual,
+                       Cr, 1, (float4*)z, D, H, W, C, total4, relu);
+  } else {
+    // shortcut type A (med3d.py:103-112): strided subsample, channels >= Cr read zero
+    if ((Cr & 3) || Cr < 4 || Cr > C || rs < 1) return DRAM_ERR_BAD_ARG;
+    if ((D - 1) * rs >= Dr || (H - 1) * rs >= Hr || (W - 1) * rs >= Wr) return DRAM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bn_apply_shortcut_a_kernel, dim3(grid), dim3(256), 0, s, (const float4*)y, scale, shift,
+                       residual, Dr, Hr, Wr, Cr, rs, (float4*)z, D, H, W, C, total4, relu);
+  }
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_colsum_nparts(long long rows, int C) {
+  if (rows < 1 || C < 4) return DRAM_ERR_BAD_ARG;
+  const int rpb = rows_per_block(rows);
+  return (int)((rows + rpb - 1) / rpb);
+}
+
+extern "C" int dram_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean,
+                                  const float* invstd, float* partial, long long rows, int C, int relu,
+                                  dram_stream_t stream) {
+  if (!dz || !y || !mean || !invstd || !partial || rows < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
+  if (relu && !z) return DRAM_ERR_BAD_ARG;
+  const int rpb = rows_per_block(rows);
+  const int nparts = (int)((rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL((colreduce_kernel<1>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, z, y, mean, invstd,
+                     partial, (long)rows, C, rpb, relu);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_colsum(const float* a, float* partial, long long rows, int C, dram_stream_t stream) {
+  if (!a || !partial || rows < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
+  const int rpb = rows_per_block(rows);
+  const int nparts = (int)((rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL((colreduce_kernel<0>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, a, nullptr, nullptr,
+                     nullptr, nullptr, partial, (long)rows, C, rpb, 0);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* mean,
+                                 const float* invstd, const float* gamma, const double* sums, double count,
+                                 float* dy, long long rows, int C, int relu, dram_stream_t stream) {
+  if (!dz || !y || !mean || !invstd || !gamma || !sums || !dy || rows < 1 || C < 4 || (C & 3) || count <= 0.0)
+    return DRAM_ERR_BAD_ARG;
+  if (relu && !z) return DRAM_ERR_BAD_ARG;
+  const long total4 = (long)rows * (C >> 2);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)dz, (const float4*)z, (const float4*)y, mean, invstd, gamma, sums, 1.0 / count,
+                     (float4*)dy, C, total4, relu);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_add(const float* a, const float* b, float* out, long long n, dram_stream_t stream) {
+  if (!a || !b || !out || n < 1) return DRAM_ERR_BAD_ARG;
+  const long n4 = ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0) ? n / 4 : 0;
+  hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n4 > 0 ? n4 : (n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)a, (const float4*)b, (float4*)out, n4, a, b, out, (long)n);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}

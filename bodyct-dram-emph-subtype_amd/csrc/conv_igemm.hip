@@ -1,0 +1,386 @@
+// conv_igemm.hip -- 3x3x3 / 1x1x1 Conv3d forward and data-gradient as an implicit GEMM
+// on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32), NDHWC activations.
+//
+// Replaces the cuDNN/ATen kernels behind nn.Conv3d at reference med3d.py:91-100, :152-157,
+// :67/:76, :226 and autograd's convolution_backward (input gradient) for the same sites.
+//
+// GEMM view:  M = output voxels, N = output channels, K = taps x input channels.
+//   A[m][k]  = in[src(m, tap)][ci]      gathered rows (K-contiguous, zero outside the volume)
+//   B[n][k]  = wp[tap][n][ci]           packed weights (K-contiguous)
+// Tiling: workgroup = 256 threads (4 waves), tile 256(M) x BN(N), K-step 32 (one 128-B
+// line of every gathered voxel row).  The M tile is a 4x8x8 block of the output
+// *lattice with step = dilation*, so a dilated conv sees a dense 6x10x10 halo.
+// Each wave owns 64 rows x BN columns = 2 x (BN/32) accumulators of 32x32.
+// K order is (ci-chunk outer, tap inner): the 27 taps of one chunk re-read the same
+// ~77 KB halo, which stays in the XCD's L2.
+// Pipeline: register-prefetch of tile it+1 is issued before the MFMAs of tile it;
+// single LDS buffer, two barriers per step; 2-3 workgroups per CU overlap each other.
+//
+// MFMA operand trick: within a group of 8 consecutive k, lane half h = lane>>5 reads
+// k = 8g+4h .. 8g+4h+3 with ONE ds_read_b128 for A and for B; MFMA step e then
+// multiplies A[.][8g+4h+e] x B[8g+4h+e][.] for both halves (k order inside the
+// reduction is free as long as A and B agree).  LDS rows are padded to 36 floats:
+// conflict-free for the ds_read_b128 lane groups.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 256;
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;  // padded LDS row (floats)
+constexpr int TZ = 4, TY = 8, TX = 8;
+
+struct IGemmGeom {
+  int B, Do, Ho, Wo, No;  // tensor written (M rows x N cols)
+  int Di, Hi, Wi, Ci;     // tensor gathered
+  int kd, kh, kw, taps;
+  int lat;                // lattice step of the M tile
+  int mul, off, step;     // MODE 0/1: src = o*mul + off + t*step
+  int stride, pad, dil;   // MODE 2:   src = (o + pad - t*dil)/stride when divisible
+  int nz, ny, nx;         // tiles per sub-lattice axis
+  int tiles_per_b;        // lat^3*nz*ny*nx
+  int n_tiles;            // N tiles
+  int nblk;
+};
+
+// MODE 0: forward (any stride/dilation) and MODE 1: data-gradient with stride 1 share
+// the affine source map; MODE 2: data-gradient with stride > 1 (divisibility test).
+template <int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
+    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ out, float* __restrict__ stats, const float* __restrict__ add,
+    const float* __restrict__ gate, const IGemmGeom g) {
+  constexpr int NJ = BN / 32;
+  constexpr int BQ = BN / 32;  // B-tile row passes per thread
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDK];
+  float* As = lds;
+  float* Bs = lds + BM * LDK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  // ---- decode the tile --------------------------------------------------------
+  int L = xcd_remap(blockIdx.x, g.nblk);
+  const int n_tile = L % g.n_tiles;
+  int mt = L / g.n_tiles;
+  const int b = mt / g.tiles_per_b;
+  int r = mt - b * g.tiles_per_b;
+  const int txi = r % g.nx; r /= g.nx;
+  const int tyi = r % g.ny; r /= g.ny;
+  const int tzi = r % g.nz; r /= g.nz;
+  const int rx = r % g.lat; r /= g.lat;
+  const int ry = r % g.lat;
+  const int rz = r / g.lat;
+  const int n0 = n_tile * BN;
+
+  // ---- per-thread gather rows ---------------------------------------------------
+  const int col4 = tid & 7;
+  const int row0 = tid >> 3;  // rows row0 + 32p
+  int rbase[8];               // MODE 0/1: element offset of (b, c0z, c0y, c0x, 0)
+  int rmask[8];               // MODE 0/1: 9 validity bits; MODE 2: packed coords
+  int rcy[(MODE == 2) ? 8 : 1], rcx[(MODE == 2) ? 8 : 1];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int row = row0 + 32 * p;
+    const int zo = ((tzi * TZ + (row >> 6)) * g.lat + rz);
+    const int yo = ((tyi * TY + ((row >> 3) & 7)) * g.lat + ry);
+    const int xo = ((txi * TX + (row & 7)) * g.lat + rx);
+    const bool rv = (zo < g.Do) & (yo < g.Ho) & (xo < g.Wo);
+    if (MODE != 2) {
+      const int cz = zo * g.mul + g.off, cy = yo * g.mul + g.off, cx = xo * g.mul + g.off;
+      rbase[p] = (((b * g.Di + cz) * g.Hi + cy) * g.Wi + cx) * g.Ci;
+      int m = 0;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int z = cz + t * g.step, y = cy + t * g.step, x = cx + t * g.step;
+        m |= ((z >= 0) & (z < g.Di)) ? (1 << t) : 0;
+        m |= ((y >= 0) & (y < g.Hi)) ? (8 << t) : 0;
+        m |= ((x >= 0) & (x < g.Wi)) ? (64 << t) : 0;
+      }
+      rmask[p] = rv ? m : 0;
+    } else {
+      rbase[p] = rv ? 1 : 0;
+      rmask[p] = zo + g.pad;
+      rcy[p] = yo + g.pad;
+      rcx[p] = xo + g.pad;
+    }
+  }
+
+  const int nchunk = g.Ci / BK;
+  const int niter = nchunk * g.taps;
+
+  float4 ra[8];
+  float4 rb[BQ];
+
+  auto load_tile = [&](int it) {
+    const int c = it / g.taps;
+    const int tap = it - c * g.taps;
+    const int tz = tap / (g.kh * g.kw);
+    const int trem = tap - tz * (g.kh * g.kw);
+    const int ty = trem / g.kw;
+    const int tx = trem - ty * g.kw;
+    const int koff = c * BK + col4 * 4;
+    if (MODE != 2) {
+      const int toff = (((tz * g.step) * g.Hi + ty * g.step) * g.Wi + tx * g.step) * g.Ci + koff;
+      const int vb = (1 << tz) | (8 << ty) | (64 << tx);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const bool v = (rmask[p] & vb) == vb;
+        ra[p] = v ? *reinterpret_cast<const float4*>(in + (long)(rbase[p] + toff))
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int nz_ = rmask[p] - tz * g.dil, ny_ = rcy[p] - ty * g.dil, nx_ = rcx[p] - tx * g.dil;
+        const int sz = nz_ / g.stride, sy = ny_ / g.stride, sx = nx_ / g.stride;
+        const bool v = (rbase[p] != 0) & (nz_ >= 0) & (ny_ >= 0) & (nx_ >= 0) & (sz * g.stride == nz_) &
+                       (sy * g.stride == ny_) & (sx * g.stride == nx_) & (sz < g.Di) & (sy < g.Hi) &
+                       (sx < g.Wi);
+        const long o = ((((long)b * g.Di + sz) * g.Hi + sy) * g.Wi + sx) * g.Ci + koff;
+        ra[p] = v ? *reinterpret_cast<const float4*>(in + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const float* wrow = wp + ((long)tap * g.No + n0 + row0) * g.Ci + koff;
+#pragma unroll
+    for (int q = 0; q < BQ; ++q)
+      rb[q] = *reinterpret_cast<const float4*>(wrow + (long)(32 * q) * g.Ci);
+  };
+
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+      *reinterpret_cast<float4*>(&As[(row0 + 32 * p) * LDK + col4 * 4]) = ra[p];
+#pragma unroll
+    for (int q = 0; q < BQ; ++q)
+      *reinterpret_cast<float4*>(&Bs[(row0 + 32 * q) * LDK + col4 * 4]) = rb[q];
+  };
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
+
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const float* a_rd = &As[(wave * 64 + li) * LDK + 4 * lh];
+  const float* b_rd = &Bs[li * LDK + 4 * lh];
+
+  load_tile(0);
+  for (int it = 0; it < niter; ++it) {
+    __syncthreads();  // every wave has finished reading the previous tile
+    store_tile();
+    __syncthreads();
+    if (it + 1 < niter) load_tile(it + 1);  // in flight during the MFMAs below
+#pragma unroll
+    for (int gk = 0; gk < BK / 8; ++gk) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(a_rd + gk * 8);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(a_rd + 32 * LDK + gk * 8);
+      f32x4 bf[NJ];
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj)
+        bf[nj] = *reinterpret_cast<const f32x4*>(b_rd + nj * 32 * LDK + gk * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+          acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bf[nj][e], acc[0][nj], 0, 0, 0);
+          acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bf[nj][e], acc[1][nj], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue -------------------------------------------------------------------
+  // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  float s1[NJ], s2[NJ], bv[NJ];
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj) {
+    s1[nj] = 0.f;
+    s2[nj] = 0.f;
+    bv[nj] = bias ? bias[n0 + nj * 32 + li] : 0.f;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wave * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      const int zo = ((tzi * TZ + (row >> 6)) * g.lat + rz);
+      const int yo = ((tyi * TY + ((row >> 3) & 7)) * g.lat + ry);
+      const int xo = ((txi * TX + (row & 7)) * g.lat + rx);
+      const bool rv = (zo < g.Do) & (yo < g.Ho) & (xo < g.Wo);
+      const long o = ((((long)b * g.Do + zo) * g.Ho + yo) * g.Wo + xo) * g.No + n0 + li;
+      if (rv) {
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+          float v = acc[mi][nj][e] + bv[nj];
+          if (add) {
+            const float av = add[o + nj * 32];
+            v += gate ? (gate[o + nj * 32] > 0.f ? av : 0.f) : av;
+          }
+          out[o + nj * 32] = v;
+          s1[nj] += v;
+          s2[nj] += v * v;
+        }
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();  // LDS is free again
+    float* red = lds; // [4 waves][2][BN]
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+      const float t1 = s1[nj] + __shfl_xor(s1[nj], 32, 64);
+      const float t2 = s2[nj] + __shfl_xor(s2[nj], 32, 64);
+      if (lh == 0) {
+        red[(wave * 2 + 0) * BN + nj * 32 + li] = t1;
+        red[(wave * 2 + 1) * BN + nj * 32 + li] = t2;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, c = tid - which * BN;
+      const float v = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c] +
+                      red[(2 * 2 + which) * BN + c] + red[(3 * 2 + which) * BN + c];
+      stats[((long)mt * 2 + which) * g.No + n0 + c] = v;
+    }
+  }
+}
+
+int pick_bn(int N) {
+  if (N % 128 == 0) return 128;
+  if (N % 64 == 0) return 64;
+  if (N % 32 == 0) return 32;
+  return 0;
+}
+
+void fill_tiles(IGemmGeom& g, int BN) {
+  const int sz = (g.Do + g.lat - 1) / g.lat, sy = (g.Ho + g.lat - 1) / g.lat, sx = (g.Wo + g.lat - 1) / g.lat;
+  g.nz = (sz + TZ - 1) / TZ;
+  g.ny = (sy + TY - 1) / TY;
+  g.nx = (sx + TX - 1) / TX;
+  g.tiles_per_b = g.lat * g.lat * g.lat * g.nz * g.ny * g.nx;
+  g.n_tiles = g.No / BN;
+  g.nblk = g.B * g.tiles_per_b * g.n_tiles;
+}
+
+bool desc_ok(const DramConvDesc* d) {
+  if (!d) return false;
+  if (d->B < 1 || d->D < 1 || d->H < 1 || d->W < 1 || d->Cin < 1 || d->Cout < 1) return false;
+  if (d->k != 1 && d->k != 3) return false;
+  if (d->stride < 1 || d->dil < 1 || d->pad < 0) return false;
+  const int eff = d->dil * (d->k - 1) + 1;
+  auto od = [&](int n) { return (n + 2 * d->pad - eff) / d->stride + 1; };
+  if (d->Do != od(d->D) || d->Ho != od(d->H) || d->Wo != od(d->W)) return false;
+  // int32 element offsets inside the kernels
+  const long long ein = (long long)d->B * d->D * d->H * d->W * d->Cin;
+  const long long eout = (long long)d->B * d->Do * d->Ho * d->Wo * d->Cout;
+  if (ein >= (1LL << 31) || eout >= (1LL << 31)) return false;
+  return true;
+}
+
+template <int MODE>
+int launch(int BN, const float* in, const float* wp, const float* bias, float* out, float* stats,
+           const float* add, const float* gate, IGemmGeom& g, hipStream_t s) {
+  fill_tiles(g, BN);
+  dim3 grid(g.nblk), block(256);
+  switch (BN) {
+    case 128:
+      hipLaunchKernelGGL((conv_igemm_kernel<128, MODE>), grid, block, 0, s, in, wp, bias, out, stats, add, gate, g);
+      break;
+    case 64:
+      hipLaunchKernelGGL((conv_igemm_kernel<64, MODE>), grid, block, 0, s, in, wp, bias, out, stats, add, gate, g);
+      break;
+    case 32:
+      hipLaunchKernelGGL((conv_igemm_kernel<32, MODE>), grid, block, 0, s, in, wp, bias, out, stats, add, gate, g);
+      break;
+    default:
+      return DRAM_ERR_UNSUPPORTED;
+  }
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+}  // namespace
+
+extern "C" int dram_conv_num_mtiles(const DramConvDesc* d) {
+  if (!desc_ok(d)) return DRAM_ERR_BAD_ARG;
+  IGemmGeom g{};
+  g.B = d->B; g.Do = d->Do; g.Ho = d->Ho; g.Wo = d->Wo; g.No = d->Cout;
+  g.lat = d->dil;
+  const int BN = pick_bn(d->Cout);
+  if (!BN) return DRAM_ERR_UNSUPPORTED;
+  fill_tiles(g, BN);
+  return g.B * g.tiles_per_b;
+}
+
+extern "C" int dram_conv3d_fwd(const float* x, const float* wf, const float* bias, float* y,
+                               float* stats_partial, const DramConvDesc* d, dram_stream_t stream) {
+  if (!desc_ok(d) || !x || !wf || !y) return DRAM_ERR_BAD_ARG;
+  if (d->Cin % BK != 0) return DRAM_ERR_UNSUPPORTED;
+  const int BN = pick_bn(d->Cout);
+  if (!BN) return DRAM_ERR_UNSUPPORTED;
+  IGemmGeom g{};
+  g.B = d->B; g.Do = d->Do; g.Ho = d->Ho; g.Wo = d->Wo; g.No = d->Cout;
+  g.Di = d->D; g.Hi = d->H; g.Wi = d->W; g.Ci = d->Cin;
+  g.kd = g.kh = g.kw = d->k; g.taps = d->k * d->k * d->k;
+  g.lat = d->dil;
+  g.mul = d->stride; g.off = -d->pad; g.step = d->dil;
+  g.stride = d->stride; g.pad = d->pad; g.dil = d->dil;
+  return launch<0>(BN, x, wf, bias, y, stats_partial, nullptr, nullptr, g, (hipStream_t)stream);
+}
+
+extern "C" int dram_conv3d_bwd_data(const float* dy, const float* wb, float* dx, const float* add,
+                                    const float* gate, const DramConvDesc* d, dram_stream_t stream) {
+  if (!desc_ok(d) || !dy || !wb || !dx) return DRAM_ERR_BAD_ARG;
+  if (gate && !add) return DRAM_ERR_BAD_ARG;
+  if (d->Cout % BK != 0) return DRAM_ERR_UNSUPPORTED;
+  const int BN = pick_bn(d->Cin);
+  if (!BN) return DRAM_ERR_UNSUPPORTED;
+  IGemmGeom g{};
+  // the tensor written is dx (forward input grid); the tensor gathered is dy
+  g.B = d->B; g.Do = d->D; g.Ho = d->H; g.Wo = d->W; g.No = d->Cin;
+  g.Di = d->Do; g.Hi = d->Ho; g.Wi = d->Wo; g.Ci = d->Cout;
+  g.kd = g.kh = g.kw = d->k; g.taps = d->k * d->k * d->k;
+  g.stride = d->stride; g.pad = d->pad; g.dil = d->dil;
+  if (d->stride == 1) {
+    g.lat = d->dil;
+    g.mul = 1; g.off = d->pad; g.step = -d->dil;
+    return launch<1>(BN, dy, wb, nullptr, dx, nullptr, add, gate, g, (hipStream_t)stream);
+  }
+  g.lat = 1;
+  return launch<2>(BN, dy, wb, nullptr, dx, nullptr, add, gate, g, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------
+// weight repack: [Cout][Cin][taps] -> wf[tap][Cout][Cin], wb[tap][Cin][Cout]
+namespace {
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wf,
+                                   float* __restrict__ wb, int Cout, int Cin, int taps) {
+  const long n = (long)Cout * Cin * taps;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    // i enumerates wf order: (tap, co, ci) -> coalesced writes of wf, strided reads of w
+    const int ci = (int)(i % Cin);
+    const long r = i / Cin;
+    const int co = (int)(r % Cout);
+    const int tap = (int)(r / Cout);
+    const float v = w[((long)co * Cin + ci) * taps + tap];
+    if (wf) wf[i] = v;
+    if (wb) wb[((long)tap * Cin + ci) * Cout + co] = v;
+  }
+}
+}  // namespace
+
+extern "C" int dram_pack_conv_weight(const float* w, float* wf, float* wb, int Cout, int Cin, int taps,
+                                     dram_stream_t stream) {
+  if (!w || (!wf && !wb) || Cout < 1 || Cin < 1 || taps < 1) return DRAM_ERR_BAD_ARG;
+  const long n = (long)Cout * Cin * taps;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wf, wb, Cout, Cin, taps);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}

@@ -1,0 +1,273 @@
+// conv_wgrad.hip -- Conv3d weight gradient on the gfx950 fp32 matrix cores.
+//
+// Replaces autograd's convolution_backward (weight) for the nn.Conv3d call sites of
+// reference med3d.py:91-100, :152-157, :67/:76, :226.
+//
+//   dW[tap][co][ci] = sum_m dy[m][co] * x[src(m,tap)][ci]      (m = output voxel)
+//
+// GEMM view per tap: M = co, N = ci, K = voxels.  One workgroup owns a (co-tile, ci-tile,
+// kz) triple and a contiguous range of "row chunks" (32 consecutive output x at fixed
+// b,z,y); the 3x3 in-plane taps of that kz share one LDS x-tile (3 input rows x
+// (31*stride + 2*dil + 1) voxels x 64 ci) and one dy-tile (32 voxels x co-tile), so a
+// wave does 9 MFMAs per (1 + 9) LDS dword reads.  Each wave keeps 9 accumulators of
+// 32x32 (144 VGPRs).  Operands are read "transposed" straight from the [voxel][channel]
+// LDS rows: A[i=co][k=vox] = dy_lds[vox][co] (lanes = consecutive channels: conflict-free).
+// Split-K over row chunks writes fp32 slabs; a second kernel sums the slabs in a fixed
+// order and scatters into the reference layout [Cout][Cin][kD][kH][kW] -> deterministic.
+#include "common.h"
+
+namespace {
+
+struct WGeom {
+  int B, D, H, W, Cin;
+  int Do, Ho, Wo, Cout;
+  int k, pad;
+  int XC;          // chunks per output row = ceil(Wo/32)
+  int NC;          // total chunks = B*Do*Ho*XC
+  int co_tiles, ci_tiles;
+  int nsplit;
+  int cps;         // chunks per split
+};
+
+// S: stride, DIL: dilation, K3: 1 -> 3x3x3 (9 in-plane taps per block), 0 -> 1x1x1
+// COW x CIW x KW = 4 waves: co-tile = 32*COW, ci-tile = 32*CIW, KW-way split of the
+// 32 voxels of a chunk between waves (extra slab slices).
+template <int S, int DIL, int K3, int COW, int CIW, int KW>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ dy,
+                                                            float* __restrict__ slab, const WGeom g) {
+  static_assert(COW * CIW * KW == 4, "4 waves");
+  constexpr int NT = K3 ? 9 : 1;
+  constexpr int NR = K3 ? 3 : 1;
+  constexpr int XW = 31 * S + (K3 ? 2 * DIL : 0) + 1;
+  constexpr int CO_T = 32 * COW, CI_T = 32 * CIW;
+  constexpr int LDY = CO_T + 4, LDX = CI_T + 4;
+  constexpr int DYP = (32 * (CO_T / 4) + 255) / 256;          // dy float4 per thread
+  constexpr int XQ = CI_T / 4;                                 // float4 per x voxel row
+  constexpr int XP = (NR * XW * XQ + 255) / 256;               // x float4 per thread
+  __shared__ __attribute__((aligned(16))) float lds[32 * LDY + NR * XW * LDX];
+  float* dyl = lds;
+  float* xl = lds + 32 * LDY;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int cw = wave % COW;
+  const int iw = (wave / COW) % CIW;
+  const int kwv = wave / (COW * CIW);
+
+  // ---- block decode: (tile, kz, split) --------------------------------------------
+  int bid = blockIdx.x;
+  const int split = bid % g.nsplit; bid /= g.nsplit;
+  const int ci_t = bid % g.ci_tiles; bid /= g.ci_tiles;
+  const int co_t = bid % g.co_tiles; bid /= g.co_tiles;
+  const int tz = bid;  // 0..k-1
+  const int co0 = co_t * CO_T, ci0 = ci_t * CI_T;
+
+  const int q0 = split * g.cps;
+  const int q1 = (q0 + g.cps < g.NC) ? q0 + g.cps : g.NC;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  float4 rdy[DYP];
+  float4 rx[XP];
+
+  auto load_chunk = [&](int q) -> bool {
+    const int xc = q % g.XC;
+    int r = q / g.XC;
+    const int yo = r % g.Ho; r /= g.Ho;
+    const int zo = r % g.Do;
+    const int b = r / g.Do;
+    const int zi = zo * S - g.pad + tz * DIL;
+    if (zi < 0 || zi >= g.D) return false;  // uniform
+    const int xo0 = xc * 32;
+    // dy tile: 32 voxels x CO_T
+#pragma unroll
+    for (int p = 0; p < DYP; ++p) {
+      const int idx = p * 256 + tid;
+      const int v = idx / (CO_T / 4), c4 = idx % (CO_T / 4);
+      const bool ok = (idx < 32 * (CO_T / 4)) & (xo0 + v < g.Wo);
+      const long o = ((((long)b * g.Do + zo) * g.Ho + yo) * g.Wo + xo0 + v) * g.Cout + co0 + c4 * 4;
+      rdy[p] = ok ? *reinterpret_cast<const float4*>(dy + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // x tile: NR rows x XW voxels x CI_T
+    const int xi0 = xo0 * S - g.pad;
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const int idx = p * 256 + tid;
+      const int v = idx / XQ, c4 = idx % XQ;
+      const int ty = v / XW, xp = v - ty * XW;
+      const int yi = yo * S - g.pad + ty * DIL;
+      const int xi = xi0 + xp;
+      const bool ok = (idx < NR * XW * XQ) & (yi >= 0) & (yi < g.H) & (xi >= 0) & (xi < g.W);
+      const long o = ((((long)b * g.D + zi) * g.H + yi) * g.W + xi) * g.Cin + ci0 + c4 * 4;
+      rx[p] = ok ? *reinterpret_cast<const float4*>(x + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return true;
+  };
+
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int p = 0; p < DYP; ++p) {
+      const int idx = p * 256 + tid;
+      const int v = idx / (CO_T / 4), c4 = idx % (CO_T / 4);
+      if (idx < 32 * (CO_T / 4)) *reinterpret_cast<float4*>(&dyl[v * LDY + c4 * 4]) = rdy[p];
+    }
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const int idx = p * 256 + tid;
+      const int v = idx / XQ, c4 = idx % XQ;
+      if (idx < NR * XW * XQ) *reinterpret_cast<float4*>(&xl[v * LDX + c4 * 4]) = rx[p];
+    }
+  };
+
+  bool cur = (q0 < q1) ? load_chunk(q0) : false;
+  for (int q = q0; q < q1; ++q) {
+    __syncthreads();
+    if (cur) store_chunk();
+    __syncthreads();
+    bool nxt = false;
+    if (q + 1 < q1) nxt = load_chunk(q + 1);
+    if (cur) {
+      constexpr int VPW = 32 / KW;  // voxels per wave
+#pragma unroll 4
+      for (int kk = 0; kk < VPW / 2; ++kk) {
+        const int vox = kwv * VPW + 2 * kk + lh;
+        const float a = dyl[vox * LDY + cw * 32 + li];
+        const float* xb = &xl[(vox * S) * LDX + iw * 32 + li];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int ty = t / 3, tx = t % 3;
+          const float bvv = xb[(ty * XW + tx * DIL) * LDX];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    cur = nxt;
+  }
+
+  // ---- write the slab slice ---------------------------------------------------------
+  const int sidx = split * KW + kwv;
+  const long tap_stride = (long)g.Cout * g.Cin;
+  float* sl = slab + ((long)sidx * g.k + tz) * NT * tap_stride;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = co0 + cw * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      const int ci = ci0 + iw * 32 + li;
+      if (co < g.Cout && ci < g.Cin) sl[t * tap_stride + (long)co * g.Cin + ci] = acc[t][e];
+    }
+  }
+}
+
+// dW[co][ci][tap] = sum_s slab[s][tap][co][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslab,
+                                    int taps, int Cout, int Cin) {
+  const long per = (long)taps * Cout * Cin;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += slab[(long)k * per + i];
+    const int ci = (int)(i % Cin);
+    const long r = i / Cin;
+    const int co = (int)(r % Cout);
+    const int tap = (int)(r / Cout);
+    dw[((long)co * Cin + ci) * taps + tap] = s;
+  }
+}
+
+struct Plan {
+  WGeom g;
+  int cow, kw;
+  int nslab;
+  int nblk;
+  int variant;  // 0: s1d1, 1: s1d2, 2: s1d4, 3: s2d1, 4: 1x1x1 (s1)
+};
+
+bool make_plan(const DramConvDesc* d, Plan& p) {
+  if (!d) return false;
+  if (d->k != 1 && d->k != 3) return false;
+  if (d->Cin % 64 != 0) return false;
+  if (d->Cout % 32 != 0) return false;
+  WGeom& g = p.g;
+  g.B = d->B; g.D = d->D; g.H = d->H; g.W = d->W; g.Cin = d->Cin;
+  g.Do = d->Do; g.Ho = d->Ho; g.Wo = d->Wo; g.Cout = d->Cout;
+  g.k = d->k; g.pad = d->pad;
+  if (d->k == 3) {
+    if (d->stride == 1 && d->dil == 1) p.variant = 0;
+    else if (d->stride == 1 && d->dil == 2) p.variant = 1;
+    else if (d->stride == 1 && d->dil == 4) p.variant = 2;
+    else if (d->stride == 2 && d->dil == 1) p.variant = 3;
+    else return false;
+  } else {
+    if (d->stride != 1) return false;
+    p.variant = 4;
+  }
+  const bool narrow = (d->Cout % 64 != 0);
+  p.cow = narrow ? 1 : 2;
+  p.kw = narrow ? 2 : 1;
+  g.co_tiles = d->Cout / (32 * p.cow);
+  g.ci_tiles = d->Cin / 64;
+  g.XC = (d->Wo + 31) / 32;
+  g.NC = d->B * d->Do * d->Ho * g.XC;
+  const int tiles = g.co_tiles * g.ci_tiles * d->k;
+  int ns = (1024 + tiles - 1) / tiles;  // aim at ~4 workgroups per CU
+  if (ns > g.NC) ns = g.NC;
+  if (ns < 1) ns = 1;
+  // keep the slab below ~192 MB
+  const double slab1 = (double)d->k * d->k * d->k * d->Cout * d->Cin * 4.0 * p.kw;
+  while (ns > 1 && slab1 * ns > 192e6) --ns;
+  g.cps = (g.NC + ns - 1) / ns;
+  ns = (g.NC + g.cps - 1) / g.cps;
+  g.nsplit = ns;
+  p.nslab = ns * p.kw;
+  p.nblk = tiles * ns;
+  return true;
+}
+
+}  // namespace
+
+extern "C" size_t dram_conv3d_bwd_weight_workspace(const DramConvDesc* d) {
+  Plan p{};
+  if (!make_plan(d, p)) return 0;
+  return (size_t)p.nslab * d->k * d->k * d->k * d->Cout * d->Cin * sizeof(float);
+}
+
+extern "C" int dram_conv3d_bwd_weight(const float* x, const float* dy, float* dw, const DramConvDesc* d,
+                                      void* workspace, size_t workspace_bytes, dram_stream_t stream) {
+  Plan p{};
+  if (!x || !dy || !dw || !d) return DRAM_ERR_BAD_ARG;
+  if (!make_plan(d, p)) return DRAM_ERR_UNSUPPORTED;
+  const size_t need = (size_t)p.nslab * d->k * d->k * d->k * d->Cout * d->Cin * sizeof(float);
+  if (!workspace || workspace_bytes < need) return DRAM_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* slab = (float*)workspace;
+  dim3 grid(p.nblk), block(256);
+  const bool narrow = (p.cow == 1);
+#define WG_LAUNCH(S_, D_, K3_)                                                                          \
+  do {                                                                                                  \
+    if (narrow)                                                                                         \
+      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 1, 2, 2>), grid, block, 0, s, x, dy, slab, p.g); \
+    else                                                                                                \
+      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 2, 2, 1>), grid, block, 0, s, x, dy, slab, p.g); \
+  } while (0)
+  switch (p.variant) {
+    case 0: WG_LAUNCH(1, 1, 1); break;
+    case 1: WG_LAUNCH(1, 2, 1); break;
+    case 2: WG_LAUNCH(1, 4, 1); break;
+    case 3: WG_LAUNCH(2, 1, 1); break;
+    case 4: WG_LAUNCH(1, 1, 0); break;
+    default: return DRAM_ERR_UNSUPPORTED;
+  }
+#undef WG_LAUNCH
+  DRAM_LAUNCH_CHECK();
+  const int taps = d->k * d->k * d->k;
+  const long per = (long)taps * d->Cout * d->Cin;
+  const int rgrid = (int)((per + 255) / 256 > 8192 ? 8192 : (per + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, slab, dw, p.nslab, taps, d->Cout, d->Cin);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}

@@ -1,0 +1,352 @@
+// head_loss.hip -- 1x1x1 heads + pooled scores, and the fused dRAM segmentation losses.
+// Replaces: fcs Conv3d(32,n,1) + adaptive_avg_pool3d (reference med3d.py:283-284),
+// sigmoid(fcs) + nearest-resized-lung masked mean (med3d.py:382-387), and the ~25
+// elementwise/reduction torch ops of _segmentation_loss (models.py:523-531, metrics.py:10-37,
+// label prep models.py:567-570), each with its backward.  One HBM pass per kernel.
+#include "common.h"
+
+namespace {
+
+// F.interpolate(mode='nearest') source index: min(floor(dst * in/out), in-1)
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in) {
+  const int s = (int)floorf((float)dst * scale);
+  return s < in - 1 ? s : in - 1;
+}
+
+struct NearGeom {
+  int Dl, Hl, Wl;
+  float sz, sy, sx;
+};
+
+__device__ __forceinline__ long near_index(const NearGeom& n, long b, int z, int y, int x) {
+  return ((b * n.Dl + nearest_src(z, n.sz, n.Dl)) * n.Hl + nearest_src(y, n.sy, n.Hl)) * (long)n.Wl +
+         nearest_src(x, n.sx, n.Wl);
+}
+
+// ----------------------------------------------------------------------------- head fwd
+template <int NOT>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, const float* __restrict__ lungs,
+                                                       NearGeom ng, float* __restrict__ dense,
+                                                       float* __restrict__ partial, int D, int H, int W, int NO,
+                                                       int sigmoid, int nblk) {
+  __shared__ float wl[NOT * 32 + NOT];
+  __shared__ float red[4][NOT + 1];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NO * 32; i += 256) wl[i] = w[i];
+  for (int i = tid; i < NO; i += 256) wl[NOT * 32 + i] = bias[i];
+  __syncthreads();
+  const long b = blockIdx.y;
+  const long vps = (long)D * H * W;
+  float acc[NOT + 1];
+#pragma unroll
+  for (int c = 0; c <= NOT; ++c) acc[c] = 0.f;
+  for (long v = blockIdx.x * 256L + tid; v < vps; v += (long)gridDim.x * 256L) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (b * vps + v) * 32);
+    float4 xv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xv[k] = xr[k];
+    float L = 1.f;
+    if (lungs) {
+      long r = v;
+      const int xo = (int)(r % W); r /= W;
+      const int yo = (int)(r % H);
+      const int zo = (int)(r / H);
+      L = lungs[near_index(ng, b, zo, yo, xo)];
+    }
+#pragma unroll
+    for (int c = 0; c < NOT; ++c) {
+      if (c < NO) {
+        float s = wl[NOT * 32 + c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          s += xv[k].x * wl[c * 32 + 4 * k] + xv[k].y * wl[c * 32 + 4 * k + 1] + xv[k].z * wl[c * 32 + 4 * k + 2] +
+               xv[k].w * wl[c * 32 + 4 * k + 3];
+        }
+        if (sigmoid) s = 1.f / (1.f + expf(-s));
+        dense[(b * NO + c) * vps + v] = s;
+        acc[c] += sigmoid ? s * L : s;
+      }
+    }
+    acc[NOT] += L;
+  }
+#pragma unroll
+  for (int c = 0; c <= NOT; ++c) {
+    const float s = wave_sum(acc[c]);
+    if ((tid & 63) == 0) red[tid >> 6][c] = s;
+  }
+  __syncthreads();
+  if (tid <= NO) {
+    const int c = tid < NO ? tid : NOT;
+    partial[((long)b * nblk + blockIdx.x) * (NO + 1) + tid] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  }
+}
+
+// ----------------------------------------------------------------------------- head bwd
+template <int NOT>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ dense, const float* __restrict__ gdense,
+                                                       const float* __restrict__ gpool, const float* __restrict__ lungs,
+                                                       NearGeom ng, float* __restrict__ dx, float* __restrict__ wpartial,
+                                                       int D, int H, int W, int NO, int sigmoid, int nblk) {
+  constexpr int SLOTS = (NOT * 33 + 255) / 256;
+  __shared__ float wl[NOT * 32];
+  __shared__ float xs[256 * 33];
+  __shared__ float ds[256 * NOT];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NO * 32; i += 256) wl[i] = w[i];
+  const long b = blockIdx.y;
+  const long vps = (long)D * H * W;
+  float gp[NOT];
+#pragma unroll
+  for (int c = 0; c < NOT; ++c) gp[c] = (c < NO) ? gpool[b * NO + c] : 0.f;
+  float wacc[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) wacc[s] = 0.f;
+  __syncthreads();
+  const long ntile = (vps + 255) / 256;
+  for (long t = blockIdx.x; t < ntile; t += gridDim.x) {
+    const long v = t * 256 + tid;
+    const bool ok = v < vps;
+    float4 xv[8];
+    float dp[NOT];
+#pragma unroll
+    for (int c = 0; c < NOT; ++c) dp[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+      const float4* xr = reinterpret_cast<const float4*>(x + (b * vps + v) * 32);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) xv[k] = xr[k];
+      float L = 1.f;
+      if (lungs) {
+        long r = v;
+        const int xo = (int)(r % W); r /= W;
+        const int yo = (int)(r % H);
+        const int zo = (int)(r / H);
+        L = lungs[near_index(ng, b, zo, yo, xo)];
+      }
+#pragma unroll
+      for (int c = 0; c < NOT; ++c) {
+        if (c < NO) {
+          float g = gp[c] * (sigmoid ? L : 1.f);
+          if (gdense) g += gdense[(b * NO + c) * vps + v];
+          if (sigmoid) {
+            const float s = dense[(b * NO + c) * vps + v];
+            g *= s * (1.f - s);
+          }
+          dp[c] = g;
+        }
+      }
+      float4 o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int c = 0; c < NOT; ++c) {
+        if (c < NO) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            o[k].x += dp[c] * wl[c * 32 + 4 * k];
+            o[k].y += dp[c] * wl[c * 32 + 4 * k + 1];
+            o[k].z += dp[c] * wl[c * 32 + 4 * k + 2];
+            o[k].w += dp[c] * wl[c * 32 + 4 * k + 3];
+          }
+        }
+      }
+      float4* dr = reinterpret_cast<float4*>(dx + (b * vps + v) * 32);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dr[k] = o[k];
+    }
+    __syncthreads();  // previous tile's LDS consumers are done
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      xs[tid * 33 + 4 * k] = xv[k].x; xs[tid * 33 + 4 * k + 1] = xv[k].y;
+      xs[tid * 33 + 4 * k + 2] = xv[k].z; xs[tid * 33 + 4 * k + 3] = xv[k].w;
+    }
+    xs[tid * 33 + 32] = ok ? 1.f : 0.f;
+#pragma unroll
+    for (int c = 0; c < NOT; ++c) ds[tid * NOT + c] = dp[c];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int idx = s * 256 + tid;
+      if (idx < NO * 33) {
+        const int c = idx / 33, k = idx - c * 33;
+        float a = 0.f;
+        for (int vv = 0; vv < 256; ++vv) a += ds[vv * NOT + c] * xs[vv * 33 + k];
+        wacc[s] += a;
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int idx = s * 256 + tid;
+    if (idx < NO * 33) wpartial[((long)b * nblk + blockIdx.x) * (NO * 33) + idx] = wacc[s];
+  }
+}
+
+// ----------------------------------------------------------------------------- seg loss
+__global__ __launch_bounds__(256) void segloss_fwd_kernel(const float* __restrict__ cle, const float* __restrict__ pse,
+                                                          const float* __restrict__ lungs, const float* __restrict__ ems,
+                                                          const float* __restrict__ binary, NearGeom ng,
+                                                          float* __restrict__ partial, int B, int D, int H, int W) {
+  __shared__ float red[4][6];
+  const long vps = (long)D * H * W;
+  const long total = vps * B;
+  float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const long b = i / vps;
+    long r = i - b * vps;
+    const int xo = (int)(r % W); r /= W;
+    const int yo = (int)(r % H);
+    const int zo = (int)(r / H);
+    const long li = near_index(ng, b, zo, yo, xo);
+    const float L = lungs[li];
+    const float t = ems[li] * binary[b];
+    const float c = cle[i], p_ = pse[i];
+    float p = c + p_;
+    p = fminf(fmaxf(p, 0.f), 1.f);
+    const float pt = p * t + (1.f - p) * (1.f - t);
+    const float ptc = fminf(fmaxf(pt, 1e-6f), 1.f - 1e-6f);
+    const float cw = 0.85f * L + (1.f - L);
+    const float nl = -cw * logf(ptc);
+    s[0] += t;
+    s[1] += nl * t;
+    s[2] += nl * (1.f - t);
+    s[3] += (c * L) * (p_ * L);
+    s[4] += c * L;
+    s[5] += p_ * L;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float v = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6)
+    partial[(long)blockIdx.x * 6 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// coef: [0] g_mul*2/den  [1] g_mul*(2I+eps)/den^2  [2] g_seg*alpha/sum_w  [3] g_seg*(1-alpha)/sum_w
+__global__ void segloss_bwd_kernel(const float* __restrict__ cle, const float* __restrict__ pse,
+                                   const float* __restrict__ lungs, const float* __restrict__ ems,
+                                   const float* __restrict__ binary, NearGeom ng, const float* __restrict__ coef,
+                                   float* __restrict__ gcle, float* __restrict__ gpse, int B, int D, int H, int W) {
+  const long vps = (long)D * H * W;
+  const long total = vps * B;
+  const float k0 = coef[0], k1 = coef[1], k2 = coef[2], k3 = coef[3];
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const long b = i / vps;
+    long r = i - b * vps;
+    const int xo = (int)(r % W); r /= W;
+    const int yo = (int)(r % H);
+    const int zo = (int)(r / H);
+    const long li = near_index(ng, b, zo, yo, xo);
+    const float L = lungs[li];
+    const float t = ems[li] * binary[b];
+    const float c = cle[i], p_ = pse[i];
+    const float sum = c + p_;
+    const float p = fminf(fmaxf(sum, 0.f), 1.f);
+    const float pt = p * t + (1.f - p) * (1.f - t);
+    const float ptc = fminf(fmaxf(pt, 1e-6f), 1.f - 1e-6f);
+    const float cw = 0.85f * L + (1.f - L);
+    // d/dp of -cw*log(ptc)*w, clamp gradients are inclusive at the bounds (torch.clamp)
+    float gb = 0.f;
+    if (pt >= 1e-6f && pt <= 1.f - 1e-6f && sum >= 0.f && sum <= 1.f)
+      gb = -cw * (2.f * t - 1.f) / ptc * (k2 * t + k3 * (1.f - t));
+    gcle[i] = k0 * p_ * L * L - k1 * L + gb;
+    gpse[i] = k0 * c * L * L - k1 * L + gb;
+  }
+}
+
+inline NearGeom make_near(int Dl, int Hl, int Wl, int D, int H, int W) {
+  NearGeom n;
+  n.Dl = Dl; n.Hl = Hl; n.Wl = Wl;
+  n.sz = (float)Dl / (float)D; n.sy = (float)Hl / (float)H; n.sx = (float)Wl / (float)W;
+  return n;
+}
+
+inline int head_blocks(long long vps) {
+  long long b = (vps + 2047) / 2048;
+  return (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int dram_head_nblk(long long voxels_per_sample) { return head_blocks(voxels_per_sample); }
+extern "C" int dram_head_bwd_nparts(long long voxels_per_sample) { return head_blocks(voxels_per_sample); }
+
+extern "C" int dram_head_fwd(const float* x, const float* w, const float* bias, const float* lungs, int Dl, int Hl,
+                             int Wl, float* dense, float* partial, int B, int D, int H, int W, int NO, int sigmoid,
+                             dram_stream_t stream) {
+  if (!x || !w || !bias || !dense || !partial || B < 1 || D < 1 || H < 1 || W < 1 || NO < 1 || NO > 16)
+    return DRAM_ERR_BAD_ARG;
+  if (lungs && (Dl < 1 || Hl < 1 || Wl < 1)) return DRAM_ERR_BAD_ARG;
+  const long vps = (long)D * H * W;
+  const int nblk = head_blocks(vps);
+  const NearGeom ng = make_near(lungs ? Dl : 1, lungs ? Hl : 1, lungs ? Wl : 1, D, H, W);
+  dim3 grid(nblk, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (NO <= 2)
+    hipLaunchKernelGGL((head_fwd_kernel<2>), grid, block, 0, s, x, w, bias, lungs, ng, dense, partial, D, H, W, NO, sigmoid, nblk);
+  else if (NO <= 9)
+    hipLaunchKernelGGL((head_fwd_kernel<9>), grid, block, 0, s, x, w, bias, lungs, ng, dense, partial, D, H, W, NO, sigmoid, nblk);
+  else
+    hipLaunchKernelGGL((head_fwd_kernel<16>), grid, block, 0, s, x, w, bias, lungs, ng, dense, partial, D, H, W, NO, sigmoid, nblk);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_head_bwd(const float* x, const float* w, const float* dense, const float* gdense,
+                             const float* gpool, const float* lungs, int Dl, int Hl, int Wl, float* dx,
+                             float* wpartial, int B, int D, int H, int W, int NO, int sigmoid, dram_stream_t stream) {
+  if (!x || !w || !gpool || !dx || !wpartial || B < 1 || D < 1 || H < 1 || W < 1 || NO < 1 || NO > 16)
+    return DRAM_ERR_BAD_ARG;
+  if (sigmoid && !dense) return DRAM_ERR_BAD_ARG;
+  if (lungs && (Dl < 1 || Hl < 1 || Wl < 1)) return DRAM_ERR_BAD_ARG;
+  const long vps = (long)D * H * W;
+  const int nblk = head_blocks(vps);
+  const NearGeom ng = make_near(lungs ? Dl : 1, lungs ? Hl : 1, lungs ? Wl : 1, D, H, W);
+  dim3 grid(nblk, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (NO <= 2)
+    hipLaunchKernelGGL((head_bwd_kernel<2>), grid, block, 0, s, x, w, dense, gdense, gpool, lungs, ng, dx, wpartial, D, H, W, NO, sigmoid, nblk);
+  else if (NO <= 9)
+    hipLaunchKernelGGL((head_bwd_kernel<9>), grid, block, 0, s, x, w, dense, gdense, gpool, lungs, ng, dx, wpartial, D, H, W, NO, sigmoid, nblk);
+  else
+    hipLaunchKernelGGL((head_bwd_kernel<16>), grid, block, 0, s, x, w, dense, gdense, gpool, lungs, ng, dx, wpartial, D, H, W, NO, sigmoid, nblk);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_segloss_nblk(long long voxels_total) {
+  long long b = (voxels_total + 4095) / 4096;
+  return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+
+extern "C" int dram_segloss_fwd(const float* cle, const float* pse, const float* lungs, const float* ems,
+                                const float* binary, int Dl, int Hl, int Wl, float* partial, int B, int D, int H,
+                                int W, dram_stream_t stream) {
+  if (!cle || !pse || !lungs || !ems || !binary || !partial || B < 1 || D < 1 || H < 1 || W < 1 || Dl < 1 || Hl < 1 ||
+      Wl < 1)
+    return DRAM_ERR_BAD_ARG;
+  const long total = (long)B * D * H * W;
+  hipLaunchKernelGGL(segloss_fwd_kernel, dim3(dram_segloss_nblk(total)), dim3(256), 0, (hipStream_t)stream, cle, pse,
+                     lungs, ems, binary, make_near(Dl, Hl, Wl, D, H, W), partial, B, D, H, W);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_segloss_bwd(const float* cle, const float* pse, const float* lungs, const float* ems,
+                                const float* binary, int Dl, int Hl, int Wl, const float* coef, float* gcle,
+                                float* gpse, int B, int D, int H, int W, dram_stream_t stream) {
+  if (!cle || !pse || !lungs || !ems || !binary || !coef || !gcle || !gpse || B < 1 || D < 1 || H < 1 || W < 1 ||
+      Dl < 1 || Hl < 1 || Wl < 1)
+    return DRAM_ERR_BAD_ARG;
+  const long total = (long)B * D * H * W;
+  hipLaunchKernelGGL(segloss_bwd_kernel, dim3(dram_segloss_nblk(total)), dim3(256), 0, (hipStream_t)stream, cle, pse,
+                     lungs, ems, binary, make_near(Dl, Hl, Wl, D, H, W), coef, gcle, gpse, B, D, H, W);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}

@@ -1,0 +1,110 @@
+// optim.hip -- multi-tensor Adam / SGD weight update (one launch for every parameter).
+// Replaces torch.optim.Adam.step at reference models.py:385-387 / :689-691 (defaults
+// betas=(0.9,0.999), eps=1e-8, weight_decay=0, no amsgrad) and the SGD(momentum,
+// weight_decay) alternative the reference keeps as arguments (train.py:25,27;
+// models.py:388-389).  HBM-bound: 28 B/param (read p,g,m,v; write p,m,v).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const DramTensorRef* __restrict__ table,
+                                                         const DramChunkRef* __restrict__ chunks, float lr, float b1,
+                                                         float b2, float eps, float wd, float bc1, float bc2,
+                                                         float gscale) {
+  const DramChunkRef ch = chunks[blockIdx.x];
+  const DramTensorRef t = table[ch.tensor];
+  const long n = t.n - ch.offset < DRAM_OPT_CHUNK ? t.n - ch.offset : DRAM_OPT_CHUNK;
+  float* p = t.p + ch.offset;
+  const float* g = t.g + ch.offset;
+  float* m = t.m + ch.offset;
+  float* v = t.v + ch.offset;
+  const float step = lr / bc1;
+  const float rs2 = 1.f / sqrtf(bc2);
+  // torch: denom = sqrt(v)/sqrt(bc2) + eps ; p -= (lr/bc1) * m / denom
+  const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+  if (vec) {
+    const long n4 = n >> 2;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+      float4 pv = reinterpret_cast<float4*>(p)[i];
+      float4 gv = reinterpret_cast<const float4*>(g)[i];
+      float4 mv = reinterpret_cast<float4*>(m)[i];
+      float4 vv = reinterpret_cast<float4*>(v)[i];
+#define ADAM1(f)                                   \
+  {                                                \
+    float gg = gv.f * gscale;                      \
+    if (wd != 0.f) gg += wd * pv.f;                \
+    mv.f = b1 * mv.f + (1.f - b1) * gg;            \
+    vv.f = b2 * vv.f + (1.f - b2) * gg * gg;       \
+    pv.f -= step * mv.f / (sqrtf(vv.f) * rs2 + eps); \
+  }
+      ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+      reinterpret_cast<float4*>(p)[i] = pv;
+      reinterpret_cast<float4*>(m)[i] = mv;
+      reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+      float gg = g[i] * gscale;
+      if (wd != 0.f) gg += wd * p[i];
+      const float mm = b1 * m[i] + (1.f - b1) * gg;
+      const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+      m[i] = mm; v[i] = vv;
+      p[i] -= step * mm / (sqrtf(vv) * rs2 + eps);
+    }
+  } else {
+    for (long i = threadIdx.x; i < n; i += 256) {
+      float gg = g[i] * gscale;
+      if (wd != 0.f) gg += wd * p[i];
+      const float mm = b1 * m[i] + (1.f - b1) * gg;
+      const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+      m[i] = mm; v[i] = vv;
+      p[i] -= step * mm / (sqrtf(vv) * rs2 + eps);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const DramTensorRef* __restrict__ table,
+                                                        const DramChunkRef* __restrict__ chunks, float lr, float mom,
+                                                        float wd, int first, float gscale) {
+  const DramChunkRef ch = chunks[blockIdx.x];
+  const DramTensorRef t = table[ch.tensor];
+  const long n = t.n - ch.offset < DRAM_OPT_CHUNK ? t.n - ch.offset : DRAM_OPT_CHUNK;
+  float* p = t.p + ch.offset;
+  const float* g = t.g + ch.offset;
+  float* m = t.m ? t.m + ch.offset : nullptr;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    float gg = g[i] * gscale;
+    if (wd != 0.f) gg += wd * p[i];
+    if (mom != 0.f && m) {
+      const float bb = first ? gg : mom * m[i] + gg;
+      m[i] = bb;
+      gg = bb;
+    }
+    p[i] -= lr * gg;
+  }
+}
+
+}  // namespace
+
+extern "C" int dram_adam_multi(const DramTensorRef* table, const DramChunkRef* chunks, int nchunks, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, float bias_corr1,
+                               float bias_corr2, float grad_scale, dram_stream_t stream) {
+  if (!table || !chunks || nchunks < 1 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return DRAM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, chunks, lr, beta1,
+                     beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_sgd_multi(const DramTensorRef* table, const DramChunkRef* chunks, int nchunks, float lr,
+                              float momentum, float weight_decay, int first_step, float grad_scale,
+                              dram_stream_t stream) {
+  if (!table || !chunks || nchunks < 1) return DRAM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, chunks, lr, momentum,
+                     weight_decay, first_step, grad_scale);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_version(void) { return DRAM_ABI_VERSION; }
+extern "C" const char* dram_build_info(void) { return "libdram_hip gfx950 fp32-mfma"; }

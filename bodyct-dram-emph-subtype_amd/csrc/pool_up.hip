@@ -1,0 +1,330 @@
+// pool_up.hip -- MaxPool3d(3,2,1), trilinear x2 up-projection + crop/concat, and the
+// predict-time up-projection to the scan grid.
+// Replaces nn.MaxPool3d (reference med3d.py:206/:275), nn.Upsample(trilinear,
+// align_corners=True) + crop_concat_5d (med3d.py:83-87, :39-48), F.interpolate at
+// models.py:438-441, and their autograd backward.  HBM-bound; float4 = 4 channels/lane.
+#include "common.h"
+
+namespace {
+
+inline int ew_grid(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+// ------------------------------------------------------------------ max pool
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                   uint8_t* __restrict__ amax, int D, int H, int W, int C, int Do, int Ho, int Wo,
+                                   long total4) {
+  const int Q = C >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    long v = i / Q;
+    const int xo = (int)(v % Wo); v /= Wo;
+    const int yo = (int)(v % Ho); v /= Ho;
+    const int zo = (int)(v % Do);
+    const long b = v / Do;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int ax = 0, ay = 0, az = 0, aw = 0;
+    bool first = true;
+    // scan order kd, kh, kw; strict '>' keeps the first maximum (ATen max_pool3d semantics)
+    for (int kz = 0; kz < 3; ++kz) {
+      const int zi = 2 * zo - 1 + kz;
+      if (zi < 0 || zi >= D) continue;
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yi = 2 * yo - 1 + ky;
+        if (yi < 0 || yi >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xi = 2 * xo - 1 + kx;
+          if (xi < 0 || xi >= W) continue;
+          const float4 t = *reinterpret_cast<const float4*>(x + ((((b * D + zi) * H + yi) * W + xi) * (long)C + 4 * q));
+          const int tap = (kz * 3 + ky) * 3 + kx;
+          if (first || t.x > m.x || t.x != t.x) { m.x = t.x; ax = tap; }
+          if (first || t.y > m.y || t.y != t.y) { m.y = t.y; ay = tap; }
+          if (first || t.z > m.z || t.z != t.z) { m.z = t.z; az = tap; }
+          if (first || t.w > m.w || t.w != t.w) { m.w = t.w; aw = tap; }
+          first = false;
+        }
+      }
+    }
+    reinterpret_cast<float4*>(y)[i] = m;
+    reinterpret_cast<uchar4*>(amax)[i] = make_uchar4((unsigned char)ax, (unsigned char)ay, (unsigned char)az,
+                                                     (unsigned char)aw);
+  }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ amax,
+                                   const float* __restrict__ add, float* __restrict__ dx, int D, int H, int W, int C,
+                                   int Do, int Ho, int Wo, long total4) {
+  const int Q = C >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    long v = i / Q;
+    const int xi = (int)(v % W); v /= W;
+    const int yi = (int)(v % H); v /= H;
+    const int zi = (int)(v % D);
+    const long b = v / D;
+    float4 s = add ? reinterpret_cast<const float4*>(add)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // windows containing zi: zo with 2zo-1 <= zi <= 2zo+1
+    const int zlo = zi >> 1, zhi = (zi + 1) >> 1;  // ceil((zi-1)/2) == zi>>1 for zi>=0
+    const int ylo = yi >> 1, yhi = (yi + 1) >> 1;
+    const int xlo = xi >> 1, xhi = (xi + 1) >> 1;
+    for (int zo = zlo; zo <= zhi; ++zo) {
+      if (zo >= Do) continue;
+      const int kz = zi - (2 * zo - 1);
+      for (int yo = ylo; yo <= yhi; ++yo) {
+        if (yo >= Ho) continue;
+        const int ky = yi - (2 * yo - 1);
+        for (int xo = xlo; xo <= xhi; ++xo) {
+          if (xo >= Wo) continue;
+          const int kx = xi - (2 * xo - 1);
+          const unsigned char tap = (unsigned char)((kz * 3 + ky) * 3 + kx);
+          const long o = ((((b * Do + zo) * Ho + yo) * Wo + xo) * (long)Q + q);
+          const uchar4 a = reinterpret_cast<const uchar4*>(amax)[o];
+          const float4 g = reinterpret_cast<const float4*>(dy)[o];
+          if (a.x == tap) s.x += g.x;
+          if (a.y == tap) s.y += g.y;
+          if (a.z == tap) s.z += g.z;
+          if (a.w == tap) s.w += g.w;
+        }
+      }
+    }
+    reinterpret_cast<float4*>(dx)[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------ trilinear helpers
+// PyTorch area_pixel_compute_source_index with align_corners=True:
+//   scale = (in-1)/(out-1) (float; 0 when out == 1), src = scale*dst, i0 = (int)src,
+//   i1 = i0 + (i0 < in-1), w1 = src - i0, w0 = 1 - w1.
+__device__ __forceinline__ void lin_src(int dst, float scale, int in, int& i0, int& i1, float& w0, float& w1) {
+  const float s = scale * (float)dst;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  w1 = s - (float)i0;
+  w0 = 1.f - w1;
+}
+
+__global__ void upcat_fwd_kernel(const float* __restrict__ src, const float* __restrict__ skip,
+                                 float* __restrict__ cat, int Ds, int Hs, int Ws, int Cu, int Dk, int Hk, int Wk,
+                                 int Ck, int oz, int oy, int ox, float sz, float sy, float sx, long total4) {
+  const int Do = 2 * Ds, Ho = 2 * Hs, Wo = 2 * Ws;
+  const int Ct = Cu + Ck, Q = Ct >> 2, Qu = Cu >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    long v = i / Q;
+    const int xo = (int)(v % Wo); v /= Wo;
+    const int yo = (int)(v % Ho); v /= Ho;
+    const int zo = (int)(v % Do);
+    const long b = v / Do;
+    float4 o;
+    if (q < Qu) {
+      int z0, z1, y0, y1, x0, x1;
+      float wz0, wz1, wy0, wy1, wx0, wx1;
+      lin_src(zo, sz, Ds, z0, z1, wz0, wz1);
+      lin_src(yo, sy, Hs, y0, y1, wy0, wy1);
+      lin_src(xo, sx, Ws, x0, x1, wx0, wx1);
+      o = make_float4(0.f, 0.f, 0.f, 0.f);
+#define UP_ACC(zz, yy, xx, ww)                                                                                   \
+  {                                                                                                              \
+    const float4 t = *reinterpret_cast<const float4*>(src + ((((b * Ds + zz) * Hs + yy) * Ws + xx) * (long)Cu + 4 * q)); \
+    const float w_ = (ww);                                                                                       \
+    o.x += w_ * t.x; o.y += w_ * t.y; o.z += w_ * t.z; o.w += w_ * t.w;                                          \
+  }
+      // same association as ATen: w0z*(w0y*(w0x*a + w1x*b) + ...) is not reproduced bit-wise; fp32 tolerance
+      UP_ACC(z0, y0, x0, wz0 * wy0 * wx0) UP_ACC(z0, y0, x1, wz0 * wy0 * wx1)
+      UP_ACC(z0, y1, x0, wz0 * wy1 * wx0) UP_ACC(z0, y1, x1, wz0 * wy1 * wx1)
+      UP_ACC(z1, y0, x0, wz1 * wy0 * wx0) UP_ACC(z1, y0, x1, wz1 * wy0 * wx1)
+      UP_ACC(z1, y1, x0, wz1 * wy1 * wx0) UP_ACC(z1, y1, x1, wz1 * wy1 * wx1)
+#undef UP_ACC
+    } else {
+      o = *reinterpret_cast<const float4*>(
+          skip + ((((b * Dk + zo + oz) * Hk + yo + oy) * Wk + xo + ox) * (long)Ck + 4 * (q - Qu)));
+    }
+    reinterpret_cast<float4*>(cat)[i] = o;
+  }
+}
+
+// transposed trilinear as a gather: each source voxel collects from the destination voxels
+// whose interpolation stencil touches it (deterministic, no atomics).
+__device__ __forceinline__ void dst_range(int s, float scale, int out, int& lo, int& hi) {
+  // destinations d with floor(scale*d) in {s-1, s}: conservative bounds, exact test in the loop
+  if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
+  const float inv = 1.f / scale;
+  lo = (int)floorf((float)(s - 1) * inv) - 1;
+  hi = (int)ceilf((float)(s + 1) * inv) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+
+__global__ void upcat_bwd_src_kernel(const float* __restrict__ dcat, float* __restrict__ dsrc, int Ds, int Hs, int Ws,
+                                     int Cu, int Ct, float sz, float sy, float sx, long total4) {
+  const int Do = 2 * Ds, Ho = 2 * Hs, Wo = 2 * Ws;
+  const int Qu = Cu >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Qu);
+    long v = i / Qu;
+    const int xs = (int)(v % Ws); v /= Ws;
+    const int ys = (int)(v % Hs); v /= Hs;
+    const int zs = (int)(v % Ds);
+    const long b = v / Ds;
+    int zlo, zhi, ylo, yhi, xlo, xhi;
+    dst_range(zs, sz, Do, zlo, zhi);
+    dst_range(ys, sy, Ho, ylo, yhi);
+    dst_range(xs, sx, Wo, xlo, xhi);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int zd = zlo; zd <= zhi; ++zd) {
+      int a0, a1; float u0, u1;
+      lin_src(zd, sz, Ds, a0, a1, u0, u1);
+      const float wz = (a0 == zs ? u0 : 0.f) + (a1 == zs ? u1 : 0.f);
+      if (wz == 0.f) continue;
+      for (int yd = ylo; yd <= yhi; ++yd) {
+        lin_src(yd, sy, Hs, a0, a1, u0, u1);
+        const float wy = (a0 == ys ? u0 : 0.f) + (a1 == ys ? u1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int xd = xlo; xd <= xhi; ++xd) {
+          lin_src(xd, sx, Ws, a0, a1, u0, u1);
+          const float wx = (a0 == xs ? u0 : 0.f) + (a1 == xs ? u1 : 0.f);
+          if (wx == 0.f) continue;
+          const float4 g = *reinterpret_cast<const float4*>(dcat + ((((b * Do + zd) * Ho + yd) * Wo + xd) * (long)Ct + 4 * q));
+          const float w_ = wz * wy * wx;
+          acc.x += w_ * g.x; acc.y += w_ * g.y; acc.z += w_ * g.z; acc.w += w_ * g.w;
+        }
+      }
+    }
+    reinterpret_cast<float4*>(dsrc)[i] = acc;
+  }
+}
+
+__global__ void upcat_bwd_skip_kernel(const float* __restrict__ dcat, float* __restrict__ dskip, int Do, int Ho,
+                                      int Wo, int Cu, int Dk, int Hk, int Wk, int Ck, int oz, int oy, int ox,
+                                      long total4) {
+  const int Qk = Ck >> 2;
+  const int Ct = Cu + Ck;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Qk);
+    long v = i / Qk;
+    const int xk = (int)(v % Wk); v /= Wk;
+    const int yk = (int)(v % Hk); v /= Hk;
+    const int zk = (int)(v % Dk);
+    const long b = v / Dk;
+    const int zo = zk - oz, yo = yk - oy, xo = xk - ox;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (zo >= 0 && zo < Do && yo >= 0 && yo < Ho && xo >= 0 && xo < Wo)
+      o = *reinterpret_cast<const float4*>(dcat + ((((b * Do + zo) * Ho + yo) * Wo + xo) * (long)Ct + Cu + 4 * q));
+    reinterpret_cast<float4*>(dskip)[i] = o;
+  }
+}
+
+// predict-time: out = trilinear(dense -> (Do,Ho,Wo), align_corners) * ess ; per-block sums
+__global__ __launch_bounds__(256) void upproject_kernel(const float* __restrict__ dense, const float* __restrict__ ess,
+                                                        float* __restrict__ out, float* __restrict__ partial, int D,
+                                                        int H, int W, int Do, int Ho, int Wo, float sz, float sy,
+                                                        float sx, long vps, int nblk) {
+  __shared__ float sm[4];
+  const int b = blockIdx.y;
+  float s = 0.f;
+  for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < vps; v += (long)gridDim.x * blockDim.x) {
+    long r = v;
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int yo = (int)(r % Ho);
+    const int zo = (int)(r / Ho);
+    int z0, z1, y0, y1, x0, x1;
+    float wz0, wz1, wy0, wy1, wx0, wx1;
+    lin_src(zo, sz, D, z0, z1, wz0, wz1);
+    lin_src(yo, sy, H, y0, y1, wy0, wy1);
+    lin_src(xo, sx, W, x0, x1, wx0, wx1);
+    const float* p = dense + (long)b * D * H * W;
+#define DV(zz, yy, xx) p[((long)(zz) * H + (yy)) * W + (xx)]
+    const float val = wz0 * (wy0 * (wx0 * DV(z0, y0, x0) + wx1 * DV(z0, y0, x1)) + wy1 * (wx0 * DV(z0, y1, x0) + wx1 * DV(z0, y1, x1))) +
+                      wz1 * (wy0 * (wx0 * DV(z1, y0, x0) + wx1 * DV(z1, y0, x1)) + wy1 * (wx0 * DV(z1, y1, x0) + wx1 * DV(z1, y1, x1)));
+#undef DV
+    const float o = val * ess[(long)b * vps + v];
+    out[(long)b * vps + v] = o;
+    s += o;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(long)b * nblk + blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+}  // namespace
+
+extern "C" int dram_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int B, int D, int H, int W, int C,
+                                dram_stream_t stream) {
+  if (!x || !y || !argmax || B < 1 || D < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
+  const int Do = (D + 2 - 3) / 2 + 1, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total4 = (long)B * Do * Ho * Wo * (C >> 2);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, D, H,
+                     W, C, Do, Ho, Wo, total4);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_maxpool_bwd(const float* dy, const uint8_t* argmax, const float* add, float* dx, int B, int D,
+                                int H, int W, int C, dram_stream_t stream) {
+  if (!dy || !dx || !argmax || B < 1 || D < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
+  const int Do = (D + 2 - 3) / 2 + 1, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total4 = (long)B * D * H * W * (C >> 2);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, argmax, add,
+                     dx, D, H, W, C, Do, Ho, Wo, total4);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_upcat_fwd(const float* src, const float* skip, float* cat, int B, int Ds, int Hs, int Ws, int Cu,
+                              int Dk, int Hk, int Wk, int Ck, dram_stream_t stream) {
+  if (!src || !skip || !cat || B < 1 || Cu < 4 || Ck < 4 || (Cu & 3) || (Ck & 3)) return DRAM_ERR_BAD_ARG;
+  const int Do = 2 * Ds, Ho = 2 * Hs, Wo = 2 * Ws;
+  if (Dk < Do || Hk < Ho || Wk < Wo) return DRAM_ERR_BAD_ARG;  // crop_concat_5d assumes t1 <= t2
+  const int oz = (Dk - Do + 1) / 2, oy = (Hk - Ho + 1) / 2, ox = (Wk - Wo + 1) / 2;  // ceil((b-a)/2)
+  const long total4 = (long)B * Do * Ho * Wo * ((Cu + Ck) >> 2);
+  hipLaunchKernelGGL(upcat_fwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, src, skip, cat, Ds,
+                     Hs, Ws, Cu, Dk, Hk, Wk, Ck, oz, oy, ox, ac_scale(Ds, Do), ac_scale(Hs, Ho), ac_scale(Ws, Wo),
+                     total4);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_upcat_bwd(const float* dcat, float* dsrc, float* dskip, int B, int Ds, int Hs, int Ws, int Cu,
+                              int Dk, int Hk, int Wk, int Ck, dram_stream_t stream) {
+  if (!dcat || (!dsrc && !dskip) || B < 1 || Cu < 4 || Ck < 4 || (Cu & 3) || (Ck & 3)) return DRAM_ERR_BAD_ARG;
+  const int Do = 2 * Ds, Ho = 2 * Hs, Wo = 2 * Ws;
+  if (Dk < Do || Hk < Ho || Wk < Wo) return DRAM_ERR_BAD_ARG;
+  const int oz = (Dk - Do + 1) / 2, oy = (Hk - Ho + 1) / 2, ox = (Wk - Wo + 1) / 2;
+  hipStream_t s = (hipStream_t)stream;
+  if (dsrc) {
+    const long total4 = (long)B * Ds * Hs * Ws * (Cu >> 2);
+    hipLaunchKernelGGL(upcat_bwd_src_kernel, dim3(ew_grid(total4)), dim3(256), 0, s, dcat, dsrc, Ds, Hs, Ws, Cu,
+                       Cu + Ck, ac_scale(Ds, Do), ac_scale(Hs, Ho), ac_scale(Ws, Wo), total4);
+    DRAM_LAUNCH_CHECK();
+  }
+  if (dskip) {
+    const long total4 = (long)B * Dk * Hk * Wk * (Ck >> 2);
+    hipLaunchKernelGGL(upcat_bwd_skip_kernel, dim3(ew_grid(total4)), dim3(256), 0, s, dcat, dskip, Do, Ho, Wo, Cu, Dk,
+                       Hk, Wk, Ck, oz, oy, ox, total4);
+    DRAM_LAUNCH_CHECK();
+  }
+  return DRAM_OK;
+}
+
+extern "C" int dram_upproject_nblk(long long vps) {
+  long long b = (vps + 1023) / 1024;
+  return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+
+extern "C" int dram_upproject(const float* dense, const float* ess, float* out, float* partial, int B, int D, int H,
+                              int W, int Do, int Ho, int Wo, dram_stream_t stream) {
+  if (!dense || !ess || !out || !partial || B < 1 || D < 1 || H < 1 || W < 1 || Do < 1 || Ho < 1 || Wo < 1)
+    return DRAM_ERR_BAD_ARG;
+  const long vps = (long)Do * Ho * Wo;
+  const int nblk = dram_upproject_nblk(vps);
+  hipLaunchKernelGGL(upproject_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, dense, ess, out, partial, D, H,
+                     W, Do, Ho, Wo, ac_scale(D, Do), ac_scale(H, Ho), ac_scale(W, Wo), vps, nblk);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}

@@ -1,0 +1,276 @@
+"""Forward / backward executor of the Med3D-ResNet + dRAM decoder on libdram_hip.
+
+This is the host-side "tape": it walks the network of reference med3d.py:270-285 /
+:369-388 layer by layer, launching the hand-written kernels (ops.py) on NDHWC buffers,
+and walks it back for the gradients.  Autograd only sees the whole network as one
+Function (med3d.py of this package); PyTorch provides memory, streams and collectives.
+
+Fusion boundaries
+  conv  -> pre-BN output y + per-tile BN statistics (conv epilogue)
+  BN-apply + residual (identity or detached shortcut-A) + ReLU -> z   (one pass)
+  backward: BN-reduce (1 pass), BN-apply (1 pass), wgrad, dgrad with the identity-
+  shortcut gradient `dz*(z>0)` folded into the dgrad epilogue.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .ops import ConvGeom
+
+Tensor = torch.Tensor
+
+ARCHS = {
+    "resnet18": ("basic", (2, 2, 2, 2)),
+    "resnet34": ("basic", (3, 4, 6, 3)),
+    "resnet50": ("bottleneck", (3, 4, 6, 3)),
+}
+EXPANSION = {"basic": 1, "bottleneck": 4}
+STAGES = ((64, 1, 1), (128, 2, 1), (256, 1, 2), (512, 1, 4))  # planes, stride, dilation (med3d.py:207-213)
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class _State:
+    """Per-call state: parameter/buffer dicts, flags, saved contexts, gradient sink."""
+
+    def __init__(self, P: Dict[str, Tensor], training: bool, need_grad: bool, dist=None):
+        self.P = P
+        self.training = training
+        self.need_grad = need_grad
+        self.dist = dist
+        self.grads: Dict[str, Tensor] = {}
+
+
+class Engine:
+    def __init__(self, net: str, head: str):
+        if net not in ARCHS:
+            raise NotImplementedError(net)
+        if head not in ("cls", "reg"):
+            raise NotImplementedError(head)
+        self.net, self.head = net, head
+        self.kind, self.layers = ARCHS[net]
+        self.e = EXPANSION[self.kind]
+
+    # ------------------------------------------------------------------ BN helpers
+    def _bn_fwd(self, st: _State, y: Tensor, sp: Optional[Tensor], bnp: str, residual, rs, relu=True):
+        P = st.P
+        count = float(y.numel() // y.shape[-1])
+        if st.training:
+            sums = ops.reduce_partials(sp)
+            if st.dist is not None:
+                sums, count = st.dist.sync_bn_stats(sums, count)
+            mean, invstd, scale, shift = ops.bn_finalize(sums, count, P[bnp + ".weight"], P[bnp + ".bias"],
+                                                         P[bnp + ".running_mean"], P[bnp + ".running_var"],
+                                                         BN_MOMENTUM, BN_EPS, True)
+            P[bnp + ".num_batches_tracked"].add_(1)
+        else:
+            mean, invstd, scale, shift = ops.bn_finalize(None, 1.0, P[bnp + ".weight"], P[bnp + ".bias"],
+                                                         P[bnp + ".running_mean"], P[bnp + ".running_var"],
+                                                         BN_MOMENTUM, BN_EPS, False)
+        z = ops.bn_apply(y, scale, shift, residual, rs, relu)
+        return z, mean, invstd, count
+
+    def _bn_bwd(self, st: _State, c: dict, dz: Tensor) -> Tensor:
+        bnp = c["bn"]
+        part = ops.bn_bwd_reduce(dz, c["z"], c["y"], c["mean"], c["invstd"], True)
+        sums = ops.reduce_partials(part)
+        # parameter gradients use the LOCAL sums (DDP averages them afterwards), the input
+        # gradient the all-reduced ones -- torch SyncBatchNorm semantics.
+        st.grads[bnp + ".weight"] = sums[1].float()
+        st.grads[bnp + ".bias"] = sums[0].float()
+        if st.dist is not None:
+            sums = st.dist.all_reduce_sum(sums)
+        return ops.bn_bwd_apply(dz, c["z"], c["y"], c["mean"], c["invstd"], st.P[bnp + ".weight"], sums, c["count"],
+                                True)
+
+    # ------------------------------------------------------------------ conv + BN unit
+    def _conv_bn_fwd(self, st: _State, x: Tensor, wname: str, bname: Optional[str], bnp: str, k: int, stride: int,
+                     pad: int, dil: int, residual=None, rs: int = 1):
+        w = st.P[wname]
+        B, D, H, W, Cin = x.shape
+        g = ConvGeom(B, D, H, W, Cin, w.shape[0], k, stride, pad, dil)
+        wf, wb = ops.pack_conv_weight(w, True, st.need_grad)
+        y, sp = ops.conv3d_fwd(x, wf, st.P[bname] if bname else None, g, st.training)
+        z, mean, invstd, count = self._bn_fwd(st, y, sp, bnp, residual, rs)
+        c = None
+        if st.need_grad:
+            c = dict(x=x, y=y, z=z, mean=mean, invstd=invstd, g=g, wb=wb, count=count, w=wname, b=bname, bn=bnp)
+        return z, c
+
+    def _conv_bn_bwd(self, st: _State, c: dict, dz: Tensor, need_dx=True, add=None, gate=None):
+        dy = self._bn_bwd(st, c, dz)
+        st.grads[c["w"]] = ops.conv3d_bwd_weight(c["x"], dy, c["g"])
+        if c["b"]:
+            st.grads[c["b"]] = ops.reduce_partials(ops.colsum(dy))[0].float()
+        self._grad_ready(st, c)
+        if not need_dx:
+            return None
+        return ops.conv3d_bwd_data(dy, c["wb"], c["g"], add, gate)
+
+    def _grad_ready(self, st: _State, c: dict):
+        if st.dist is not None:
+            names = [c["w"], c["bn"] + ".weight", c["bn"] + ".bias"] + ([c["b"]] if c["b"] else [])
+            st.dist.grads_ready(st.grads, names)
+
+    # ------------------------------------------------------------------ residual blocks
+    def _block_fwd(self, st, x, p, planes, stride, dil, has_ds):
+        e = self.e
+        if self.kind == "basic":
+            z1, c1 = self._conv_bn_fwd(st, x, p + ".conv1.weight", None, p + ".bn1", 3, stride, dil, dil)
+            z2, c2 = self._conv_bn_fwd(st, z1, p + ".conv2.weight", None, p + ".bn2", 3, 1, dil, dil,
+                                       residual=x, rs=stride if has_ds else 1)
+            return z2, (c1, c2, has_ds)
+        z1, c1 = self._conv_bn_fwd(st, x, p + ".conv1.weight", None, p + ".bn1", 1, 1, 0, 1)
+        z2, c2 = self._conv_bn_fwd(st, z1, p + ".conv2.weight", None, p + ".bn2", 3, stride, dil, dil)
+        z3, c3 = self._conv_bn_fwd(st, z2, p + ".conv3.weight", None, p + ".bn3", 1, 1, 0, 1,
+                                   residual=x, rs=stride if has_ds else 1)
+        del e
+        return z3, (c1, c2, c3, has_ds)
+
+    def _block_bwd(self, st, ctx, dz_out, extra_add=None, need_dx=True):
+        """dz_out: gradient w.r.t. the block output (post-ReLU).  Identity shortcut:
+        dx = dgrad(conv1) + dz_out*(z_out>0); shortcut A is detached (med3d.py:110): no term."""
+        *cs, has_ds = ctx
+        last = cs[-1]
+        d = dz_out
+        for c in reversed(cs[1:]):
+            d = self._conv_bn_bwd(st, c, d)
+        if has_ds:
+            return self._conv_bn_bwd(st, cs[0], d, need_dx=need_dx, add=extra_add, gate=None)
+        if extra_add is not None:
+            raise NotImplementedError("extra gradient into an identity-shortcut block")
+        return self._conv_bn_bwd(st, cs[0], d, need_dx=need_dx, add=dz_out, gate=last["z"])
+
+    # ------------------------------------------------------------------ decoder block
+    def _up_fwd(self, st, src, skip, p):
+        cat = ops.upcat_fwd(src, skip)
+        za, ca = self._conv_bn_fwd(st, cat, f"{p}.conv_blocks.0.0.weight", f"{p}.conv_blocks.0.0.bias",
+                                   f"{p}.conv_blocks.0.1", 3, 1, 1, 1)
+        zb, cb = self._conv_bn_fwd(st, za, f"{p}.conv_blocks.1.0.weight", f"{p}.conv_blocks.1.0.bias",
+                                   f"{p}.conv_blocks.1.1", 3, 1, 1, 1)
+        return zb, (ca, cb, tuple(src.shape), tuple(skip.shape))
+
+    def _up_bwd(self, st, ctx, dz):
+        ca, cb, src_shape, skip_shape = ctx
+        dza = self._conv_bn_bwd(st, cb, dz)
+        dcat = self._conv_bn_bwd(st, ca, dza)
+        return ops.upcat_bwd(dcat, src_shape, skip_shape, True, True)
+
+    # ------------------------------------------------------------------ whole network
+    def forward(self, P: Dict[str, Tensor], x: Tensor, lungs: Optional[Tensor], training: bool, need_grad: bool,
+                dist=None):
+        """x [B,1,D,H,W] (NCDHW == NDHW for C=1), lungs None or [B,1,D,H,W] float.
+        Returns (dense_list, outs_list, saved-or-None)."""
+        if need_grad and not training:
+            raise NotImplementedError("gradients through eval-mode BatchNorm are not part of the hot path")
+        st = _State(P, training, need_grad, dist)
+        B, _, D, H, W = x.shape
+        x4 = x.reshape(B, D, H, W)
+        lungs4 = None if lungs is None else lungs.reshape(B, *lungs.shape[-3:]).contiguous()
+
+        y0, sp0 = ops.stem_fwd(x4, P["conv1.weight"], training)
+        xs, mean0, invstd0, count0 = self._bn_fwd(st, y0, sp0, "bn1", None, 1)
+        xp, amax = ops.maxpool_fwd(xs)
+
+        h = xp
+        inplanes = 64
+        block_ctx = []
+        feats = []
+        for li, ((planes, stride, dil), nblk) in enumerate(zip(STAGES, self.layers)):
+            for bi in range(nblk):
+                s = stride if bi == 0 else 1
+                has_ds = bi == 0 and (stride != 1 or inplanes != planes * self.e)
+                h, c = self._block_fwd(st, h, f"layer{li + 1}.{bi}", planes, s, dil, has_ds)
+                block_ctx.append(c)
+                inplanes = planes * self.e
+            feats.append(h)
+        x1, x4f = feats[0], feats[3]
+        xup1, cu1 = self._up_fwd(st, x4f, x1, "us1")
+        xup2, cu2 = self._up_fwd(st, xup1, xs, "us2")
+        xup3, cu3 = self._conv_bn_fwd(st, xup2, "us3.0.weight", "us3.0.bias", "us3.1", 3, 1, 1, 1)
+
+        n0, n1 = P["fcs.0.weight"].shape[0], P["fcs.1.weight"].shape[0]
+        NO = n0 + n1
+        hw = torch.cat([P["fcs.0.weight"].reshape(n0, 32), P["fcs.1.weight"].reshape(n1, 32)], 0).contiguous()
+        hb = torch.cat([P["fcs.0.bias"], P["fcs.1.bias"]], 0).contiguous()
+        sig = self.head == "reg"
+        dense, partial = ops.head_fwd(xup3, hw, hb, lungs4 if sig else None, sig)
+        sums = partial.sum(1)  # [B, NO+1]   (tiny: glue)
+        denom = sums[:, NO]
+        if sig:
+            outs = [sums[:, 0] / denom, sums[:, 1] / denom]
+        else:
+            pooled = sums[:, :NO] / denom[:, None]
+            outs = [pooled[:, :n0].contiguous(), pooled[:, n0:].contiguous()]
+        dense_list = [dense[:, :n0], dense[:, n0:]]
+        saved = None
+        if need_grad:
+            saved = dict(st=st, x4=x4, y0=y0, xs=xs, mean0=mean0, invstd0=invstd0, count0=count0, amax=amax,
+                         blocks=block_ctx, cu1=cu1, cu2=cu2, cu3=cu3, xup3=xup3, hw=hw, dense=dense, lungs4=lungs4,
+                         denom=denom, n0=n0, n1=n1, xs_shape=tuple(xs.shape))
+        return dense_list, outs, saved
+
+    def backward(self, saved: dict, g_dense: List[Optional[Tensor]], g_outs: List[Optional[Tensor]]):
+        st: _State = saved["st"]
+        n0, n1 = saved["n0"], saved["n1"]
+        NO = n0 + n1
+        dense = saved["dense"]
+        B = dense.shape[0]
+        sig = self.head == "reg"
+        dev = dense.device
+        # pooled-score gradient coefficients
+        gpool = torch.zeros((B, NO), device=dev, dtype=torch.float32)
+        denom = saved["denom"]
+        if sig:
+            if g_outs[0] is not None:
+                gpool[:, 0] = g_outs[0] / denom
+            if g_outs[1] is not None:
+                gpool[:, 1] = g_outs[1] / denom
+        else:
+            if g_outs[0] is not None:
+                gpool[:, :n0] = g_outs[0] / denom[:, None]
+            if g_outs[1] is not None:
+                gpool[:, n0:] = g_outs[1] / denom[:, None]
+        gd = None
+        if g_dense[0] is not None or g_dense[1] is not None:
+            gd = torch.zeros_like(dense)
+            if g_dense[0] is not None:
+                gd[:, :n0] = g_dense[0]
+            if g_dense[1] is not None:
+                gd[:, n0:] = g_dense[1]
+        dxup3, wpart = ops.head_bwd(saved["xup3"], saved["hw"], dense if sig else None, gd, gpool,
+                                    saved["lungs4"] if sig else None, sig)
+        wg = ops.reduce_partials(wpart.reshape(wpart.shape[0], 1, NO * 33)).reshape(NO, 33).float()
+        st.grads["fcs.0.weight"] = wg[:n0, :32].reshape(n0, 32, 1, 1, 1).contiguous()
+        st.grads["fcs.0.bias"] = wg[:n0, 32].contiguous()
+        st.grads["fcs.1.weight"] = wg[n0:, :32].reshape(n1, 32, 1, 1, 1).contiguous()
+        st.grads["fcs.1.bias"] = wg[n0:, 32].contiguous()
+        if st.dist is not None:
+            st.dist.grads_ready(st.grads, ["fcs.0.weight", "fcs.0.bias", "fcs.1.weight", "fcs.1.bias"])
+
+        dxup2 = self._conv_bn_bwd(st, saved["cu3"], dxup3)
+        dxup1, dskip_stem = self._up_bwd(st, saved["cu2"], dxup2)
+        d, dskip_x1 = self._up_bwd(st, saved["cu1"], dxup1)
+
+        # walk the residual stages backwards; x1 (end of layer1) also feeds the us1 skip
+        blocks = saved["blocks"]
+        idx = len(blocks)
+        for li in (3, 2, 1, 0):
+            nblk = self.layers[li]
+            for bi in reversed(range(nblk)):
+                idx -= 1
+                extra = dskip_x1 if (li == 1 and bi == 0) else None
+                d = self._block_bwd(st, blocks[idx], d, extra_add=extra)
+        # d = gradient w.r.t. the max-pooled stem output
+        dxs = ops.maxpool_bwd(d, saved["amax"], saved["xs_shape"], dskip_stem)
+        c0 = dict(z=saved["xs"], y=saved["y0"], mean=saved["mean0"], invstd=saved["invstd0"], count=saved["count0"],
+                  bn="bn1")
+        dy0 = self._bn_bwd(st, c0, dxs)
+        st.grads["conv1.weight"] = ops.stem_bwd_weight(saved["x4"], dy0)
+        if st.dist is not None:
+            st.dist.grads_ready(st.grads, ["conv1.weight", "bn1.weight", "bn1.bias"])
+            st.dist.finish(st.grads)
+        return st.grads

@@ -1,0 +1,442 @@
+"""Tensor-level wrappers over the C ABI (include/dram_hip.h).
+
+PyTorch is used here for device memory (``torch.empty``) and the current HIP stream
+only; every computation is a hand-written kernel in libdram_hip.so.  Each wrapper
+validates on the host that operand shapes/dtypes match what the kernel and its grid
+assume *before* launching (a faulting kernel can reset the whole GPU host).
+
+Activations are NDHWC float32: ``[B, D, H, W, C]``.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import DramConvDesc
+
+Tensor = torch.Tensor
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(rc: int, name: str):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with code {rc}")
+
+
+def _req(t: Tensor, name: str, dtype=torch.float32, shape=None):
+    if not isinstance(t, Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a device tensor (libdram_hip has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+@dataclass(frozen=True)
+class ConvGeom:
+    """Forward-sense geometry of one convolution call."""
+    B: int
+    D: int
+    H: int
+    W: int
+    Cin: int
+    Cout: int
+    k: int
+    stride: int
+    pad: int
+    dil: int
+
+    def out(self, n: int) -> int:
+        return (n + 2 * self.pad - (self.dil * (self.k - 1) + 1)) // self.stride + 1
+
+    @property
+    def Do(self):
+        return self.out(self.D)
+
+    @property
+    def Ho(self):
+        return self.out(self.H)
+
+    @property
+    def Wo(self):
+        return self.out(self.W)
+
+    @property
+    def taps(self):
+        return self.k ** 3
+
+    @property
+    def in_shape(self):
+        return (self.B, self.D, self.H, self.W, self.Cin)
+
+    @property
+    def out_shape(self):
+        return (self.B, self.Do, self.Ho, self.Wo, self.Cout)
+
+    def desc(self) -> DramConvDesc:
+        return DramConvDesc(self.B, self.D, self.H, self.W, self.Cin, self.Do, self.Ho, self.Wo, self.Cout,
+                            self.k, self.stride, self.pad, self.dil)
+
+
+# --------------------------------------------------------------------------- conv
+def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """[Cout,Cin,k,k,k] -> wf [taps,Cout,Cin], wb [taps,Cin,Cout]."""
+    _req(w, "w")
+    Cout, Cin = w.shape[0], w.shape[1]
+    taps = w.shape[2] * w.shape[3] * w.shape[4]
+    wf = torch.empty((taps, Cout, Cin), device=w.device, dtype=torch.float32) if want_fwd else None
+    wb = torch.empty((taps, Cin, Cout), device=w.device, dtype=torch.float32) if want_bwd else None
+    _chk(_L().dram_pack_conv_weight(_p(w), _p(wf), _p(wb), Cout, Cin, taps, _stream()), "dram_pack_conv_weight")
+    return wf, wb
+
+
+def conv3d_fwd(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, want_stats: bool):
+    _req(x, "x", shape=g.in_shape)
+    _req(wf, "wf", shape=(g.taps, g.Cout, g.Cin))
+    if bias is not None:
+        _req(bias, "bias", shape=(g.Cout,))
+    d = g.desc()
+    y = torch.empty(g.out_shape, device=x.device, dtype=torch.float32)
+    stats = None
+    if want_stats:
+        nt = _L().dram_conv_num_mtiles(ctypes.byref(d))
+        if nt <= 0:
+            raise RuntimeError(f"dram_conv_num_mtiles rejected {g}")
+        stats = torch.empty((nt, 2, g.Cout), device=x.device, dtype=torch.float32)
+    _chk(_L().dram_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), ctypes.byref(d), _stream()),
+         f"dram_conv3d_fwd{g}")
+    return y, stats
+
+
+def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] = None,
+                    gate: Optional[Tensor] = None) -> Tensor:
+    _req(dy, "dy", shape=g.out_shape)
+    _req(wb, "wb", shape=(g.taps, g.Cin, g.Cout))
+    if add is not None:
+        _req(add, "add", shape=g.in_shape)
+    if gate is not None:
+        _req(gate, "gate", shape=g.in_shape)
+    d = g.desc()
+    dx = torch.empty(g.in_shape, device=dy.device, dtype=torch.float32)
+    _chk(_L().dram_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d), _stream()),
+         f"dram_conv3d_bwd_data{g}")
+    return dx
+
+
+def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] = None) -> Tensor:
+    _req(x, "x", shape=g.in_shape)
+    _req(dy, "dy", shape=g.out_shape)
+    d = g.desc()
+    nbytes = _L().dram_conv3d_bwd_weight_workspace(ctypes.byref(d))
+    if nbytes == 0:
+        raise RuntimeError(f"dram_conv3d_bwd_weight: unsupported geometry {g}")
+    ws = torch.empty(((nbytes + 3) // 4,), device=x.device, dtype=torch.float32)
+    shape = (g.Cout, g.Cin, g.k, g.k, g.k)
+    dw = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
+    _req(dw, "dw", shape=shape)
+    _chk(_L().dram_conv3d_bwd_weight(_p(x), _p(dy), _p(dw), ctypes.byref(d), _p(ws), nbytes, _stream()),
+         f"dram_conv3d_bwd_weight{g}")
+    return dw
+
+
+# --------------------------------------------------------------------------- stem
+def stem_out(n: int) -> int:
+    return (n + 6 - 7) // 2 + 1
+
+
+def stem_fwd(x: Tensor, w: Tensor, want_stats: bool):
+    """x [B,D,H,W] (C=1), w [64,1,7,7,7] -> y [B,Do,Ho,Wo,64]."""
+    _req(x, "x")
+    if x.dim() != 4:
+        raise ValueError("stem_fwd: x must be [B,D,H,W]")
+    _req(w, "w", shape=(64, 1, 7, 7, 7))
+    B, D, H, W = x.shape
+    Do, Ho, Wo = stem_out(D), stem_out(H), stem_out(W)
+    y = torch.empty((B, Do, Ho, Wo, 64), device=x.device, dtype=torch.float32)
+    stats = None
+    if want_stats:
+        nt = _L().dram_stem_num_tiles(B, Do, Ho, Wo)
+        stats = torch.empty((nt, 2, 64), device=x.device, dtype=torch.float32)
+    _chk(_L().dram_stem_fwd(_p(x), _p(w), _p(y), _p(stats), B, D, H, W, _stream()), "dram_stem_fwd")
+    return y, stats
+
+
+def stem_bwd_weight(x: Tensor, dy: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    _req(x, "x")
+    B, D, H, W = x.shape
+    _req(dy, "dy", shape=(B, stem_out(D), stem_out(H), stem_out(W), 64))
+    nbytes = _L().dram_stem_bwd_weight_workspace(B, D, H, W)
+    ws = torch.empty(((nbytes + 3) // 4,), device=x.device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty((64, 1, 7, 7, 7), device=x.device, dtype=torch.float32)
+    _req(dw, "dw", shape=(64, 1, 7, 7, 7))
+    _chk(_L().dram_stem_bwd_weight(_p(x), _p(dy), _p(dw), B, D, H, W, _p(ws), nbytes, _stream()),
+         "dram_stem_bwd_weight")
+    return dw
+
+
+# --------------------------------------------------------------------------- batch norm
+def reduce_partials(partial: Tensor) -> Tensor:
+    """[P,R,C] float32 -> [R,C] float64."""
+    _req(partial, "partial")
+    Pn, R, C = partial.shape
+    sums = torch.empty((R, C), device=partial.device, dtype=torch.float64)
+    _chk(_L().dram_reduce_partials(_p(partial), _p(sums), Pn, R, C, _stream()), "dram_reduce_partials")
+    return sums
+
+
+def bn_finalize(sums: Optional[Tensor], count: float, gamma: Tensor, beta: Tensor, running_mean: Tensor,
+                running_var: Tensor, momentum: float, eps: float, update_running: bool):
+    C = gamma.numel()
+    _req(gamma, "gamma", shape=(C,))
+    _req(beta, "beta", shape=(C,))
+    _req(running_mean, "running_mean", shape=(C,))
+    _req(running_var, "running_var", shape=(C,))
+    if sums is not None:
+        _req(sums, "sums", dtype=torch.float64, shape=(2, C))
+    out = torch.empty((4, C), device=gamma.device, dtype=torch.float32)
+    mean, invstd, scale, shift = out[0], out[1], out[2], out[3]
+    _chk(_L().dram_bn_finalize(_p(sums), float(count), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                               float(momentum), float(eps), int(update_running), _p(mean), _p(invstd), _p(scale),
+                               _p(shift), C, _stream()), "dram_bn_finalize")
+    return mean, invstd, scale, shift
+
+
+def bn_apply(y: Tensor, scale: Tensor, shift: Tensor, residual: Optional[Tensor], rs: int, relu: bool) -> Tensor:
+    _req(y, "y")
+    B, D, H, W, C = y.shape
+    _req(scale, "scale", shape=(C,))
+    _req(shift, "shift", shape=(C,))
+    Dr = Hr = Wr = Cr = 0
+    if residual is not None:
+        _req(residual, "residual")
+        if residual.shape[0] != B:
+            raise ValueError("bn_apply: residual batch mismatch")
+        _, Dr, Hr, Wr, Cr = residual.shape
+        if Cr > C or (D - 1) * rs >= Dr or (H - 1) * rs >= Hr or (W - 1) * rs >= Wr:
+            raise ValueError(f"bn_apply: residual {tuple(residual.shape)} incompatible with {tuple(y.shape)} rs={rs}")
+        # F.avg_pool3d(kernel_size=1, stride=rs) output size must equal ours
+        if ((Dr - 1) // rs + 1, (Hr - 1) // rs + 1, (Wr - 1) // rs + 1) != (D, H, W):
+            raise ValueError("bn_apply: strided residual does not match the output grid")
+    z = torch.empty_like(y)
+    _chk(_L().dram_bn_apply(_p(y), _p(scale), _p(shift), _p(residual), Dr, Hr, Wr, Cr, rs, _p(z), B, D, H, W, C,
+                            int(relu), _stream()), "dram_bn_apply")
+    return z
+
+
+def _rows(t: Tensor) -> int:
+    return t.numel() // t.shape[-1]
+
+
+def bn_bwd_reduce(dz: Tensor, z: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, relu: bool) -> Tensor:
+    _req(dz, "dz", shape=y.shape)
+    _req(y, "y")
+    if relu:
+        _req(z, "z", shape=y.shape)
+    C = y.shape[-1]
+    _req(mean, "mean", shape=(C,))
+    _req(invstd, "invstd", shape=(C,))
+    rows = _rows(y)
+    nparts = _L().dram_colsum_nparts(rows, C)
+    partial = torch.empty((nparts, 2, C), device=y.device, dtype=torch.float32)
+    _chk(_L().dram_bn_bwd_reduce(_p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(partial), rows, C, int(relu),
+                                 _stream()), "dram_bn_bwd_reduce")
+    return partial
+
+
+def bn_bwd_apply(dz: Tensor, z: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, sums: Tensor,
+                 count: float, relu: bool) -> Tensor:
+    C = y.shape[-1]
+    _req(dz, "dz", shape=y.shape)
+    _req(sums, "sums", dtype=torch.float64, shape=(2, C))
+    _req(gamma, "gamma", shape=(C,))
+    dy = torch.empty_like(y)
+    _chk(_L().dram_bn_bwd_apply(_p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums), float(count), _p(dy),
+                                _rows(y), C, int(relu), _stream()), "dram_bn_bwd_apply")
+    return dy
+
+
+def colsum(a: Tensor) -> Tensor:
+    """[..., C] -> partial [P,1,C]."""
+    _req(a, "a")
+    C = a.shape[-1]
+    rows = _rows(a)
+    nparts = _L().dram_colsum_nparts(rows, C)
+    partial = torch.empty((nparts, 1, C), device=a.device, dtype=torch.float32)
+    _chk(_L().dram_colsum(_p(a), _p(partial), rows, C, _stream()), "dram_colsum")
+    return partial
+
+
+def add(a: Tensor, b: Tensor) -> Tensor:
+    _req(a, "a")
+    _req(b, "b", shape=a.shape)
+    out = torch.empty_like(a)
+    _chk(_L().dram_add(_p(a), _p(b), _p(out), a.numel(), _stream()), "dram_add")
+    return out
+
+
+# --------------------------------------------------------------------------- pool / up-projection
+def pool_out(n: int) -> int:
+    return (n + 2 - 3) // 2 + 1
+
+
+def maxpool_fwd(x: Tensor):
+    _req(x, "x")
+    B, D, H, W, C = x.shape
+    shape = (B, pool_out(D), pool_out(H), pool_out(W), C)
+    y = torch.empty(shape, device=x.device, dtype=torch.float32)
+    am = torch.empty(shape, device=x.device, dtype=torch.uint8)
+    _chk(_L().dram_maxpool_fwd(_p(x), _p(y), _p(am), B, D, H, W, C, _stream()), "dram_maxpool_fwd")
+    return y, am
+
+
+def maxpool_bwd(dy: Tensor, argmax: Tensor, in_shape, add_: Optional[Tensor] = None) -> Tensor:
+    B, D, H, W, C = in_shape
+    oshape = (B, pool_out(D), pool_out(H), pool_out(W), C)
+    _req(dy, "dy", shape=oshape)
+    _req(argmax, "argmax", dtype=torch.uint8, shape=oshape)
+    if add_ is not None:
+        _req(add_, "add", shape=in_shape)
+    dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
+    _chk(_L().dram_maxpool_bwd(_p(dy), _p(argmax), _p(add_), _p(dx), B, D, H, W, C, _stream()), "dram_maxpool_bwd")
+    return dx
+
+
+def upcat_fwd(src: Tensor, skip: Tensor) -> Tensor:
+    _req(src, "src")
+    _req(skip, "skip")
+    B, Ds, Hs, Ws, Cu = src.shape
+    Bk, Dk, Hk, Wk, Ck = skip.shape
+    if Bk != B or Dk < 2 * Ds or Hk < 2 * Hs or Wk < 2 * Ws:
+        raise ValueError(f"upcat_fwd: skip {tuple(skip.shape)} smaller than upsampled {tuple(src.shape)}")
+    cat = torch.empty((B, 2 * Ds, 2 * Hs, 2 * Ws, Cu + Ck), device=src.device, dtype=torch.float32)
+    _chk(_L().dram_upcat_fwd(_p(src), _p(skip), _p(cat), B, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck, _stream()),
+         "dram_upcat_fwd")
+    return cat
+
+
+def upcat_bwd(dcat: Tensor, src_shape, skip_shape, need_src=True, need_skip=True):
+    B, Ds, Hs, Ws, Cu = src_shape
+    _, Dk, Hk, Wk, Ck = skip_shape
+    _req(dcat, "dcat", shape=(B, 2 * Ds, 2 * Hs, 2 * Ws, Cu + Ck))
+    dsrc = torch.empty(src_shape, device=dcat.device, dtype=torch.float32) if need_src else None
+    dskip = torch.empty(skip_shape, device=dcat.device, dtype=torch.float32) if need_skip else None
+    _chk(_L().dram_upcat_bwd(_p(dcat), _p(dsrc), _p(dskip), B, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck, _stream()),
+         "dram_upcat_bwd")
+    return dsrc, dskip
+
+
+def upproject(dense: Tensor, ess: Tensor, size):
+    """dense [B,D,H,W] -> out [B,Do,Ho,Wo] = trilinear(align_corners)(dense)*ess, partial [B,nblk]."""
+    _req(dense, "dense")
+    B, D, H, W = dense.shape
+    Do, Ho, Wo = size
+    _req(ess, "ess", shape=(B, Do, Ho, Wo))
+    nblk = _L().dram_upproject_nblk(Do * Ho * Wo)
+    out = torch.empty((B, Do, Ho, Wo), device=dense.device, dtype=torch.float32)
+    partial = torch.empty((B, nblk), device=dense.device, dtype=torch.float32)
+    _chk(_L().dram_upproject(_p(dense), _p(ess), _p(out), _p(partial), B, D, H, W, Do, Ho, Wo, _stream()),
+         "dram_upproject")
+    return out, partial
+
+
+# --------------------------------------------------------------------------- heads / losses
+def head_fwd(x: Tensor, w: Tensor, bias: Tensor, lungs: Optional[Tensor], sigmoid: bool):
+    """x [B,D,H,W,32]; w [NO,32]; lungs None or [B,Dl,Hl,Wl] full-res mask."""
+    _req(x, "x")
+    B, D, H, W, C = x.shape
+    if C != 32:
+        raise ValueError("head_fwd: the head consumes the 32-channel us3 output")
+    NO = w.shape[0]
+    _req(w, "w", shape=(NO, 32))
+    _req(bias, "bias", shape=(NO,))
+    Dl = Hl = Wl = 0
+    if lungs is not None:
+        _req(lungs, "lungs")
+        if lungs.dim() != 4 or lungs.shape[0] != B:
+            raise ValueError("head_fwd: lungs must be [B,Dl,Hl,Wl]")
+        _, Dl, Hl, Wl = lungs.shape
+    nblk = _L().dram_head_nblk(D * H * W)
+    dense = torch.empty((B, NO, D, H, W), device=x.device, dtype=torch.float32)
+    partial = torch.empty((B, nblk, NO + 1), device=x.device, dtype=torch.float32)
+    _chk(_L().dram_head_fwd(_p(x), _p(w), _p(bias), _p(lungs), Dl, Hl, Wl, _p(dense), _p(partial), B, D, H, W, NO,
+                            int(sigmoid), _stream()), "dram_head_fwd")
+    return dense, partial
+
+
+def head_bwd(x: Tensor, w: Tensor, dense: Optional[Tensor], gdense: Optional[Tensor], gpool: Tensor,
+             lungs: Optional[Tensor], sigmoid: bool):
+    _req(x, "x")
+    B, D, H, W, C = x.shape
+    NO = w.shape[0]
+    _req(w, "w", shape=(NO, 32))
+    _req(gpool, "gpool", shape=(B, NO))
+    if dense is not None:
+        _req(dense, "dense", shape=(B, NO, D, H, W))
+    if gdense is not None:
+        _req(gdense, "gdense", shape=(B, NO, D, H, W))
+    Dl = Hl = Wl = 0
+    if lungs is not None:
+        _req(lungs, "lungs")
+        _, Dl, Hl, Wl = lungs.shape
+    nparts = _L().dram_head_bwd_nparts(D * H * W)
+    dx = torch.empty_like(x)
+    wpartial = torch.empty((B * nparts, NO, 33), device=x.device, dtype=torch.float32)
+    _chk(_L().dram_head_bwd(_p(x), _p(w), _p(dense), _p(gdense), _p(gpool), _p(lungs), Dl, Hl, Wl, _p(dx),
+                            _p(wpartial), B, D, H, W, NO, int(sigmoid), _stream()), "dram_head_bwd")
+    return dx, wpartial
+
+
+def segloss_fwd(cle: Tensor, pse: Tensor, lungs: Tensor, ems: Tensor, binary: Tensor) -> Tensor:
+    """cle/pse [B,D,H,W]; lungs/ems [B,Dl,Hl,Wl]; binary [B] -> partial [nblk,6]."""
+    _req(cle, "cle")
+    B, D, H, W = cle.shape
+    _req(pse, "pse", shape=cle.shape)
+    _req(lungs, "lungs")
+    _req(ems, "ems", shape=lungs.shape)
+    _req(binary, "binary", shape=(B,))
+    _, Dl, Hl, Wl = lungs.shape
+    nblk = _L().dram_segloss_nblk(B * D * H * W)
+    partial = torch.empty((nblk, 6), device=cle.device, dtype=torch.float32)
+    _chk(_L().dram_segloss_fwd(_p(cle), _p(pse), _p(lungs), _p(ems), _p(binary), Dl, Hl, Wl, _p(partial), B, D, H, W,
+                               _stream()), "dram_segloss_fwd")
+    return partial
+
+
+def segloss_bwd(cle: Tensor, pse: Tensor, lungs: Tensor, ems: Tensor, binary: Tensor, coef: Tensor):
+    B, D, H, W = cle.shape
+    _req(coef, "coef", shape=(8,))
+    _, Dl, Hl, Wl = lungs.shape
+    gcle = torch.empty_like(cle)
+    gpse = torch.empty_like(pse)
+    _chk(_L().dram_segloss_bwd(_p(cle), _p(pse), _p(lungs), _p(ems), _p(binary), Dl, Hl, Wl, _p(coef), _p(gcle),
+                               _p(gpse), B, D, H, W, _stream()), "dram_segloss_bwd")
+    return gcle, gpse
+
+
+# --------------------------------------------------------------------------- optimizer
+def adam_multi(table: Tensor, chunks: Tensor, nchunks: int, lr, b1, b2, eps, wd, bc1, bc2, grad_scale):
+    _chk(_L().dram_adam_multi(_p(table), _p(chunks), nchunks, lr, b1, b2, eps, wd, bc1, bc2, grad_scale, _stream()),
+         "dram_adam_multi")
+
+
+def sgd_multi(table: Tensor, chunks: Tensor, nchunks: int, lr, momentum, wd, first_step, grad_scale):
+    _chk(_L().dram_sgd_multi(_p(table), _p(chunks), nchunks, lr, momentum, wd, int(first_step), grad_scale,
+                             _stream()), "dram_sgd_multi")

@@ -1,0 +1,228 @@
+/* dram_hip.h -- C ABI of libdram_hip.so (MI355X / gfx950 hand-written HIP kernels).
+ *
+ * The reference has no FFI of its own: its hot path is torch-op call sites inside
+ * med3d.py / models.py / metrics.py.  Each entry point below
+ * replaces the cuDNN/ATen kernels behind one family of those call sites; the
+ * reference file:line each one stands in for is cited on the declaration.
+ *
+ * Conventions
+ *  - Activations are NDHWC ("channels-last-3D") contiguous float32:
+ *      x[b][z][y][x][c], element offset ((((b*D+z)*H+y)*W+x)*C+c).
+ *    The reference uses NCDHW; for C == 1 (network input, lung masks, regression
+ *    dRAM maps) the two layouts are the same bytes.
+ *  - Convolution weights cross the ABI in the reference's own layout
+ *    [Cout][Cin][kD][kH][kW] (state_dict contract); packed copies
+ *    are produced by dram_pack_conv_weight.
+ *  - Every function enqueues on `stream` and never synchronises, allocates or frees.
+ *    The caller owns all buffers including workspaces.
+ *  - Return value: 0 on success, DRAM_ERR_* (<0) on a rejected argument, or a
+ *    positive hipError_t from the launch.  Nothing is thrown across the ABI.
+ */
+#ifndef DRAM_HIP_H
+#define DRAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dram_stream_t; /* hipStream_t */
+
+#define DRAM_OK 0
+#define DRAM_ERR_BAD_ARG (-1)
+#define DRAM_ERR_UNSUPPORTED (-2)
+#define DRAM_ERR_WORKSPACE (-3)
+
+#define DRAM_ABI_VERSION 1
+int dram_version(void);
+/* static string: "gfx950" build tag */
+const char* dram_build_info(void);
+
+/* ------------------------------------------------------------------------- */
+/* Convolution geometry (isotropic stride / padding / dilation, cubic kernel). */
+typedef struct DramConvDesc {
+  int32_t B;             /* batch */
+  int32_t D, H, W, Cin;  /* input  (forward sense) */
+  int32_t Do, Ho, Wo, Cout; /* output (forward sense) */
+  int32_t k;             /* kernel edge: 1 or 3 (7 only via dram_stem_*) */
+  int32_t stride, pad, dil;
+} DramConvDesc;
+
+/* Repack [Cout][Cin][k^3] -> wf[tap][Cout][Cin] (forward B-operand, K=Cin contiguous)
+ * and wb[tap][Cin][Cout] (data-gradient B-operand).  Either output may be NULL. */
+int dram_pack_conv_weight(const float* w, float* wf, float* wb, int Cout, int Cin, int taps,
+                          dram_stream_t stream);
+
+/* Forward 3x3x3 / 1x1x1 convolution as an LDS-tiled fp32-MFMA implicit GEMM.
+ * Replaces nn.Conv3d at med3d.py:91-100 (conv3x3x3), :152-157 (Bottleneck), :67/:76
+ * (decoder, with bias), :226/:325 (us3).
+ *   x  [B,D,H,W,Cin]   wf packed [k^3][Cout][Cin]   bias [Cout] or NULL
+ *   y  [B,Do,Ho,Wo,Cout] (pre-BatchNorm output)
+ *   stats_partial: NULL, or [dram_conv_num_mtiles(desc)][2][Cout] -- per-M-tile
+ *     sum(y) and sum(y*y) per channel (BatchNorm batch statistics, fused epilogue). */
+int dram_conv3d_fwd(const float* x, const float* wf, const float* bias, float* y,
+                    float* stats_partial, const DramConvDesc* desc, dram_stream_t stream);
+
+/* Data gradient: dx[B,D,H,W,Cin] = conv^T(dy[B,Do,Ho,Wo,Cout], w); wb packed [k^3][Cin][Cout].
+ * Optional fused epilogue: dx += add * (gate > 0)   (gate NULL => dx += add); both
+ * shaped like dx.  This is the identity-shortcut gradient of med3d.py:141-142/:181-182.
+ * Replaces autograd's convolution_backward (input) for the call sites above. */
+int dram_conv3d_bwd_data(const float* dy, const float* wb, float* dx, const float* add,
+                         const float* gate, const DramConvDesc* desc, dram_stream_t stream);
+
+/* Weight gradient.  dw is written in the reference layout [Cout][Cin][k^3].
+ * workspace: split-K slabs, size from dram_conv3d_bwd_weight_workspace().
+ * Deterministic (slab + ordered reduce, no float atomics). */
+size_t dram_conv3d_bwd_weight_workspace(const DramConvDesc* desc);
+int dram_conv3d_bwd_weight(const float* x, const float* dy, float* dw, const DramConvDesc* desc,
+                           void* workspace, size_t workspace_bytes, dram_stream_t stream);
+
+/* number of M tiles (rows of stats_partial) dram_conv3d_fwd produces for desc */
+int dram_conv_num_mtiles(const DramConvDesc* desc);
+
+/* ------------------------------------------------------------------------- */
+/* Stem: Conv3d(1,64,k=7,s=2,p=3,bias=False)  (med3d.py:196-202 / :296-302).
+ *   x [B,D,H,W] (C=1), w [64][1][7][7][7], y [B,Do,Ho,Wo,64], Do=(D+6-7)/2+1 ...
+ *   stats_partial [dram_stem_num_tiles][2][64] or NULL. */
+int dram_stem_num_tiles(int B, int Do, int Ho, int Wo);
+int dram_stem_fwd(const float* x, const float* w, float* y, float* stats_partial, int B, int D, int H,
+                  int W, dram_stream_t stream);
+size_t dram_stem_bwd_weight_workspace(int B, int D, int H, int W);
+int dram_stem_bwd_weight(const float* x, const float* dy, float* dw, int B, int D, int H, int W,
+                         void* workspace, size_t workspace_bytes, dram_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* BatchNorm3d (+ReLU, + residual) -- med3d.py:121-124,133-142,153-182,203-204,227-228.
+ *
+ * dram_reduce_partials: sums[r][c] (double) = sum_p partial[p][r][c], r < R.
+ *   Used for the BN statistics, BN-backward sums and bias gradients.  In DDP the
+ *   caller all-reduces `sums` (SyncBatchNorm, train.py:101) before finalising. */
+int dram_reduce_partials(const float* partial, double* sums, int nparts, int R, int C,
+                         dram_stream_t stream);
+
+/* training: mean/var from sums[2][C] over `count` elements per channel;
+ * eval (sums == NULL): running stats.  Writes mean, invstd, scale = gamma*invstd,
+ * shift = beta - mean*scale; when update_running != 0 also
+ * running = (1-momentum)*running + momentum*{mean, unbiased var}. */
+int dram_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps,
+                     int update_running, float* mean, float* invstd, float* scale, float* shift,
+                     int C, dram_stream_t stream);
+
+/* z = act(y*scale[c] + shift[c] + residual).  residual: NULL, or a tensor
+ * [B,Dr,Hr,Wr,Cr] sampled at (z*rs, y*rs, x*rs) with channels >= Cr reading 0 --
+ * identity shortcut (rs=1, same shape) or shortcut type A (med3d.py:103-112, strided
+ * subsample + zero channel pad).  relu != 0 => max(0,.) */
+int dram_bn_apply(const float* y, const float* scale, const float* shift, const float* residual,
+                  int Dr, int Hr, int Wr, int Cr, int rs, float* z, int B, int D, int H, int W, int C,
+                  int relu, dram_stream_t stream);
+
+/* Backward, phase 1: g = dz * (z > 0) (relu != 0) ; partial[p][0][c] = sum g,
+ * partial[p][1][c] = sum g * xhat, xhat = (y-mean)*invstd.  nparts from dram_colsum_nparts. */
+int dram_colsum_nparts(long long rows, int C);
+int dram_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean,
+                       const float* invstd, float* partial, long long rows, int C, int relu,
+                       dram_stream_t stream);
+/* phase 2: dy = gamma*invstd*(g - sums[0]/count - xhat*sums[1]/count) */
+int dram_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* mean,
+                      const float* invstd, const float* gamma, const double* sums, double count,
+                      float* dy, long long rows, int C, int relu, dram_stream_t stream);
+/* partial[p][0][c] = sum_rows a[row][c]  (conv-bias gradient) */
+int dram_colsum(const float* a, float* partial, long long rows, int C, dram_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* MaxPool3d(k=3,s=2,p=1) -- med3d.py:206/:275.  argmax: uint8 tap index (first max
+ * wins, scan order kd,kh,kw like ATen).  Backward is a gather (deterministic);
+ * dx = maxpool^T(dy) (+ add if not NULL). */
+int dram_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int B, int D, int H, int W, int C,
+                     dram_stream_t stream);
+int dram_maxpool_bwd(const float* dy, const uint8_t* argmax, const float* add, float* dx, int B, int D,
+                     int H, int W, int C, dram_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* dRAM up-projection inside the decoder: nn.Upsample(x2, trilinear, align_corners=True)
+ * + crop_concat_5d -- med3d.py:83-87, :39-48.
+ *   src  [B,Ds,Hs,Ws,Cu]  -> upsampled to (2Ds,2Hs,2Ws)
+ *   skip [B,Dk,Hk,Wk,Ck]  centre-cropped to the upsampled size
+ *   cat  [B,2Ds,2Hs,2Ws,Cu+Ck]  (upsampled channels FIRST) */
+int dram_upcat_fwd(const float* src, const float* skip, float* cat, int B, int Ds, int Hs, int Ws, int Cu,
+                   int Dk, int Hk, int Wk, int Ck, dram_stream_t stream);
+/* dsrc = upsample^T(dcat[..., :Cu]);  dskip (full skip shape, zero outside the crop)
+ * = dcat[..., Cu:].  Either output may be NULL. */
+int dram_upcat_bwd(const float* dcat, float* dsrc, float* dskip, int B, int Ds, int Hs, int Ws, int Cu,
+                   int Dk, int Hk, int Wk, int Ck, dram_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* Heads -- med3d.py:283-284 (cls) / :382-387 (reg).
+ *   x [B,D,H,W,32]; w [NO][32], bias [NO]  (fcs.0 and fcs.1 stacked: NO = 6+3 or 1+1)
+ *   dense [B][NO][D*H*W]  (planar == the reference's NCDHW per head)
+ *   sigmoid != 0: dense = sigmoid(.) and pooled sums are lung-weighted:
+ *     lungs: NULL (=> ones) or the FULL-RES mask [B,Dl,Hl,Wl], sampled nearest
+ *     (F.interpolate(mode='nearest'), med3d.py:386).
+ *   partial [B][nblk][NO+1]: per-block sum(dense*L) per output, and sum(L) last. */
+int dram_head_nblk(long long voxels_per_sample);
+int dram_head_fwd(const float* x, const float* w, const float* bias, const float* lungs, int Dl, int Hl,
+                  int Wl, float* dense, float* partial, int B, int D, int H, int W, int NO, int sigmoid,
+                  dram_stream_t stream);
+/* backward: dpre[c] = (gdense[b][c][v] + gpool[b][c]*L[v]) * (sigmoid ? s(1-s) : 1)
+ *   gdense may be NULL.  dx [B,D,H,W,32] = sum_c w[c][:] dpre[c];
+ *   wpartial [B*nparts][NO][33]: per-block sum dpre[c]*x[k] (k<32) and sum dpre[c] (k=32);
+ *   nparts = dram_head_bwd_nparts(D*H*W) blocks per sample. */
+int dram_head_bwd_nparts(long long voxels_per_sample);
+int dram_head_bwd(const float* x, const float* w, const float* dense, const float* gdense,
+                  const float* gpool, const float* lungs, int Dl, int Hl, int Wl, float* dx,
+                  float* wpartial, int B, int D, int H, int W, int NO, int sigmoid, dram_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* dRAM segmentation losses -- models.py:523-531 + metrics.py:10-37, label prep
+ * models.py:567-570.  cle/pse: [B,1,D,H,W] dense maps; lungs/ems: full-res masks
+ * [B,Dl,Hl,Wl] sampled nearest; binary[b] in {0,1} multiplies ems.
+ *   partial [nblk][6]: sum t, A1, A0, I, S1, S2 (see csrc/loss.hip). */
+int dram_segloss_nblk(long long voxels_total);
+int dram_segloss_fwd(const float* cle, const float* pse, const float* lungs, const float* ems,
+                     const float* binary, int Dl, int Hl, int Wl, float* partial, int B, int D, int H,
+                     int W, dram_stream_t stream);
+/* coef[8] (device): c_dice_a, c_dice_b, c_bce1, c_bce0, -, -, -, - (see loss.hip) */
+int dram_segloss_bwd(const float* cle, const float* pse, const float* lungs, const float* ems,
+                     const float* binary, int Dl, int Hl, int Wl, const float* coef, float* gcle,
+                     float* gpse, int B, int D, int H, int W, dram_stream_t stream);
+
+/* Predict-time up-projection (models.py:438-441): out = trilinear(dense -> Do,Ho,Wo,
+ * align_corners) * ess; partial [B][nblk] per-block sums of out. */
+int dram_upproject_nblk(long long voxels_per_sample);
+int dram_upproject(const float* dense, const float* ess, float* out, float* partial, int B, int D, int H,
+                   int W, int Do, int Ho, int Wo, dram_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* Multi-tensor optimizers -- torch.optim.Adam at models.py:385-387 / :689-691 and the
+ * SGD arguments of train.py:25,27.  table: device array of DramTensorRef[ntensors];
+ * chunks: device array of DramChunkRef[nchunks] (tensor index + element offset). */
+typedef struct DramTensorRef {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+} DramTensorRef;
+typedef struct DramChunkRef {
+  int32_t tensor;
+  int32_t pad;
+  int64_t offset;
+} DramChunkRef;
+#define DRAM_OPT_CHUNK 16384
+int dram_adam_multi(const DramTensorRef* table, const DramChunkRef* chunks, int nchunks, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, float bias_corr1,
+                    float bias_corr2, float grad_scale, dram_stream_t stream);
+int dram_sgd_multi(const DramTensorRef* table, const DramChunkRef* chunks, int nchunks, float lr,
+                   float momentum, float weight_decay, int first_step, float grad_scale,
+                   dram_stream_t stream);
+
+/* out[i] = a[i] + b[i]  (gradient accumulation where two consumers meet) */
+int dram_add(const float* a, const float* b, float* out, long long n, dram_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRAM_HIP_H */

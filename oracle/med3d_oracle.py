@@ -1,0 +1,356 @@
+"""CPU oracle for the Med3D-ResNet + dRAM train-step hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a from-scratch CPU restatement (plain
+``torch`` CPU ops, functional style, no ``nn.Module``) of the algorithm the
+reference runs on its hot path.  Only ``tests/``, ``__graft_entry__.smoke()``
+and the ``cpu_baseline`` leg of ``bench.py`` may import it, and only as the
+checker.  The product path (``bodyct-dram-emph-subtype_amd``) never imports it
+and fails loudly when the HIP library is missing.
+
+Parity pinning: the reference ships no tests/golden vectors, so
+this oracle is pinned by fixtures generated in the build container by importing
+the reference itself (``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``);
+``tests/test_oracle_golden.py`` checks every function below against them.
+
+Each function cites the reference file:line it restates (paths relative to the
+reference repo root).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+# ---------------------------------------------------------------------------
+# architecture table (med3d.py:391-425: factories -> block type + layer counts)
+# ---------------------------------------------------------------------------
+ARCHS = {
+    "resnet18": ("basic", (2, 2, 2, 2)),
+    "resnet34": ("basic", (3, 4, 6, 3)),
+    "resnet50": ("bottleneck", (3, 4, 6, 3)),
+}
+EXPANSION = {"basic": 1, "bottleneck": 4}
+# (planes, stride, dilation) per stage -- med3d.py:207-213 / :306-312
+STAGES = ((64, 1, 1), (128, 2, 1), (256, 1, 2), (512, 1, 4))
+BN_EPS = 1e-5        # nn.BatchNorm3d default (med3d.py:12)
+BN_MOMENTUM = 0.1
+
+
+def split_arch(name: str) -> Tuple[str, str]:
+    """'resnet18segreg' -> ('resnet18', 'reg')."""
+    assert name.startswith("resnet") and name[-6:-3] == "seg", name
+    return name[:-6], name[-3:]
+
+
+# ---------------------------------------------------------------------------
+# primitive ops
+# ---------------------------------------------------------------------------
+def batch_norm(x: Tensor, sd: Dict[str, Tensor], prefix: str, train: bool,
+               new_stats: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """nn.BatchNorm3d (med3d.py:121,124,153,156,158,203,227).
+
+    train: biased batch variance for normalisation; running stats updated with
+    momentum 0.1 using the UNBIASED variance.  eval: running stats.
+    """
+    w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    dims = [0, 2, 3, 4]
+    if train:
+        n = x.numel() // x.shape[1]
+        mean = x.mean(dims)
+        var = x.var(dims, unbiased=False)
+        if new_stats is not None:
+            with torch.no_grad():
+                new_stats[prefix + ".running_mean"] = (1 - BN_MOMENTUM) * rm + BN_MOMENTUM * mean
+                new_stats[prefix + ".running_var"] = (1 - BN_MOMENTUM) * rv + BN_MOMENTUM * var * (n / max(n - 1, 1))
+                new_stats[prefix + ".num_batches_tracked"] = sd[prefix + ".num_batches_tracked"] + 1
+    else:
+        mean, var = rm, rv
+    shape = (1, -1, 1, 1, 1)
+    xhat = (x - mean.view(shape)) * torch.rsqrt(var.view(shape) + BN_EPS)
+    return xhat * w.view(shape) + b.view(shape)
+
+
+def shortcut_a(x: Tensor, planes: int, stride: int) -> Tensor:
+    """downsample_basic_block (med3d.py:103-112): strided subsample, zero channel
+    pad, and -- crucially -- DETACHED from autograd (``Variable(... out.data ...)``)."""
+    out = x.detach()[:, :, ::stride, ::stride, ::stride]
+    pad = planes - out.shape[1]
+    if pad > 0:
+        out = torch.cat([out, out.new_zeros(out.shape[0], pad, *out.shape[2:])], dim=1)
+    return out
+
+
+def crop_concat(t1: Tensor, t2: Tensor) -> Tensor:
+    """crop_concat_5d (med3d.py:39-48): centre-crop t2 to t1's DHW, cat [t1, t2]."""
+    sl = [slice(None), slice(None)]
+    for a, b in zip(t1.shape[2:], t2.shape[2:]):
+        o = int(math.ceil((b - a) / 2))
+        sl.append(slice(o, a + o))
+    return torch.cat([t1, t2[tuple(sl)]], dim=1)
+
+
+def upsample2_trilinear(x: Tensor) -> Tensor:
+    """nn.Upsample(scale_factor=2, 'trilinear', align_corners=True) (med3d.py:83)."""
+    return F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=True)
+
+
+# ---------------------------------------------------------------------------
+# blocks
+# ---------------------------------------------------------------------------
+def basic_block(x, sd, p, planes, stride, dil, has_ds, train, ns):
+    """BasicBlock.forward (med3d.py:129-144)."""
+    out = F.conv3d(x, sd[p + ".conv1.weight"], None, stride, dil, dil)
+    out = F.relu(batch_norm(out, sd, p + ".bn1", train, ns))
+    out = F.conv3d(out, sd[p + ".conv2.weight"], None, 1, dil, dil)
+    out = batch_norm(out, sd, p + ".bn2", train, ns)
+    res = shortcut_a(x, planes, stride) if has_ds else x
+    return F.relu(out + res)
+
+
+def bottleneck(x, sd, p, planes, stride, dil, has_ds, train, ns):
+    """Bottleneck.forward (med3d.py:164-184)."""
+    out = F.conv3d(x, sd[p + ".conv1.weight"])
+    out = F.relu(batch_norm(out, sd, p + ".bn1", train, ns))
+    out = F.conv3d(out, sd[p + ".conv2.weight"], None, stride, dil, dil)
+    out = F.relu(batch_norm(out, sd, p + ".bn2", train, ns))
+    out = F.conv3d(out, sd[p + ".conv3.weight"])
+    out = batch_norm(out, sd, p + ".bn3", train, ns)
+    res = shortcut_a(x, planes * 4, stride) if has_ds else x
+    return F.relu(out + res)
+
+
+def up_block(inputs, cats, sd, p, nconv, train, ns):
+    """UpsampleConvBlock5d.forward (med3d.py:85-89): up2 -> crop_concat (upsampled
+    channels FIRST) -> nconv x (conv3+bias -> BN -> ReLU)."""
+    x = crop_concat(upsample2_trilinear(inputs), cats)
+    for i in range(nconv):
+        q = f"{p}.conv_blocks.{i}"
+        x = F.conv3d(x, sd[q + ".0.weight"], sd[q + ".0.bias"], 1, 1)
+        x = F.relu(batch_norm(x, sd, q + ".1", train, ns))
+    return x
+
+
+# ---------------------------------------------------------------------------
+# whole network
+# ---------------------------------------------------------------------------
+def forward(sd: Dict[str, Tensor], x: Tensor, lungs: Optional[Tensor], arch: str,
+            train: bool = True, new_stats: Optional[Dict[str, Tensor]] = None,
+            taps: Optional[Dict[str, Tensor]] = None):
+    """ResNetSegCls.forward (med3d.py:270-285) / ResNetSegReg.forward (:369-388).
+
+    ``sd``: state_dict-keyed tensors (reference key names).  Returns
+    (dense_outs, outs) exactly like the reference.  ``taps`` (optional dict)
+    receives named intermediate activations for layer-level tests.
+    """
+    net, head = split_arch(arch)
+    kind, layers = ARCHS[net]
+    e = EXPANSION[kind]
+    blk = basic_block if kind == "basic" else bottleneck
+    B = x.shape[0]
+    ns = new_stats
+
+    x = F.conv3d(x, sd["conv1.weight"], None, 2, 3)                     # :272 / :371
+    x = F.relu(batch_norm(x, sd, "bn1", train, ns))                     # :273-274
+    xp = F.max_pool3d(x, 3, 2, 1)                                       # :275
+    feats = []
+    h = xp
+    inplanes = 64
+    for li, ((planes, stride, dil), nblk) in enumerate(zip(STAGES, layers)):
+        for bi in range(nblk):
+            s = stride if bi == 0 else 1
+            has_ds = bi == 0 and (stride != 1 or inplanes != planes * e)  # :244
+            h = blk(h, sd, f"layer{li + 1}.{bi}", planes, s, dil, has_ds, train, ns)
+            inplanes = planes * e
+        feats.append(h)
+    x1, x4 = feats[0], feats[3]
+    xup1 = up_block(x4, x1, sd, "us1", 2, train, ns)                    # :280 / :379
+    xup2 = up_block(xup1, x, sd, "us2", 2, train, ns)                   # :281 / :380 (skip = post-ReLU stem)
+    xup3 = F.conv3d(xup2, sd["us3.0.weight"], sd["us3.0.bias"], 1, 1)   # :282 / :381
+    xup3 = F.relu(batch_norm(xup3, sd, "us3.1", train, ns))
+    if taps is not None:
+        taps.update(stem=x, xp=xp, x1=feats[0], x2=feats[1], x3=feats[2], x4=x4,
+                    xup1=xup1, xup2=xup2, xup3=xup3)
+    nheads = 2
+    if head == "cls":
+        dense = [F.conv3d(xup3, sd[f"fcs.{i}.weight"], sd[f"fcs.{i}.bias"]) for i in range(nheads)]
+        outs = [d.mean(dim=(2, 3, 4)).view(B, -1) for d in dense]       # :284 adaptive_avg_pool3d(.,1)
+        return dense, outs
+    dense = [torch.sigmoid(F.conv3d(xup3, sd[f"fcs.{i}.weight"], sd[f"fcs.{i}.bias"]))
+             for i in range(nheads)]                                     # :382
+    if lungs is None:
+        lg = torch.ones_like(x)                                          # :383-384 (64-ch; broadcast == mean)
+    else:
+        lg = F.interpolate(lungs, xup3.shape[-3:], mode="nearest")       # :386
+    outs = [(d * lg).view(B, -1).sum(-1) / lg.view(B, -1).sum(-1) for d in dense]  # :387
+    return dense, outs
+
+
+# ---------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------
+# dataset.py:99-112
+CLE_RATIO_MAP = {0: (0.0, 0.01), 1: (0.01, 0.05), 2: (0.05, 0.1), 3: (0.1, 0.2), 4: (0.2, 0.3), 5: (0.3, 1.0001)}
+PSE_RATIO_MAP = {0: (0.0, 0.01), 1: (0.01, 0.05), 2: (0.05, 1.0001)}
+BETA, GAMMA = 0.7338, 0.2578          # models.py:414-415
+
+
+def regression_labels(cls_targets: Sequence[int], ratio_map, tightness: float = 1.0) -> Tensor:
+    """_generate_regression_labels (models.py:495-510)."""
+    bands = []
+    for c in cls_targets:
+        lb, ub = ratio_map[int(c)]
+        if lb < 1e-7:
+            bands.append((0.0, 0.0))
+        else:
+            m = (lb + ub) / 2.0
+            span = (ub - lb) * tightness / 2.0
+            bands.append((m - span, m + span))
+    return torch.tensor(bands, dtype=torch.float32)
+
+
+def interval_regression_loss(outs: Tensor, reg_targets: Tensor, weights: Tensor) -> Tensor:
+    """_interval_regression_loss (models.py:512-521)."""
+    n = torch.cat([outs.unsqueeze(1), reg_targets], dim=1)
+    n = BETA * n ** GAMMA
+    K = (0.5 * (n[:, 2] - n[:, 1])) ** 2
+    unh = (n[:, 0] - (n[:, 2] + n[:, 1]) / 2.0) ** 2 - K
+    return (10.0 * F.relu(unh) * weights).sum()
+
+
+def dice_coef(y: Tensor, y_hat: Tensor, smooth: float = 1e-7) -> Tensor:
+    """dice_coef (metrics.py:33-37), smooth=1e-7 per models.py:412."""
+    inter = (y_hat.reshape(-1) * y.reshape(-1)).sum()
+    return (2.0 * inter + smooth) / (y.sum() + y_hat.sum() + smooth)
+
+
+def balanced_bce(y: Tensor, y_hat: Tensor, mask: Optional[Tensor], smoothness: float = 0.65,
+                 eps: float = 1e-6) -> Tensor:
+    """BinaryCrossEntropy.__call__ (metrics.py:10-30)."""
+    t = y.float()
+    p = y_hat
+    alpha = (1.0 - t.sum() / t.shape[0]).clamp(0.3, 0.7)
+    pt = p * t + (1.0 - p) * (1.0 - t)
+    w = alpha * t + (1.0 - alpha) * (1.0 - t)
+    ptc = pt.clamp(eps, 1.0 - eps)
+    if mask is not None:
+        nll = -1.0 * (smoothness * torch.log(ptc) * w * mask + torch.log(ptc) * w * (1.0 - mask))
+    else:
+        nll = -smoothness * torch.log(ptc) * w
+    return nll.sum() / w.sum()
+
+
+def segmentation_loss(dense_cle: Tensor, dense_pse: Tensor, ems: Tensor, lungs: Tensor):
+    """_segmentation_loss (models.py:523-531)."""
+    mul = dice_coef(dense_cle * lungs, dense_pse * lungs)
+    p = torch.clamp(dense_cle + dense_pse, 0.0, 1.0)
+    seg = balanced_bce(ems, p, lungs, smoothness=0.85)
+    return mul, seg
+
+
+def reg_train_loss(dense_outs, reg_outs, lungs, ems, cle_labels, pse_labels,
+                   cle_w: Tensor, pse_w: Tensor):
+    """Train branch of ScanRegLightningModule.shared_step (models.py:549-574).
+
+    lungs/ems: f32 [B,1,D,H,W]; labels int64 [B]; cle_w/pse_w: per-SAMPLE class
+    weights (models.py:556-561).  Returns (loss, parts dict).
+    """
+    B = lungs.shape[0]
+    cle_t = regression_labels(cle_labels.tolist(), CLE_RATIO_MAP)
+    pse_t = regression_labels(pse_labels.tolist(), PSE_RATIO_MAP)
+    loss_cle = interval_regression_loss(reg_outs[0], cle_t, cle_w)
+    loss_pse = interval_regression_loss(reg_outs[1], pse_t, pse_w)
+    binary = torch.logical_or(cle_labels > 0, pse_labels > 0).long()
+    size = dense_outs[0].shape[-3:]
+    seg_labels = F.interpolate(ems * binary.float().view(B, 1, 1, 1, 1), size, mode="nearest").detach()
+    lung_labels = F.interpolate(lungs, size=size, mode="nearest")
+    mul, seg = segmentation_loss(dense_outs[0], dense_outs[1], seg_labels, lung_labels)
+    loss = loss_cle + loss_pse + 2.0 * mul + seg
+    return loss, dict(loss_cle=loss_cle, loss_pse=loss_pse, mul_loss=mul, seg_loss=seg)
+
+
+def cls_train_loss(cls_outs, cle_labels, pse_labels, cle_cw: Tensor, pse_cw: Tensor):
+    """Train branch of ScanCLSLightningModule.shared_step (models.py:248-258)."""
+    loss_cle = F.cross_entropy(cls_outs[0], cle_labels, weight=cle_cw)
+    loss_pse = F.cross_entropy(cls_outs[1], pse_labels, weight=pse_cw)
+    return loss_cle + loss_pse, dict(loss_cle=loss_cle, loss_pse=loss_pse)
+
+
+def ratio_to_label(ratios: Tensor, ratio_map) -> Tensor:
+    """_ratio_to_label (models.py:533-537)."""
+    out = []
+    for r in ratios.tolist():
+        out.append([k for k, (lo, hi) in ratio_map.items() if lo <= r < hi][0])
+    return torch.tensor(out, dtype=torch.long)
+
+
+# ---------------------------------------------------------------------------
+# predict-time up-projection (models.py:430-450)
+# ---------------------------------------------------------------------------
+def predict_upproject(dense: Tensor, size, ess: Tensor, lungs: Tensor):
+    """K18: trilinear(align_corners) resize to scan grid x ess mask; percentage =
+    per-sample sum / lungs.sum() over the WHOLE batch (models.py:438-441)."""
+    up = F.interpolate(dense, size=size, mode="trilinear", align_corners=True) * ess
+    pct = up.view(up.shape[0], -1).sum(-1) / lungs.sum()
+    return up, pct
+
+
+# ---------------------------------------------------------------------------
+# optimizers (torch.optim.Adam / SGD semantics; models.py:385-394, 689-698)
+# ---------------------------------------------------------------------------
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
+              b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8, wd: float = 0.0):
+    """One torch.optim.Adam update (no amsgrad), in place on p, m, v.  ``step`` is
+    the 1-based step count AFTER increment."""
+    if wd != 0.0:
+        g = g + wd * p
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def sgd_step(p: Tensor, g: Tensor, buf: Optional[Tensor], lr: float, momentum: float = 0.0,
+             wd: float = 0.0, first: bool = False):
+    """torch.optim.SGD update (dampening 0, no nesterov).  train.py:25,27 args."""
+    if wd != 0.0:
+        g = g + wd * p
+    if momentum != 0.0:
+        if first:
+            buf.copy_(g)
+        else:
+            buf.mul_(momentum).add_(g)
+        g = buf
+    p.add_(g, alpha=-lr)
+
+
+# ---------------------------------------------------------------------------
+# N-rank DDP + SyncBN emulation
+# ---------------------------------------------------------------------------
+def ddp_emulated_grads(sd, xs: List[Tensor], lungs: List[Optional[Tensor]], arch: str, loss_fn):
+    """Gradients an N-rank DDP+SyncBatchNorm run produces (train.py:70,100-103):
+    BN statistics over the concatenated batch, loss = mean over ranks of the loss
+    computed from rank r's slice only.  ``loss_fn(rank, dense_slice, outs_slice)``.
+    """
+    N = len(xs)
+    sizes = [t.shape[0] for t in xs]
+    x = torch.cat(xs, 0)
+    lg = None if lungs[0] is None else torch.cat(lungs, 0)
+    leaves = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v)
+              for k, v in sd.items()}
+    dense, outs = forward(leaves, x, lg, arch, train=True)
+    total = 0.0
+    off = 0
+    for r, b in enumerate(sizes):
+        d_r = [d[off:off + b] for d in dense]
+        o_r = [o[off:off + b] for o in outs]
+        total = total + loss_fn(r, d_r, o_r) / N
+        off += b
+    total.backward()
+    return {k: v.grad for k, v in leaves.items() if isinstance(v, Tensor) and v.requires_grad}, total.detach()
