@@ -50,6 +50,62 @@ def _req(t: Tensor, name: str, dtype=torch.float32, shape=None):
     return t
 
 
+class KernelProfiler:
+    """HIP-event timing of kernel families on the launch stream (bench.py's roofline leg).
+    Records (family, algorithmic flops, start, end) per launch; summary() after a sync."""
+
+    def __init__(self):
+        self.records = []
+
+    def span(self, family: str, flops: float):
+        return _Span(self, family, flops)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for fam, flops, a, b in self.records:
+            d = out.setdefault(fam, dict(launches=0, ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["ms"] += a.elapsed_time(b)
+            d["flops"] += flops
+        return out
+
+
+class _Span:
+    def __init__(self, prof, family, flops):
+        self.prof, self.family, self.flops = prof, family, flops
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.prof.records.append((self.family, self.flops, self.a, self.b))
+
+
+class _NoSpan:
+    def __enter__(self):
+        pass
+
+    def __exit__(self, *exc):
+        pass
+
+
+_PROFILER: Optional[KernelProfiler] = None
+_NOSPAN = _NoSpan()
+
+
+def set_profiler(p: Optional[KernelProfiler]):
+    global _PROFILER
+    _PROFILER = p
+
+
+def _span(family: str, flops: float):
+    return _NOSPAN if _PROFILER is None else _PROFILER.span(family, flops)
+
+
 @dataclass(frozen=True)
 class ConvGeom:
     """Forward-sense geometry of one convolution call."""
@@ -82,6 +138,11 @@ class ConvGeom:
     @property
     def taps(self):
         return self.k ** 3
+
+    @property
+    def flops(self) -> float:
+        """algorithmic FLOPs of one pass (fwd, dgrad and wgrad each): 2*M*N*K"""
+        return 2.0 * self.B * self.Do * self.Ho * self.Wo * self.Cout * self.Cin * self.taps
 
     @property
     def in_shape(self):
@@ -121,8 +182,9 @@ def conv3d_fwd(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, want_
         if nt <= 0:
             raise RuntimeError(f"dram_conv_num_mtiles rejected {g}")
         stats = torch.empty((nt, 2, g.Cout), device=x.device, dtype=torch.float32)
-    _chk(_L().dram_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), ctypes.byref(d), _stream()),
-         f"dram_conv3d_fwd{g}")
+    with _span("conv_igemm_kernel", g.flops):
+        _chk(_L().dram_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), ctypes.byref(d), _stream()),
+             f"dram_conv3d_fwd{g}")
     return y, stats
 
 
@@ -136,8 +198,9 @@ def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] =
         _req(gate, "gate", shape=g.in_shape)
     d = g.desc()
     dx = torch.empty(g.in_shape, device=dy.device, dtype=torch.float32)
-    _chk(_L().dram_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d), _stream()),
-         f"dram_conv3d_bwd_data{g}")
+    with _span("conv_igemm_kernel", g.flops):
+        _chk(_L().dram_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d), _stream()),
+             f"dram_conv3d_bwd_data{g}")
     return dx
 
 
@@ -152,8 +215,9 @@ def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] 
     shape = (g.Cout, g.Cin, g.k, g.k, g.k)
     dw = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
     _req(dw, "dw", shape=shape)
-    _chk(_L().dram_conv3d_bwd_weight(_p(x), _p(dy), _p(dw), ctypes.byref(d), _p(ws), nbytes, _stream()),
-         f"dram_conv3d_bwd_weight{g}")
+    with _span("conv_wgrad_kernel+reduce", g.flops):
+        _chk(_L().dram_conv3d_bwd_weight(_p(x), _p(dy), _p(dw), ctypes.byref(d), _p(ws), nbytes, _stream()),
+             f"dram_conv3d_bwd_weight{g}")
     return dw
 
 
@@ -175,7 +239,8 @@ def stem_fwd(x: Tensor, w: Tensor, want_stats: bool):
     if want_stats:
         nt = _L().dram_stem_num_tiles(B, Do, Ho, Wo)
         stats = torch.empty((nt, 2, 64), device=x.device, dtype=torch.float32)
-    _chk(_L().dram_stem_fwd(_p(x), _p(w), _p(y), _p(stats), B, D, H, W, _stream()), "dram_stem_fwd")
+    with _span("stem_fwd_kernel", 2.0 * B * Do * Ho * Wo * 64 * 343):
+        _chk(_L().dram_stem_fwd(_p(x), _p(w), _p(y), _p(stats), B, D, H, W, _stream()), "dram_stem_fwd")
     return y, stats
 
 
@@ -187,8 +252,9 @@ def stem_bwd_weight(x: Tensor, dy: Tensor, out: Optional[Tensor] = None) -> Tens
     ws = torch.empty(((nbytes + 3) // 4,), device=x.device, dtype=torch.float32)
     dw = out if out is not None else torch.empty((64, 1, 7, 7, 7), device=x.device, dtype=torch.float32)
     _req(dw, "dw", shape=(64, 1, 7, 7, 7))
-    _chk(_L().dram_stem_bwd_weight(_p(x), _p(dy), _p(dw), B, D, H, W, _p(ws), nbytes, _stream()),
-         "dram_stem_bwd_weight")
+    with _span("stem_wgrad_kernel+reduce", 2.0 * dy.numel() * 343):
+        _chk(_L().dram_stem_bwd_weight(_p(x), _p(dy), _p(dw), B, D, H, W, _p(ws), nbytes, _stream()),
+             "dram_stem_bwd_weight")
     return dw
 
 

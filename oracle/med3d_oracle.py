@@ -58,21 +58,27 @@ def batch_norm(x: Tensor, sd: Dict[str, Tensor], prefix: str, train: bool,
     """
     w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
     rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    if not train:
+        return F.batch_norm(x, rm, rv, w, b, False, BN_MOMENTUM, BN_EPS)
+    # torch's own batch-norm op (what nn.BatchNorm3d calls); running stats go to copies
+    rm2, rv2 = rm.detach().clone(), rv.detach().clone()
+    out = F.batch_norm(x, rm2, rv2, w, b, True, BN_MOMENTUM, BN_EPS)
+    if new_stats is not None:
+        new_stats[prefix + ".running_mean"] = rm2
+        new_stats[prefix + ".running_var"] = rv2
+        new_stats[prefix + ".num_batches_tracked"] = sd[prefix + ".num_batches_tracked"] + 1
+    return out
+
+
+def batch_norm_explicit(x: Tensor, w: Tensor, b: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """The same training-mode arithmetic spelled out (used by kernel-level tests):
+    returns (out, batch mean, biased batch variance)."""
     dims = [0, 2, 3, 4]
-    if train:
-        n = x.numel() // x.shape[1]
-        mean = x.mean(dims)
-        var = x.var(dims, unbiased=False)
-        if new_stats is not None:
-            with torch.no_grad():
-                new_stats[prefix + ".running_mean"] = (1 - BN_MOMENTUM) * rm + BN_MOMENTUM * mean
-                new_stats[prefix + ".running_var"] = (1 - BN_MOMENTUM) * rv + BN_MOMENTUM * var * (n / max(n - 1, 1))
-                new_stats[prefix + ".num_batches_tracked"] = sd[prefix + ".num_batches_tracked"] + 1
-    else:
-        mean, var = rm, rv
+    mean = x.mean(dims)
+    var = x.var(dims, unbiased=False)
     shape = (1, -1, 1, 1, 1)
     xhat = (x - mean.view(shape)) * torch.rsqrt(var.view(shape) + BN_EPS)
-    return xhat * w.view(shape) + b.view(shape)
+    return xhat * w.view(shape) + b.view(shape), mean, var
 
 
 def shortcut_a(x: Tensor, planes: int, stride: int) -> Tensor:

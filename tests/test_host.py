@@ -1,0 +1,105 @@
+"""CPU: host logic of the package -- C-ABI library loads and exports every declared symbol,
+drop-in surface (factories, conf, state_dict contract), optimizer work tables, geometry."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from bodyct_dram_emph_subtype_amd import _build, _lib
+    path = _build.build_library()
+    header = open(os.path.join(ROOT, "include", "dram_hip.h")).read()
+    declared = set(re.findall(r"\b(dram_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert declared <= exported, declared - exported
+    lib = _lib.load()                       # dlopen works without a GPU; no compute call is made
+    assert lib.dram_version() == 1
+    assert b"gfx950" in lib.dram_build_info()
+    # pure host-side entry points (no kernel launch)
+    d = _lib.DramConvDesc(2, 16, 32, 32, 64, 16, 32, 32, 128, 3, 1, 4, 4)
+    assert lib.dram_conv_num_mtiles(ctypes.byref(d)) == 2 * 64 * 1     # 4^3 residues x 1 tile, per sample
+    assert lib.dram_conv3d_bwd_weight_workspace(ctypes.byref(d)) > 0
+    bad = _lib.DramConvDesc(2, 16, 32, 32, 64, 15, 32, 32, 128, 3, 1, 4, 4)
+    assert lib.dram_conv_num_mtiles(ctypes.byref(bad)) == -1            # inconsistent output dims rejected
+    assert lib.dram_stem_num_tiles(2, 64, 128, 128) == 2 * 16 * 16 * 16
+    assert ctypes.sizeof(_lib.DramTensorRef) == 40 and ctypes.sizeof(_lib.DramChunkRef) == 16
+
+
+def test_factories_conf_and_state_dict_contract():
+    from bodyct_dram_emph_subtype_amd import med3d, utils
+    m = utils.get_model_by_name("med3ddram18")
+    sd = m.state_dict()
+    assert len(sd) == 141
+    assert tuple(sd["conv1.weight"].shape) == (64, 1, 7, 7, 7)
+    for k in ("layer4.1.bn2.running_var", "us1.conv_blocks.0.0.bias", "us3.1.num_batches_tracked", "fcs.1.weight"):
+        assert k in sd
+    assert tuple(sd["us1.conv_blocks.0.0.weight"].shape) == (64, 576, 3, 3, 3)
+    assert m.get_target_layer() is m.us3
+    n = {f: sum(p.numel() for p in getattr(med3d, f)(**kw).parameters())
+         for f, kw in (("resnet18segcls", dict(n_classes=[6, 3])), ("resnet18segreg", {}), ("resnet50segreg", {}))}
+    assert n == {"resnet18segcls": 34480329, "resnet18segreg": 34480098, "resnet50segreg": 47858402}
+    r50 = utils.get_model_by_name("med3d50")
+    assert tuple(r50.state_dict()["us1.conv_blocks.0.0.weight"].shape) == (64, 2304, 3, 3, 3)
+    assert tuple(r50.fcs[0].weight.shape) == (6, 32, 1, 1, 1)
+    with pytest.raises(NotImplementedError):
+        med3d.ResNetSegReg(med3d.BasicBlock, [2, 2, 2, 2], shortcut_type="B")
+    with pytest.raises(FileNotFoundError):
+        utils.get_model_by_name("nope")
+
+
+def test_greedy_loader():
+    from bodyct_dram_emph_subtype_amd import med3d, utils
+    a, b = med3d.resnet18segreg(), med3d.resnet18segreg()
+    sd = {k: v.clone() for k, v in a.state_dict().items()}
+    sd["conv1.weight"] = torch.zeros(3)          # shape mismatch -> skipped
+    sd["unexpected.key"] = torch.zeros(1)
+    del sd["fcs.0.bias"]
+    before = b.state_dict()["conv1.weight"].clone()
+    utils.load_state_dict_greedy(b, sd)
+    assert torch.equal(b.state_dict()["conv1.weight"], before)
+    assert torch.equal(b.state_dict()["layer1.0.conv1.weight"], a.state_dict()["layer1.0.conv1.weight"])
+
+
+def test_conv_geometry_and_optimizer_tables():
+    from bodyct_dram_emph_subtype_amd import ops, optim
+    g = ops.ConvGeom(2, 32, 64, 64, 64, 128, 3, 2, 1, 1)
+    assert g.out_shape == (2, 16, 32, 32, 128) and g.taps == 27
+    assert abs(g.flops - 2.0 * 2 * 16 * 32 * 32 * 128 * 64 * 27) < 1
+    d = g.desc()
+    assert (d.Do, d.Ho, d.Wo, d.k, d.stride) == (16, 32, 32, 3, 2)
+    table, chunks = optim.build_tables([(1000, 2000, 3000, 4000, 40000), (5, 6, 7, 8, 10)])
+    assert len(table) == 2 and len(chunks) == 3 + 1
+    assert [int(c["offset"]) for c in chunks] == [0, 16384, 32768, 0]
+    assert [int(c["tensor"]) for c in chunks] == [0, 0, 0, 1]
+    with pytest.raises(RuntimeError):            # no CPU path for the optimizer either
+        p = torch.zeros(4, requires_grad=True)
+        p.grad = torch.ones(4)
+        optim.FusedAdam([p]).step()
+
+
+def test_loss_host_algebra_matches_oracle():
+    """label tables / interval loss / ratio->label are host-side torch: check vs the oracle."""
+    from bodyct_dram_emph_subtype_amd import models
+    from oracle import med3d_oracle as orc
+    cle = torch.tensor([0, 1, 2, 3, 4, 5])
+    assert torch.allclose(models.generate_regression_labels(cle, "cle"),
+                          orc.regression_labels(cle.tolist(), orc.CLE_RATIO_MAP))
+    pse = torch.tensor([2, 0, 1])
+    assert torch.allclose(models.generate_regression_labels(pse, "pse"),
+                          orc.regression_labels(pse.tolist(), orc.PSE_RATIO_MAP))
+    outs = torch.tensor([0.001, 0.03, 0.5, 0.12, 0.9, 0.31])
+    w = torch.rand(6)
+    a = models.interval_regression_loss(outs, models.generate_regression_labels(cle, "cle"), w)
+    b = orc.interval_regression_loss(outs, orc.regression_labels(cle.tolist(), orc.CLE_RATIO_MAP), w)
+    assert torch.allclose(a, b)
+    assert torch.equal(models.ratio_to_label(outs, "cle"), orc.ratio_to_label(outs, orc.CLE_RATIO_MAP))
+    assert torch.equal(models.ratio_to_label(outs, "pse"), orc.ratio_to_label(outs, orc.PSE_RATIO_MAP))

@@ -1,0 +1,307 @@
+"""GPU: every HIP kernel (through the C ABI) against the CPU oracle on seeded inputs.
+
+Tolerances: fp32 kernels vs fp32 CPU ops, different summation order -> relative L2
+1e-5..1e-4 per tensor (stated per test); the end-to-end 1e-3 bar of BASELINE.json is
+checked in test_network_gpu.py.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+from oracle import med3d_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from bodyct_dram_emph_subtype_amd import ops as o
+    import bodyct_dram_emph_subtype_amd as pkg
+    pkg.load_library()
+    return o
+
+
+def to_ndhwc(t):  # NCDHW cpu -> NDHWC gpu
+    return t.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+
+
+def to_ncdhw(t):  # NDHWC gpu -> NCDHW cpu
+    return t.permute(0, 4, 1, 2, 3).contiguous().cpu()
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+CONV_CASES = [
+    # B, D, H, W, Cin, Cout, k, stride, dil
+    (1, 6, 8, 10, 32, 32, 3, 1, 1),
+    (2, 8, 8, 8, 64, 64, 3, 1, 1),
+    (1, 5, 9, 7, 64, 128, 3, 1, 2),
+    (1, 6, 10, 9, 64, 64, 3, 1, 4),
+    (1, 8, 12, 10, 64, 128, 3, 2, 1),
+    (2, 4, 6, 5, 128, 64, 1, 1, 1),
+    (1, 8, 16, 16, 96, 32, 3, 1, 1),
+    (1, 3, 4, 5, 256, 256, 3, 1, 4),
+]
+
+
+def conv_ref(x, w, b, k, stride, dil):
+    pad = dil * (k - 1) // 2
+    return F.conv3d(x, w, b, stride, pad, dil)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv3d_fwd_bwd(ops, case):
+    B, D, H, W, Cin, Cout, k, stride, dil = case
+    pad = dil * (k - 1) // 2
+    x = rnd(B, Cin, D, H, W, seed=1).requires_grad_(True)
+    w = (rnd(Cout, Cin, k, k, k, seed=2) * 0.1).requires_grad_(True)
+    bias = rnd(Cout, seed=3)
+    y_ref = conv_ref(x, w, bias, k, stride, dil)
+    gy = rnd(*y_ref.shape, seed=4)
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, [x, w], gy)
+
+    g = ops.ConvGeom(B, D, H, W, Cin, Cout, k, stride, pad, dil)
+    assert g.out_shape == (B,) + tuple(y_ref.shape[2:]) + (Cout,)
+    wf, wb = ops.pack_conv_weight(w.detach().to(DEV))
+    xd = to_ndhwc(x.detach())
+    y, stats = ops.conv3d_fwd(xd, wf, bias.to(DEV), g, True)
+    assert rel_l2(to_ncdhw(y), y_ref.detach()) < 2e-6
+    # fused BN statistics epilogue
+    s = ops.reduce_partials(stats).cpu()
+    yr = y_ref.detach().double()
+    assert torch.allclose(s[0], yr.sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[1], (yr * yr).sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    # no-bias / no-stats variant
+    y2, st2 = ops.conv3d_fwd(xd, wf, None, g, False)
+    assert st2 is None and rel_l2(to_ncdhw(y2), conv_ref(x, w, None, k, stride, dil).detach()) < 2e-6
+
+    gyd = to_ndhwc(gy)
+    dx = ops.conv3d_bwd_data(gyd, wb, g)
+    assert rel_l2(to_ncdhw(dx), gx_ref) < 2e-6
+    add = rnd(B, Cin, D, H, W, seed=5)
+    gate = rnd(B, Cin, D, H, W, seed=6)
+    dx2 = ops.conv3d_bwd_data(gyd, wb, g, to_ndhwc(add), to_ndhwc(gate))
+    assert rel_l2(to_ncdhw(dx2), gx_ref + add * (gate > 0).float()) < 2e-6
+    dx3 = ops.conv3d_bwd_data(gyd, wb, g, to_ndhwc(add), None)
+    assert rel_l2(to_ncdhw(dx3), gx_ref + add) < 2e-6
+
+    if Cin % 64 == 0:
+        dw = ops.conv3d_bwd_weight(xd, gyd, g)
+        assert rel_l2(dw.cpu(), gw_ref) < 5e-6
+
+
+def test_conv_linearity_at_scale(ops):
+    """size-independent property at a BASELINE-sized layer (us2.1: 64->64 @ 64x128x128):
+    conv(a*x1 + x2) == a*conv(x1) + conv(x2), and a checksum against a strided CPU probe."""
+    B, D, H, W, C = 1, 64, 128, 128, 64
+    g = ops.ConvGeom(B, D, H, W, C, C, 3, 1, 1, 1)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    x1 = torch.randn(g.in_shape, device=DEV, generator=gen)
+    x2 = torch.randn(g.in_shape, device=DEV, generator=gen)
+    w = torch.randn(C, C, 3, 3, 3, device=DEV, generator=gen) * 0.05
+    wf, _ = ops.pack_conv_weight(w)
+    y1, _ = ops.conv3d_fwd(x1, wf, None, g, False)
+    y2, _ = ops.conv3d_fwd(x2, wf, None, g, False)
+    y3, _ = ops.conv3d_fwd(0.5 * x1 + x2, wf, None, g, False)
+    assert rel_l2((0.5 * y1 + y2).cpu(), y3.cpu()) < 1e-5
+    # probe a slab against the CPU op
+    sl = x1[:, 10:16].permute(0, 4, 1, 2, 3).cpu()
+    ref = F.conv3d(sl, w.cpu(), None, 1, (0, 1, 1))  # valid in z: output planes 11..14
+    assert rel_l2(y1[:, 11:15].permute(0, 4, 1, 2, 3).cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 16, 16), (2, 8, 24, 40), (1, 10, 14, 18)])
+def test_stem(ops, shape):
+    B, D, H, W = shape
+    x = rnd(B, 1, D, H, W, seed=1)
+    w = (rnd(64, 1, 7, 7, 7, seed=2) * 0.1).requires_grad_(True)
+    y_ref = F.conv3d(x, w, None, 2, 3)
+    gy = rnd(*y_ref.shape, seed=3)
+    (gw_ref,) = torch.autograd.grad(y_ref, [w], gy)
+    xd = x.reshape(B, D, H, W).to(DEV)
+    y, stats = ops.stem_fwd(xd, w.detach().to(DEV), True)
+    assert rel_l2(to_ncdhw(y), y_ref.detach()) < 2e-6
+    s = ops.reduce_partials(stats).cpu()
+    assert torch.allclose(s[0], y_ref.detach().double().sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[1], y_ref.detach().double().square().sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    dw = ops.stem_bwd_weight(xd, to_ndhwc(gy))
+    assert rel_l2(dw.cpu(), gw_ref) < 5e-6
+
+
+@pytest.mark.parametrize("C,res", [(32, None), (64, "id"), (128, "a2"), (256, "a1"), (2048, None)])
+def test_batchnorm_relu_residual(ops, C, res):
+    B, D, H, W = 2, 4, 6, 5
+    y = rnd(B, C, D, H, W, seed=1) * 2 + 0.5
+    gamma = (rnd(C, seed=2) * 0.2 + 1).requires_grad_(True)
+    beta = (rnd(C, seed=3) * 0.2).requires_grad_(True)
+    y.requires_grad_(True)
+    if res == "id":
+        r = rnd(B, C, D, H, W, seed=4)
+        rfull, rs = r, 1
+    elif res == "a2":   # stride-2 shortcut A from a wider grid with C/2 channels
+        r = rnd(B, C // 2, 2 * D - 1, 2 * H, 2 * W - 1, seed=4)
+        rfull, rs = orc.shortcut_a(r, C, 2), 2
+    elif res == "a1":   # stride-1 channel-padded shortcut A (ResNet-50 layer1.0)
+        r = rnd(B, C // 4, D, H, W, seed=4)
+        rfull, rs = orc.shortcut_a(r, C, 1), 1
+    else:
+        r, rfull, rs = None, 0.0, 1
+    out, mean, var = orc.batch_norm_explicit(y, gamma, beta)
+    z_ref = F.relu(out + rfull)
+    gz = rnd(B, C, D, H, W, seed=5)
+    gy_ref, gg_ref, gb_ref = torch.autograd.grad(z_ref, [y, gamma, beta], gz)
+
+    yd = to_ndhwc(y.detach())
+    n = B * D * H * W
+    yf = yd.reshape(-1, C)
+    # statistics path: partial sums -> double reduce -> finalize (+ running stats)
+    part = torch.stack([yf.sum(0), (yf * yf).sum(0)])[None].contiguous()
+    sums = ops.reduce_partials(part)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean_d, invstd_d, scale, shift = ops.bn_finalize(sums, n, gamma.detach().to(DEV), beta.detach().to(DEV), rm, rv,
+                                                     0.1, 1e-5, True)
+    assert torch.allclose(mean_d.cpu(), mean.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(invstd_d.cpu(), torch.rsqrt(var.detach() + 1e-5), rtol=1e-5)
+    assert torch.allclose(rm.cpu(), 0.1 * mean.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rv.cpu(), 0.9 + 0.1 * var.detach() * n / (n - 1), rtol=1e-5)
+    rd = None if r is None else to_ndhwc(r)
+    z = ops.bn_apply(yd, scale, shift, rd, rs, True)
+    assert rel_l2(to_ncdhw(z), z_ref.detach()) < 1e-6
+    # eval-mode finalize reads the running stats
+    m2, is2, _, _ = ops.bn_finalize(None, 1.0, gamma.detach().to(DEV), beta.detach().to(DEV), rm, rv, 0.1, 1e-5, False)
+    assert torch.allclose(m2, rm) and torch.allclose(is2.cpu(), torch.rsqrt(rv.cpu() + 1e-5), rtol=1e-6)
+    # backward
+    gzd = to_ndhwc(gz)
+    bp = ops.bn_bwd_reduce(gzd, z, yd, mean_d, invstd_d, True)
+    bs = ops.reduce_partials(bp)
+    assert rel_l2(bs[1].cpu(), gg_ref) < 1e-5 and rel_l2(bs[0].cpu(), gb_ref) < 1e-5
+    dy = ops.bn_bwd_apply(gzd, z, yd, mean_d, invstd_d, gamma.detach().to(DEV), bs, n, True)
+    assert rel_l2(to_ncdhw(dy), gy_ref) < 2e-5
+    cs = ops.reduce_partials(ops.colsum(gzd))[0]
+    assert rel_l2(cs.cpu(), gz.double().sum((0, 2, 3, 4))) < 1e-5
+
+
+def test_add(ops):
+    a, b = rnd(1237, seed=1).to(DEV), rnd(1237, seed=2).to(DEV)
+    assert torch.equal(ops.add(a, b), a + b)
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 8, 8, 64), (2, 6, 10, 7, 64), (1, 5, 5, 5, 8)])
+def test_maxpool(ops, shape):
+    B, D, H, W, C = shape
+    x = F.relu(rnd(B, C, D, H, W, seed=1)).requires_grad_(True)   # post-ReLU: ties at 0 like the stem
+    y_ref = F.max_pool3d(x, 3, 2, 1)
+    gy = rnd(*y_ref.shape, seed=2)
+    (gx_ref,) = torch.autograd.grad(y_ref, [x], gy)
+    xd = to_ndhwc(x.detach())
+    y, am = ops.maxpool_fwd(xd)
+    assert torch.equal(to_ncdhw(y), y_ref.detach())
+    addt = rnd(B, C, D, H, W, seed=3)
+    dx = ops.maxpool_bwd(to_ndhwc(gy), am, tuple(xd.shape), to_ndhwc(addt))
+    assert rel_l2(to_ncdhw(dx), gx_ref + addt) < 1e-6
+
+
+@pytest.mark.parametrize("case", [(1, 3, 4, 5, 8, 6, 8, 10, 4), (2, 2, 4, 4, 16, 5, 9, 8, 8), (1, 4, 4, 4, 64, 8, 8, 8, 64)])
+def test_upcat(ops, case):
+    B, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck = case
+    src = rnd(B, Cu, Ds, Hs, Ws, seed=1).requires_grad_(True)
+    skip = rnd(B, Ck, Dk, Hk, Wk, seed=2).requires_grad_(True)
+    cat_ref = orc.crop_concat(orc.upsample2_trilinear(src), skip)
+    g = rnd(*cat_ref.shape, seed=3)
+    gs_ref, gk_ref = torch.autograd.grad(cat_ref, [src, skip], g)
+    cat = ops.upcat_fwd(to_ndhwc(src.detach()), to_ndhwc(skip.detach()))
+    assert rel_l2(to_ncdhw(cat), cat_ref.detach()) < 1e-6
+    dsrc, dskip = ops.upcat_bwd(to_ndhwc(g), (B, Ds, Hs, Ws, Cu), (B, Dk, Hk, Wk, Ck))
+    assert rel_l2(to_ncdhw(dsrc), gs_ref) < 1e-5
+    assert torch.equal(to_ncdhw(dskip), gk_ref)
+
+
+@pytest.mark.parametrize("mode", ["cls", "reg", "reg_nolungs"])
+def test_head(ops, mode):
+    B, D, H, W = 2, 4, 6, 5
+    x = rnd(B, 32, D, H, W, seed=1).requires_grad_(True)
+    n = (6, 3) if mode == "cls" else (1, 1)
+    NO = sum(n)
+    w = (rnd(NO, 32, 1, 1, 1, seed=2) * 0.3).requires_grad_(True)
+    b = (rnd(NO, seed=3) * 0.1).requires_grad_(True)
+    lungs = (torch.rand(B, 1, 2 * D, 2 * H, 2 * W, generator=torch.Generator().manual_seed(4)) > 0.4).float()
+    pre = F.conv3d(x, w, b)
+    if mode == "cls":
+        dense_ref = pre
+        outs_ref = dense_ref.mean((2, 3, 4))
+    else:
+        dense_ref = torch.sigmoid(pre)
+        lg = torch.ones(B, 1, D, H, W) if mode == "reg_nolungs" else F.interpolate(lungs, (D, H, W), mode="nearest")
+        outs_ref = (dense_ref * lg).flatten(2).sum(-1) / lg.flatten(2).sum(-1)
+    go = rnd(B, NO, seed=5)
+    gd = rnd(B, NO, D, H, W, seed=6) * 0.01
+    loss = (outs_ref * go).sum() + (dense_ref * gd).sum()
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad(loss, [x, w, b])
+
+    sig = mode != "cls"
+    lun = lungs.reshape(B, 2 * D, 2 * H, 2 * W).to(DEV) if mode == "reg" else None
+    xd = to_ndhwc(x.detach())
+    wd = w.detach().reshape(NO, 32).to(DEV)
+    dense, partial = ops.head_fwd(xd, wd, b.detach().to(DEV), lun, sig)
+    assert rel_l2(dense.cpu(), dense_ref.detach()) < 1e-6
+    sums = partial.sum(1)
+    outs = sums[:, :NO] / sums[:, NO:]
+    assert torch.allclose(outs.cpu(), outs_ref.detach(), rtol=1e-5, atol=1e-6)
+    gpool = (go.to(DEV) / sums[:, NO:]).contiguous()
+    dx, wpart = ops.head_bwd(xd, wd, dense if sig else None, gd.to(DEV), gpool, lun, sig)
+    assert rel_l2(to_ncdhw(dx), gx_ref) < 1e-5
+    wg = ops.reduce_partials(wpart.reshape(wpart.shape[0], 1, NO * 33)).reshape(NO, 33).cpu()
+    assert rel_l2(wg[:, :32], gw_ref.reshape(NO, 32)) < 1e-5
+    assert rel_l2(wg[:, 32], gb_ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,binary", [(2, [1.0, 0.0]), (3, [1.0, 1.0, 1.0])])
+def test_segloss(ops, B, binary):
+    D, H, W = 4, 8, 6
+    gen = torch.Generator().manual_seed(7)
+    cle = torch.rand(B, 1, D, H, W, generator=gen).requires_grad_(True)
+    pse = torch.rand(B, 1, D, H, W, generator=gen).requires_grad_(True)
+    lungs = (torch.rand(B, 1, 2 * D, 2 * H, 2 * W, generator=gen) > 0.4).float()
+    ems = (torch.rand(B, 1, 2 * D, 2 * H, 2 * W, generator=gen) > 0.7).float() * lungs
+    bt = torch.tensor(binary)
+    seg_labels = F.interpolate(ems * bt.view(B, 1, 1, 1, 1), (D, H, W), mode="nearest")
+    lung_labels = F.interpolate(lungs, (D, H, W), mode="nearest")
+    mul_ref, seg_ref = orc.segmentation_loss(cle, pse, seg_labels, lung_labels)
+    (2.0 * mul_ref + seg_ref).backward()
+
+    c4, p4 = cle.detach().reshape(B, D, H, W).to(DEV), pse.detach().reshape(B, D, H, W).to(DEV)
+    l4, e4 = lungs.reshape(B, 2 * D, 2 * H, 2 * W).to(DEV), ems.reshape(B, 2 * D, 2 * H, 2 * W).to(DEV)
+    part = ops.segloss_fwd(c4, p4, l4, e4, bt.to(DEV))
+    s = part.double().sum(0).cpu()
+    N = B * D * H * W
+    st, A1, A0, I, S1, S2 = [float(v) for v in s]
+    alpha = min(max(1.0 - st / B, 0.3), 0.7)
+    sw = alpha * st + (1 - alpha) * (N - st)
+    seg = (alpha * A1 + (1 - alpha) * A0) / sw
+    den = S1 + S2 + 1e-7
+    mul = (2 * I + 1e-7) / den
+    assert abs(mul - float(mul_ref)) < 1e-5 and abs(seg - float(seg_ref)) < 1e-5 * max(1, abs(float(seg_ref)))
+    coef = torch.tensor([2.0 * 2 / den, 2.0 * (2 * I + 1e-7) / den ** 2, alpha / sw, (1 - alpha) / sw, 0, 0, 0, 0],
+                        dtype=torch.float32, device=DEV)
+    gc, gp = ops.segloss_bwd(c4, p4, l4, e4, bt.to(DEV), coef)
+    assert rel_l2(gc.cpu().reshape(cle.shape), cle.grad) < 1e-5
+    assert rel_l2(gp.cpu().reshape(pse.shape), pse.grad) < 1e-5
+
+
+def test_upproject(ops):
+    B, D, H, W = 2, 4, 6, 5
+    dense = torch.rand(B, 1, D, H, W, generator=torch.Generator().manual_seed(1))
+    size = (8, 12, 10)
+    ess = (torch.rand(B, 1, *size, generator=torch.Generator().manual_seed(2)) > 0.5).float()
+    lungs = (torch.rand(B, 1, *size, generator=torch.Generator().manual_seed(3)) > 0.3).float()
+    up_ref, pct_ref = orc.predict_upproject(dense, size, ess, lungs)
+    out, partial = ops.upproject(dense.reshape(B, D, H, W).to(DEV), ess.reshape(B, *size).to(DEV), size)
+    assert rel_l2(out.cpu().reshape(up_ref.shape), up_ref) < 1e-6
+    pct = partial.sum(1).cpu() / lungs.sum()
+    assert torch.allclose(pct, pct_ref, rtol=1e-5)
