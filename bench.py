@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--config", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--detail", type=str, default="", help="write a per-launch-geometry timing table to this file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -178,6 +179,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     summ = prof.summary()
+    if rank == 0 and args.detail:
+        rows = sorted(prof.by_launch().items(), key=lambda kv: -kv[1]["ms"])
+        with open(args.detail, "w") as f:
+            for (fam, det), v in rows:
+                tf = (v["flops"] / 1e12) / (v["ms"] / 1e3) if v["ms"] > 0 else 0.0
+                f.write(f"{v['ms'] / args.steps:9.3f} ms/step  {v['launches'] // args.steps:3d}x  {tf:7.1f} TF  {fam}  {det}\n")
     if rank == 0:
         vols = args.steps * B * world
         fam = "conv_igemm_kernel"

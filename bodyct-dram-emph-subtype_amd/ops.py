@@ -57,13 +57,24 @@ class KernelProfiler:
     def __init__(self):
         self.records = []
 
-    def span(self, family: str, flops: float):
-        return _Span(self, family, flops)
+    def span(self, family: str, flops: float, detail: str = ""):
+        return _Span(self, family, flops, detail)
+
+    def by_launch(self):
+        """{(family, detail): dict(launches, ms, flops)} -- per-geometry breakdown."""
+        torch.cuda.synchronize()
+        out = {}
+        for fam, flops, a, b, detail in self.records:
+            d = out.setdefault((fam, detail), dict(launches=0, ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["ms"] += a.elapsed_time(b)
+            d["flops"] += flops
+        return out
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for fam, flops, a, b in self.records:
+        for fam, flops, a, b, _ in self.records:
             d = out.setdefault(fam, dict(launches=0, ms=0.0, flops=0.0))
             d["launches"] += 1
             d["ms"] += a.elapsed_time(b)
@@ -72,8 +83,8 @@ class KernelProfiler:
 
 
 class _Span:
-    def __init__(self, prof, family, flops):
-        self.prof, self.family, self.flops = prof, family, flops
+    def __init__(self, prof, family, flops, detail=""):
+        self.prof, self.family, self.flops, self.detail = prof, family, flops, detail
 
     def __enter__(self):
         self.a = torch.cuda.Event(enable_timing=True)
@@ -82,7 +93,7 @@ class _Span:
 
     def __exit__(self, *exc):
         self.b.record()
-        self.prof.records.append((self.family, self.flops, self.a, self.b))
+        self.prof.records.append((self.family, self.flops, self.a, self.b, self.detail))
 
 
 class _NoSpan:
@@ -102,8 +113,8 @@ def set_profiler(p: Optional[KernelProfiler]):
     _PROFILER = p
 
 
-def _span(family: str, flops: float):
-    return _NOSPAN if _PROFILER is None else _PROFILER.span(family, flops)
+def _span(family: str, flops: float, detail: str = ""):
+    return _NOSPAN if _PROFILER is None else _PROFILER.span(family, flops, detail)
 
 
 @dataclass(frozen=True)
@@ -182,7 +193,7 @@ def conv3d_fwd(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, want_
         if nt <= 0:
             raise RuntimeError(f"dram_conv_num_mtiles rejected {g}")
         stats = torch.empty((nt, 2, g.Cout), device=x.device, dtype=torch.float32)
-    with _span("conv_igemm_kernel", g.flops):
+    with _span("conv_igemm_kernel", g.flops, f"fwd {g}"):
         _chk(_L().dram_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), ctypes.byref(d), _stream()),
              f"dram_conv3d_fwd{g}")
     return y, stats
@@ -198,7 +209,7 @@ def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] =
         _req(gate, "gate", shape=g.in_shape)
     d = g.desc()
     dx = torch.empty(g.in_shape, device=dy.device, dtype=torch.float32)
-    with _span("conv_igemm_kernel", g.flops):
+    with _span("conv_igemm_kernel", g.flops, f"dgrad {g}"):
         _chk(_L().dram_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d), _stream()),
              f"dram_conv3d_bwd_data{g}")
     return dx
@@ -215,7 +226,7 @@ def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] 
     shape = (g.Cout, g.Cin, g.k, g.k, g.k)
     dw = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
     _req(dw, "dw", shape=shape)
-    with _span("conv_wgrad_kernel+reduce", g.flops):
+    with _span("conv_wgrad_kernel+reduce", g.flops, f"wgrad {g}"):
         _chk(_L().dram_conv3d_bwd_weight(_p(x), _p(dy), _p(dw), ctypes.byref(d), _p(ws), nbytes, _stream()),
              f"dram_conv3d_bwd_weight{g}")
     return dw
