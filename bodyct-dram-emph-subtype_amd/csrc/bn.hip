@@ -11,18 +11,23 @@
 
 namespace {
 
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, double* __restrict__ sums,
-                                       int nparts, int RC) {
-  // one thread per (r, c); 4-way split of the partial range folded through LDS
+// sums[col] = sum_p partial[p][col] in double.  Stage 1: grid (cols/64, S) -- block (x, s)
+// folds parts p = s, s+S, ... (4 interleaved lanes per column through LDS) into tmp[s][col];
+// stage 2 (same kernel, double input, S = 1) folds the S rows.  Fixed order -> deterministic.
+template <typename T>
+__global__ void reduce_partials_kernel(const T* __restrict__ partial, double* __restrict__ out, int nparts,
+                                       int RC) {
   __shared__ double sm[256];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int part = threadIdx.x >> 6;  // 0..3
+  const int lane4 = threadIdx.x >> 6;  // 0..3
+  const int S = gridDim.y, sidx = blockIdx.y;
   double s = 0.0;
   if (col < RC)
-    for (int p = part; p < nparts; p += 4) s += (double)partial[(long)p * RC + col];
+    for (int p = sidx + S * lane4; p < nparts; p += 4 * S) s += (double)partial[(long)p * RC + col];
   sm[threadIdx.x] = s;
   __syncthreads();
-  if (part == 0 && col < RC) sums[col] = sm[threadIdx.x] + sm[threadIdx.x + 64] + sm[threadIdx.x + 128] + sm[threadIdx.x + 192];
+  if (lane4 == 0 && col < RC)
+    out[(long)sidx * RC + col] = sm[threadIdx.x] + sm[threadIdx.x + 64] + sm[threadIdx.x + 128] + sm[threadIdx.x + 192];
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
@@ -222,12 +227,30 @@ inline int rows_per_block(long long rows) {
 
 }  // namespace
 
-extern "C" int dram_reduce_partials(const float* partial, double* sums, int nparts, int R, int C,
+extern "C" int dram_reduce_partials_stages(int nparts) {
+  // number of stage-1 rows (scratch doubles needed = stages * R * C); 1 => single pass
+  if (nparts <= 64) return 1;
+  int s = (nparts + 31) / 32;
+  return s > 64 ? 64 : s;
+}
+
+extern "C" int dram_reduce_partials(const float* partial, double* sums, double* scratch, int nparts, int R, int C,
                                     dram_stream_t stream) {
   if (!partial || !sums || nparts < 1 || R < 1 || C < 1) return DRAM_ERR_BAD_ARG;
   const int RC = R * C;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((RC + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial,
-                     sums, nparts, RC);
+  const int S = dram_reduce_partials_stages(nparts);
+  hipStream_t st = (hipStream_t)stream;
+  if (S == 1) {
+    hipLaunchKernelGGL((reduce_partials_kernel<float>), dim3((RC + 63) / 64, 1), dim3(256), 0, st, partial, sums,
+                       nparts, RC);
+  } else {
+    if (!scratch) return DRAM_ERR_WORKSPACE;
+    hipLaunchKernelGGL((reduce_partials_kernel<float>), dim3((RC + 63) / 64, S), dim3(256), 0, st, partial, scratch,
+                       nparts, RC);
+    DRAM_LAUNCH_CHECK();
+    hipLaunchKernelGGL((reduce_partials_kernel<double>), dim3((RC + 63) / 64, 1), dim3(256), 0, st,
+                       (const double*)scratch, sums, S, RC);
+  }
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
   constexpr int NJ = BN / 32;
   constexpr int BQ = BN / 32;  // B-tile row passes per thread
   __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDK];
+  __shared__ int taplist[28];  // MODE 2: taps whose stride-divisibility test passes for this tile
   float* As = lds;
   float* Bs = lds + BM * LDK;
 
@@ -108,14 +109,34 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
   }
 
   const int nchunk = g.Ci / BK;
-  const int niter = nchunk * g.taps;
+  int ntv = g.taps;
+  if (MODE == 2) {
+    // the M tile is a lattice of step `stride`: (o + pad - t*dil) % stride is the same for every
+    // row, so invalid taps are skipped for the whole workgroup (27 -> ~27/stride^3 taps)
+    if (tid == 0) {
+      int n = 0;
+      for (int tz = 0; tz < g.kd; ++tz)
+        for (int ty = 0; ty < g.kh; ++ty)
+          for (int tx = 0; tx < g.kw; ++tx) {
+            const int az = rz + g.pad - tz * g.dil, ay = ry + g.pad - ty * g.dil, ax = rx + g.pad - tx * g.dil;
+            const bool ok = (((az % g.stride) + g.stride) % g.stride == 0) &
+                            (((ay % g.stride) + g.stride) % g.stride == 0) &
+                            (((ax % g.stride) + g.stride) % g.stride == 0);
+            if (ok) taplist[n++] = (tz * g.kh + ty) * g.kw + tx;
+          }
+      taplist[27] = n;
+    }
+    __syncthreads();
+    ntv = taplist[27];
+  }
+  const int niter = nchunk * ntv;
 
   float4 ra[8];
   float4 rb[BQ];
 
   auto load_tile = [&](int it) {
-    const int c = it / g.taps;
-    const int tap = it - c * g.taps;
+    const int c = it / ntv;
+    const int tap = (MODE == 2) ? taplist[it - c * ntv] : it - c * ntv;
     const int tz = tap / (g.kh * g.kw);
     const int trem = tap - tz * (g.kh * g.kw);
     const int ty = trem / g.kw;
@@ -170,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
   const float* a_rd = &As[(wave * 64 + li) * LDK + 4 * lh];
   const float* b_rd = &Bs[li * LDK + 4 * lh];
 
-  load_tile(0);
+  if (niter > 0) load_tile(0);
   for (int it = 0; it < niter; ++it) {
     __syncthreads();  // every wave has finished reading the previous tile
     store_tile();
@@ -258,6 +279,21 @@ int pick_bn(int N) {
   return 0;
 }
 
+// Narrow the N tile while the launch would not fill the chip (256 CUs x 2-3 workgroups):
+// the 16x32x32 stages have only 128 M tiles at batch 2.
+int pick_bn_for(const IGemmGeom& g0) {
+  int BN = pick_bn(g0.No);
+  if (!BN) return 0;
+  IGemmGeom g = g0;
+  while (BN > 32) {
+    const int sz = (g.Do + g.lat - 1) / g.lat, sy = (g.Ho + g.lat - 1) / g.lat, sx = (g.Wo + g.lat - 1) / g.lat;
+    const long mt = (long)g.B * g.lat * g.lat * g.lat * ((sz + TZ - 1) / TZ) * ((sy + TY - 1) / TY) * ((sx + TX - 1) / TX);
+    if (mt * (g.No / BN) >= 512) break;
+    BN >>= 1;
+  }
+  return BN;
+}
+
 void fill_tiles(IGemmGeom& g, int BN) {
   const int sz = (g.Do + g.lat - 1) / g.lat, sy = (g.Ho + g.lat - 1) / g.lat, sx = (g.Wo + g.lat - 1) / g.lat;
   g.nz = (sz + TZ - 1) / TZ;
@@ -314,7 +350,7 @@ extern "C" int dram_conv_num_mtiles(const DramConvDesc* d) {
   g.lat = d->dil;
   const int BN = pick_bn(d->Cout);
   if (!BN) return DRAM_ERR_UNSUPPORTED;
-  fill_tiles(g, BN);
+  fill_tiles(g, BN);  // the M-tile count does not depend on the N tile
   return g.B * g.tiles_per_b;
 }
 
@@ -322,8 +358,6 @@ extern "C" int dram_conv3d_fwd(const float* x, const float* wf, const float* bia
                                float* stats_partial, const DramConvDesc* d, dram_stream_t stream) {
   if (!desc_ok(d) || !x || !wf || !y) return DRAM_ERR_BAD_ARG;
   if (d->Cin % BK != 0) return DRAM_ERR_UNSUPPORTED;
-  const int BN = pick_bn(d->Cout);
-  if (!BN) return DRAM_ERR_UNSUPPORTED;
   IGemmGeom g{};
   g.B = d->B; g.Do = d->Do; g.Ho = d->Ho; g.Wo = d->Wo; g.No = d->Cout;
   g.Di = d->D; g.Hi = d->H; g.Wi = d->W; g.Ci = d->Cin;
@@ -331,6 +365,8 @@ extern "C" int dram_conv3d_fwd(const float* x, const float* wf, const float* bia
   g.lat = d->dil;
   g.mul = d->stride; g.off = -d->pad; g.step = d->dil;
   g.stride = d->stride; g.pad = d->pad; g.dil = d->dil;
+  const int BN = pick_bn_for(g);
+  if (!BN) return DRAM_ERR_UNSUPPORTED;
   return launch<0>(BN, x, wf, bias, y, stats_partial, nullptr, nullptr, g, (hipStream_t)stream);
 }
 
@@ -339,8 +375,7 @@ extern "C" int dram_conv3d_bwd_data(const float* dy, const float* wb, float* dx,
   if (!desc_ok(d) || !dy || !wb || !dx) return DRAM_ERR_BAD_ARG;
   if (gate && !add) return DRAM_ERR_BAD_ARG;
   if (d->Cout % BK != 0) return DRAM_ERR_UNSUPPORTED;
-  const int BN = pick_bn(d->Cin);
-  if (!BN) return DRAM_ERR_UNSUPPORTED;
+  if (!pick_bn(d->Cin)) return DRAM_ERR_UNSUPPORTED;
   IGemmGeom g{};
   // the tensor written is dx (forward input grid); the tensor gathered is dy
   g.B = d->B; g.Do = d->D; g.Ho = d->H; g.Wo = d->W; g.No = d->Cin;
@@ -350,10 +385,10 @@ extern "C" int dram_conv3d_bwd_data(const float* dy, const float* wb, float* dx,
   if (d->stride == 1) {
     g.lat = d->dil;
     g.mul = 1; g.off = d->pad; g.step = -d->dil;
-    return launch<1>(BN, dy, wb, nullptr, dx, nullptr, add, gate, g, (hipStream_t)stream);
+    return launch<1>(pick_bn_for(g), dy, wb, nullptr, dx, nullptr, add, gate, g, (hipStream_t)stream);
   }
-  g.lat = 1;
-  return launch<2>(BN, dy, wb, nullptr, dx, nullptr, add, gate, g, (hipStream_t)stream);
+  g.lat = d->stride;
+  return launch<2>(pick_bn_for(g), dy, wb, nullptr, dx, nullptr, add, gate, g, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------

@@ -274,8 +274,11 @@ def reduce_partials(partial: Tensor) -> Tensor:
     """[P,R,C] float32 -> [R,C] float64."""
     _req(partial, "partial")
     Pn, R, C = partial.shape
-    sums = torch.empty((R, C), device=partial.device, dtype=torch.float64)
-    _chk(_L().dram_reduce_partials(_p(partial), _p(sums), Pn, R, C, _stream()), "dram_reduce_partials")
+    stages = _L().dram_reduce_partials_stages(Pn)
+    buf = torch.empty((stages + 1 if stages > 1 else 1, R, C), device=partial.device, dtype=torch.float64)
+    sums = buf[0]
+    scratch = buf[1:] if stages > 1 else None
+    _chk(_L().dram_reduce_partials(_p(partial), _p(sums), _p(scratch), Pn, R, C, _stream()), "dram_reduce_partials")
     return sums
 
 

@@ -98,8 +98,11 @@ int dram_stem_bwd_weight(const float* x, const float* dy, float* dw, int B, int 
  *
  * dram_reduce_partials: sums[r][c] (double) = sum_p partial[p][r][c], r < R.
  *   Used for the BN statistics, BN-backward sums and bias gradients.  In DDP the
- *   caller all-reduces `sums` (SyncBatchNorm, train.py:101) before finalising. */
-int dram_reduce_partials(const float* partial, double* sums, int nparts, int R, int C,
+ *   caller all-reduces `sums` (SyncBatchNorm, train.py:101) before finalising.
+ *   Two-stage for many partials: scratch = dram_reduce_partials_stages(nparts)*R*C doubles
+ *   (may be NULL when stages == 1).  Fixed summation order (deterministic). */
+int dram_reduce_partials_stages(int nparts);
+int dram_reduce_partials(const float* partial, double* sums, double* scratch, int nparts, int R, int C,
                          dram_stream_t stream);
 
 /* training: mean/var from sums[2][C] over `count` elements per channel;

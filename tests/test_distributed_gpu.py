@@ -1,0 +1,85 @@
+"""GPU: the real engine under 2 data-parallel ranks (two processes sharing the one GPU of the
+test box, gloo backend on device tensors -- RCCL needs one GPU per rank) against the oracle's
+N-rank DDP+SyncBatchNorm emulation: BN statistics over the global batch,
+loss_r from rank r's slice only, gradients averaged over ranks."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, rel_l2
+
+pytestmark = pytest.mark.gpu
+FACTORY, SHAPE = "resnet18segreg", (1, 1, 16, 32, 32)
+
+
+def _inputs(rank):
+    g = torch.Generator().manual_seed(500 + rank)
+    x = torch.randn(*SHAPE, generator=g)
+    lungs = (torch.rand(*SHAPE, generator=g) > 0.3).float()
+    return x, lungs
+
+
+def _loss(rank, dense, outs):
+    return (1.0 + rank) * outs[0].sum() - 0.5 * outs[1].sum() + 0.1 * (dense[0] * dense[1]).mean()
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bodyct_dram_emph_subtype_amd import med3d, distributed as ddist
+        torch.manual_seed(21 + rank)            # different init per rank: attach() must broadcast rank 0's
+        m = med3d.resnet18segreg().to("cuda:0").train()
+        ddist.attach(m, bucket_bytes=8 << 20)
+        x, lungs = _inputs(rank)
+        dense, outs = m(x.cuda(), lungs.cuda())
+        _loss(rank, dense, outs).backward()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.cpu() for n, p in m.named_parameters()}
+        stats = {k: v.cpu() for k, v in m.state_dict().items() if "running" in k}
+        q.put((rank, grads, stats, [float(o) for o in outs]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_engine_matches_ddp_syncbn_emulation():
+    from oracle import med3d_oracle as orc
+    from bodyct_dram_emph_subtype_amd import med3d
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    torch.manual_seed(21)                        # rank 0's initial weights
+    sd = {k: v.clone() for k, v in med3d.resnet18segreg().state_dict().items()}
+    xs, ls = zip(*[_inputs(r) for r in range(2)])
+    ref, _ = orc.ddp_emulated_grads(sd, list(xs), list(ls), FACTORY, _loss)
+    ns = {}
+    d, o = orc.forward(sd, torch.cat(xs), torch.cat(ls), FACTORY, train=True, new_stats=ns)
+    g0, g1 = res[0][1], res[1][1]
+    for n in ref:
+        assert torch.equal(g0[n], g1[n]), f"ranks disagree on {n}"          # averaged gradients are identical
+        if n.endswith(".0.bias") and n.startswith("us"):
+            continue
+        assert rel_l2(g0[n], ref[n]) < 3e-2, n                              # tiny-volume flip allowance (see test_network_gpu)
+    worst = max(rel_l2(g0[n], ref[n]) for n in ref if not (n.endswith(".0.bias") and n.startswith("us")))
+    print("worst 2-rank gradient rel-L2 vs DDP+SyncBN emulation:", worst)
+    # SyncBN: both ranks track the statistics of the GLOBAL batch
+    for k in ("bn1.running_mean", "layer4.1.bn2.running_var", "us3.1.running_var"):
+        assert torch.equal(res[0][2][k], res[1][2][k])
+        assert np.allclose(res[0][2][k].numpy(), ns[k].numpy(), rtol=1e-3, atol=1e-5), k
+    # per-rank regression scores = the global-batch forward, sliced
+    for r in range(2):
+        assert abs(res[r][3][0] - float(o[0][r])) < 1e-3 and abs(res[r][3][1] - float(o[1][r])) < 1e-3
