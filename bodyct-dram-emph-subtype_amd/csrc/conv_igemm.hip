@@ -131,10 +131,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
   }
   const int niter = nchunk * ntv;
 
-  float4 ra[8];
-  float4 rb[BQ];
+  // Staging registers are individually named on purpose: as arrays, hipcc's PromoteAlloca
+  // moved `rb` into LDS (+8..16 KB per workgroup and a vmcnt(0) right behind the prefetch).
+  float4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7;
+  float4 rb0, rb1, rb2, rb3;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  ra0 = ra1 = ra2 = ra3 = ra4 = ra5 = ra6 = ra7 = zero4;
+  rb0 = rb1 = rb2 = rb3 = zero4;
 
-  auto load_tile = [&](int it) {
+#define IG_LOAD_A01(P)                                                                              \
+  ra##P = ((rmask[P] & vb) == vb) ? *reinterpret_cast<const float4*>(in + (long)(rbase[P] + toff)) : zero4;
+#define IG_LOAD_A2(P)                                                                               \
+  {                                                                                                 \
+    const int nz_ = rmask[P] - tz * g.dil, ny_ = rcy[P] - ty * g.dil, nx_ = rcx[P] - tx * g.dil;    \
+    const int sz = nz_ / g.stride, sy = ny_ / g.stride, sx = nx_ / g.stride;                        \
+    const bool v = (rbase[P] != 0) & (nz_ >= 0) & (ny_ >= 0) & (nx_ >= 0) & (sz * g.stride == nz_) & \
+                   (sy * g.stride == ny_) & (sx * g.stride == nx_) & (sz < g.Di) & (sy < g.Hi) &     \
+                   (sx < g.Wi);                                                                      \
+    const long o = ((((long)b * g.Di + sz) * g.Hi + sy) * g.Wi + sx) * g.Ci + koff;                  \
+    ra##P = v ? *reinterpret_cast<const float4*>(in + o) : zero4;                                    \
+  }
+
+  auto load_tile = [&](int it) __attribute__((always_inline)) {
     const int c = it / ntv;
     const int tap = (MODE == 2) ? taplist[it - c * ntv] : it - c * ntv;
     const int tz = tap / (g.kh * g.kw);
@@ -145,37 +163,38 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
     if (MODE != 2) {
       const int toff = (((tz * g.step) * g.Hi + ty * g.step) * g.Wi + tx * g.step) * g.Ci + koff;
       const int vb = (1 << tz) | (8 << ty) | (64 << tx);
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const bool v = (rmask[p] & vb) == vb;
-        ra[p] = v ? *reinterpret_cast<const float4*>(in + (long)(rbase[p] + toff))
-                  : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      IG_LOAD_A01(0) IG_LOAD_A01(1) IG_LOAD_A01(2) IG_LOAD_A01(3)
+      IG_LOAD_A01(4) IG_LOAD_A01(5) IG_LOAD_A01(6) IG_LOAD_A01(7)
     } else {
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int nz_ = rmask[p] - tz * g.dil, ny_ = rcy[p] - ty * g.dil, nx_ = rcx[p] - tx * g.dil;
-        const int sz = nz_ / g.stride, sy = ny_ / g.stride, sx = nx_ / g.stride;
-        const bool v = (rbase[p] != 0) & (nz_ >= 0) & (ny_ >= 0) & (nx_ >= 0) & (sz * g.stride == nz_) &
-                       (sy * g.stride == ny_) & (sx * g.stride == nx_) & (sz < g.Di) & (sy < g.Hi) &
-                       (sx < g.Wi);
-        const long o = ((((long)b * g.Di + sz) * g.Hi + sy) * g.Wi + sx) * g.Ci + koff;
-        ra[p] = v ? *reinterpret_cast<const float4*>(in + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      IG_LOAD_A2(0) IG_LOAD_A2(1) IG_LOAD_A2(2) IG_LOAD_A2(3)
+      IG_LOAD_A2(4) IG_LOAD_A2(5) IG_LOAD_A2(6) IG_LOAD_A2(7)
     }
     const float* wrow = wp + ((long)tap * g.No + n0 + row0) * g.Ci + koff;
-#pragma unroll
-    for (int q = 0; q < BQ; ++q)
-      rb[q] = *reinterpret_cast<const float4*>(wrow + (long)(32 * q) * g.Ci);
+    rb0 = *reinterpret_cast<const float4*>(wrow);
+    if (BQ > 1) rb1 = *reinterpret_cast<const float4*>(wrow + (long)32 * g.Ci);
+    if (BQ > 2) {
+      rb2 = *reinterpret_cast<const float4*>(wrow + (long)64 * g.Ci);
+      rb3 = *reinterpret_cast<const float4*>(wrow + (long)96 * g.Ci);
+    }
   };
 
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int p = 0; p < 8; ++p)
-      *reinterpret_cast<float4*>(&As[(row0 + 32 * p) * LDK + col4 * 4]) = ra[p];
-#pragma unroll
-    for (int q = 0; q < BQ; ++q)
-      *reinterpret_cast<float4*>(&Bs[(row0 + 32 * q) * LDK + col4 * 4]) = rb[q];
+  auto store_tile = [&]() __attribute__((always_inline)) {
+    float* ap = &As[row0 * LDK + col4 * 4];
+    *reinterpret_cast<float4*>(ap + 0 * 32 * LDK) = ra0;
+    *reinterpret_cast<float4*>(ap + 1 * 32 * LDK) = ra1;
+    *reinterpret_cast<float4*>(ap + 2 * 32 * LDK) = ra2;
+    *reinterpret_cast<float4*>(ap + 3 * 32 * LDK) = ra3;
+    *reinterpret_cast<float4*>(ap + 4 * 32 * LDK) = ra4;
+    *reinterpret_cast<float4*>(ap + 5 * 32 * LDK) = ra5;
+    *reinterpret_cast<float4*>(ap + 6 * 32 * LDK) = ra6;
+    *reinterpret_cast<float4*>(ap + 7 * 32 * LDK) = ra7;
+    float* bp = &Bs[row0 * LDK + col4 * 4];
+    *reinterpret_cast<float4*>(bp) = rb0;
+    if (BQ > 1) *reinterpret_cast<float4*>(bp + 32 * LDK) = rb1;
+    if (BQ > 2) {
+      *reinterpret_cast<float4*>(bp + 64 * LDK) = rb2;
+      *reinterpret_cast<float4*>(bp + 96 * LDK) = rb3;
+    }
   };
 
   f32x16 acc[2][NJ];
@@ -319,20 +338,35 @@ bool desc_ok(const DramConvDesc* d) {
   return true;
 }
 
+// Workgroups per CU the register/LDS budget admits (see -Rpass-analysis): BN=128 -> 2, else 3.
+// When the grid is a poor multiple of 256 CUs x that many slots (e.g. 1024 tiles on 768 slots
+// = 1.33 rounds) but a good multiple of 2 per CU, pad the launch with dynamic LDS so that only
+// two workgroups fit per CU: 1024 tiles then run as exactly two full rounds.
+int lds_pad_for_balance(int BN, int nblk) {
+  if (BN == 128) return 0;
+  auto eff = [&](int slots) { return (double)nblk / (double)(((nblk + slots - 1) / slots) * slots); };
+  const double e3 = eff(768), e2 = eff(512) * 0.97;  // 2/CU overlaps slightly less
+  if (e2 <= e3) return 0;
+  const int stat = (BM + BN) * LDK * 4;
+  const int need = 160 * 1024 / 3 + 1024;  // > 1/3 of the 160 KB LDS
+  return need > stat ? need - stat : 0;
+}
+
 template <int MODE>
 int launch(int BN, const float* in, const float* wp, const float* bias, float* out, float* stats,
            const float* add, const float* gate, IGemmGeom& g, hipStream_t s) {
   fill_tiles(g, BN);
   dim3 grid(g.nblk), block(256);
+  const int pad = lds_pad_for_balance(BN, g.nblk);
   switch (BN) {
     case 128:
-      hipLaunchKernelGGL((conv_igemm_kernel<128, MODE>), grid, block, 0, s, in, wp, bias, out, stats, add, gate, g);
+      hipLaunchKernelGGL((conv_igemm_kernel<128, MODE>), grid, block, pad, s, in, wp, bias, out, stats, add, gate, g);
       break;
     case 64:
-      hipLaunchKernelGGL((conv_igemm_kernel<64, MODE>), grid, block, 0, s, in, wp, bias, out, stats, add, gate, g);
+      hipLaunchKernelGGL((conv_igemm_kernel<64, MODE>), grid, block, pad, s, in, wp, bias, out, stats, add, gate, g);
       break;
     case 32:
-      hipLaunchKernelGGL((conv_igemm_kernel<32, MODE>), grid, block, 0, s, in, wp, bias, out, stats, add, gate, g);
+      hipLaunchKernelGGL((conv_igemm_kernel<32, MODE>), grid, block, pad, s, in, wp, bias, out, stats, add, gate, g);
       break;
     default:
       return DRAM_ERR_UNSUPPORTED;

@@ -14,6 +14,7 @@
 // LDS rows: A[i=co][k=vox] = dy_lds[vox][co] (lanes = consecutive channels: conflict-free).
 // Split-K over row chunks writes fp32 slabs; a second kernel sums the slabs in a fixed
 // order and scatters into the reference layout [Cout][Cin][kD][kH][kW] -> deterministic.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -32,8 +33,11 @@ struct WGeom {
 // S: stride, DIL: dilation, K3: 1 -> 3x3x3 (9 in-plane taps per block), 0 -> 1x1x1
 // COW x CIW x KW = 4 waves: co-tile = 32*COW, ci-tile = 32*CIW, KW-way split of the
 // 32 voxels of a chunk between waves (extra slab slices).
-template <int S, int DIL, int K3, int COW, int CIW, int KW>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restrict__ x,
+// PF: 1 = register prefetch of the next chunk (1 workgroup per CU: 184+144 registers);
+//     0 = no prefetch, registers capped at 256 so that TWO workgroups share a CU and hide
+//         each other's load phase.
+template <int S, int DIL, int K3, int COW, int CIW, int KW, int PF>
+__global__ __launch_bounds__(256, PF ? 1 : 2) void conv_wgrad_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ dy,
                                                             float* __restrict__ slab, const WGeom g) {
   static_assert(COW * CIW * KW == 4, "4 waves");
@@ -124,29 +128,54 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
     }
   };
 
-  bool cur = (q0 < q1) ? load_chunk(q0) : false;
-  for (int q = q0; q < q1; ++q) {
-    __syncthreads();
-    if (cur) store_chunk();
-    __syncthreads();
-    bool nxt = false;
-    if (q + 1 < q1) nxt = load_chunk(q + 1);
-    if (cur) {
-      constexpr int VPW = 32 / KW;  // voxels per wave
+  if (PF) {
+    bool cur = (q0 < q1) ? load_chunk(q0) : false;
+    for (int q = q0; q < q1; ++q) {
+      __syncthreads();
+      if (cur) store_chunk();
+      __syncthreads();
+      bool nxt = false;
+      if (q + 1 < q1) nxt = load_chunk(q + 1);
+      if (cur) {
+        constexpr int VPW = 32 / KW;  // voxels per wave
 #pragma unroll 4
-      for (int kk = 0; kk < VPW / 2; ++kk) {
-        const int vox = kwv * VPW + 2 * kk + lh;
-        const float a = dyl[vox * LDY + cw * 32 + li];
-        const float* xb = &xl[(vox * S) * LDX + iw * 32 + li];
+        for (int kk = 0; kk < VPW / 2; ++kk) {
+          const int vox = kwv * VPW + 2 * kk + lh;
+          const float a = dyl[vox * LDY + cw * 32 + li];
+          const float* xb = &xl[(vox * S) * LDX + iw * 32 + li];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int ty = t / 3, tx = t % 3;
-          const float bvv = xb[(ty * XW + tx * DIL) * LDX];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) {
+            const int ty = t / 3, tx = t % 3;
+            const float bvv = xb[(ty * XW + tx * DIL) * LDX];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc[t], 0, 0, 0);
+          }
+        }
+      }
+      cur = nxt;
+    }
+  } else {
+    for (int q = q0; q < q1; ++q) {
+      const bool cur = load_chunk(q);   // uniform
+      if (!cur) continue;
+      __syncthreads();                  // previous chunk's LDS readers are done
+      store_chunk();
+      __syncthreads();
+      {
+        constexpr int VPW = 32 / KW;  // voxels per wave
+#pragma unroll 4
+        for (int kk = 0; kk < VPW / 2; ++kk) {
+          const int vox = kwv * VPW + 2 * kk + lh;
+          const float a = dyl[vox * LDY + cw * 32 + li];
+          const float* xb = &xl[(vox * S) * LDX + iw * 32 + li];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int ty = t / 3, tx = t % 3;
+            const float bvv = xb[(ty * XW + tx * DIL) * LDX];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc[t], 0, 0, 0);
+          }
         }
       }
     }
-    cur = nxt;
   }
 
   // ---- write the slab slice ---------------------------------------------------------
@@ -164,7 +193,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
   }
 }
 
-// dW[co][ci][tap] = sum_s slab[s][tap][co][ci]
+// dW[co][ci][tap] = sum_s slab[s][tap][co][ci]   (one thread per output element: small layers
+// have few (co,ci) pairs but hundreds of slabs, so parallelism must come from every element)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslab,
                                     int taps, int Cout, int Cin) {
   const long per = (long)taps * Cout * Cin;
@@ -177,6 +207,16 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     const int tap = (int)(r / Cout);
     dw[((long)co * Cin + ci) * taps + tap] = s;
   }
+}
+
+// A/B switch (tuning): DRAM_WGRAD_PREFETCH=0 selects the 2-workgroups-per-CU variant
+bool wgrad_prefetch() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DRAM_WGRAD_PREFETCH");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v != 0;
 }
 
 struct Plan {
@@ -214,9 +254,16 @@ bool make_plan(const DramConvDesc* d, Plan& p) {
   g.XC = (d->Wo + 31) / 32;
   g.NC = d->B * d->Do * d->Ho * g.XC;
   const int tiles = g.co_tiles * g.ci_tiles * d->k;
-  int ns = (1024 + tiles - 1) / tiles;  // aim at ~4 workgroups per CU
-  if (ns > g.NC) ns = g.NC;
-  if (ns < 1) ns = 1;
+  // split-K factor: 512..1280 workgroups, chosen so that the grid is as close as possible
+  // to a whole number of 256-CU rounds (1026 workgroups would cost a fifth round for 2)
+  int ns = 1;
+  double best = -1.0;
+  for (int c = 1; c <= g.NC && (long)tiles * c <= 1280; ++c) {
+    const long wg = (long)tiles * c;
+    if (wg < 512 && (long)tiles * (c + 1) <= 1280 && c < g.NC) continue;
+    const double eff = (double)wg / (double)(((wg + 255) / 256) * 256);
+    if (eff >= best - 1e-9) { best = eff; ns = c; }
+  }
   // keep the slab below ~192 MB
   const double slab1 = (double)d->k * d->k * d->k * d->Cout * d->Cin * 4.0 * p.kw;
   while (ns > 1 && slab1 * ns > 192e6) --ns;
@@ -247,12 +294,17 @@ extern "C" int dram_conv3d_bwd_weight(const float* x, const float* dy, float* dw
   float* slab = (float*)workspace;
   dim3 grid(p.nblk), block(256);
   const bool narrow = (p.cow == 1);
-#define WG_LAUNCH(S_, D_, K3_)                                                                          \
-  do {                                                                                                  \
-    if (narrow)                                                                                         \
-      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 1, 2, 2>), grid, block, 0, s, x, dy, slab, p.g); \
-    else                                                                                                \
-      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 2, 2, 1>), grid, block, 0, s, x, dy, slab, p.g); \
+  const bool pf = wgrad_prefetch();
+#define WG_LAUNCH(S_, D_, K3_)                                                                             \
+  do {                                                                                                     \
+    if (narrow && pf)                                                                                      \
+      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 1, 2, 2, 1>), grid, block, 0, s, x, dy, slab, p.g); \
+    else if (narrow)                                                                                       \
+      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 1, 2, 2, 0>), grid, block, 0, s, x, dy, slab, p.g); \
+    else if (pf)                                                                                           \
+      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 2, 2, 1, 1>), grid, block, 0, s, x, dy, slab, p.g); \
+    else                                                                                                   \
+      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 2, 2, 1, 0>), grid, block, 0, s, x, dy, slab, p.g); \
   } while (0)
   switch (p.variant) {
     case 0: WG_LAUNCH(1, 1, 1); break;
