@@ -31,25 +31,29 @@ struct WGeom {
 };
 
 // S: stride, DIL: dilation, K3: 1 -> 3x3x3 (9 in-plane taps per block), 0 -> 1x1x1
-// COW x CIW x KW = 4 waves: co-tile = 32*COW, ci-tile = 32*CIW, KW-way split of the
-// 32 voxels of a chunk between waves (extra slab slices).
-// PF: 1 = register prefetch of the next chunk (1 workgroup per CU: 184+144 registers);
-//     0 = no prefetch, registers capped at 256 so that TWO workgroups share a CU and hide
-//         each other's load phase.
-template <int S, int DIL, int K3, int COW, int CIW, int KW, int PF>
-__global__ __launch_bounds__(256, PF ? 1 : 2) void conv_wgrad_kernel(const float* __restrict__ x,
-                                                            const float* __restrict__ dy,
-                                                            float* __restrict__ slab, const WGeom g) {
-  static_assert(COW * CIW * KW == 4, "4 waves");
+// COW x CIW x KW waves (8 = 512 threads, two waves per SIMD so that sibling waves hide each
+// other's ds_read latency and barrier skew): co-tile = 32*COW, ci-tile = 32*CIW; the 32 voxels
+// of a chunk are split KW ways between wave groups, whose accumulators are folded together
+// through LDS (fixed order) once, after the chunk loop.
+template <int S, int DIL, int K3, int COW, int CIW, int KW>
+__global__ __launch_bounds__(64 * COW * CIW * KW, (COW * CIW * KW) / 4) void conv_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, const WGeom g) {
+  constexpr int NW = COW * CIW * KW;
+  constexpr int NTHR = 64 * NW;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   constexpr int NT = K3 ? 9 : 1;
   constexpr int NR = K3 ? 3 : 1;
   constexpr int XW = 31 * S + (K3 ? 2 * DIL : 0) + 1;
   constexpr int CO_T = 32 * COW, CI_T = 32 * CIW;
   constexpr int LDY = CO_T + 4, LDX = CI_T + 4;
-  constexpr int DYP = (32 * (CO_T / 4) + 255) / 256;          // dy float4 per thread
+  constexpr int DYP = (32 * (CO_T / 4) + NTHR - 1) / NTHR;     // dy float4 per thread
   constexpr int XQ = CI_T / 4;                                 // float4 per x voxel row
-  constexpr int XP = (NR * XW * XQ + 255) / 256;               // x float4 per thread
-  __shared__ __attribute__((aligned(16))) float lds[32 * LDY + NR * XW * LDX];
+  constexpr int XP = (NR * XW * XQ + NTHR - 1) / NTHR;         // x float4 per thread
+  constexpr int PAIRS = COW * CIW;
+  constexpr int LDS_TILE = 32 * LDY + NR * XW * LDX;
+  constexpr int LDS_RED = (KW > 1) ? (KW - 1) * PAIRS * 1024 : 0;   // one tap of every folded group
+  constexpr int LDSF = LDS_TILE > LDS_RED ? LDS_TILE : LDS_RED;
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
   float* dyl = lds;
   float* xl = lds + 32 * LDY;
 
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv_wgrad_kernel(const float
     // dy tile: 32 voxels x CO_T
 #pragma unroll
     for (int p = 0; p < DYP; ++p) {
-      const int idx = p * 256 + tid;
+      const int idx = p * NTHR + tid;
       const int v = idx / (CO_T / 4), c4 = idx % (CO_T / 4);
       const bool ok = (idx < 32 * (CO_T / 4)) & (xo0 + v < g.Wo);
       const long o = ((((long)b * g.Do + zo) * g.Ho + yo) * g.Wo + xo0 + v) * g.Cout + co0 + c4 * 4;
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv_wgrad_kernel(const float
     const int xi0 = xo0 * S - g.pad;
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
-      const int idx = p * 256 + tid;
+      const int idx = p * NTHR + tid;
       const int v = idx / XQ, c4 = idx % XQ;
       const int ty = v / XW, xp = v - ty * XW;
       const int yi = yo * S - g.pad + ty * DIL;
@@ -116,72 +120,70 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv_wgrad_kernel(const float
   auto store_chunk = [&]() {
 #pragma unroll
     for (int p = 0; p < DYP; ++p) {
-      const int idx = p * 256 + tid;
+      const int idx = p * NTHR + tid;
       const int v = idx / (CO_T / 4), c4 = idx % (CO_T / 4);
       if (idx < 32 * (CO_T / 4)) *reinterpret_cast<float4*>(&dyl[v * LDY + c4 * 4]) = rdy[p];
     }
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
-      const int idx = p * 256 + tid;
+      const int idx = p * NTHR + tid;
       const int v = idx / XQ, c4 = idx % XQ;
       if (idx < NR * XW * XQ) *reinterpret_cast<float4*>(&xl[v * LDX + c4 * 4]) = rx[p];
     }
   };
 
-  if (PF) {
-    bool cur = (q0 < q1) ? load_chunk(q0) : false;
-    for (int q = q0; q < q1; ++q) {
-      __syncthreads();
-      if (cur) store_chunk();
-      __syncthreads();
-      bool nxt = false;
-      if (q + 1 < q1) nxt = load_chunk(q + 1);
-      if (cur) {
-        constexpr int VPW = 32 / KW;  // voxels per wave
+  bool cur = (q0 < q1) ? load_chunk(q0) : false;
+  for (int q = q0; q < q1; ++q) {
+    __syncthreads();
+    if (cur) store_chunk();
+    __syncthreads();
+    bool nxt = false;
+    if (q + 1 < q1) nxt = load_chunk(q + 1);
+    if (cur) {
+      constexpr int VPW = 32 / KW;  // voxels per wave
 #pragma unroll 4
-        for (int kk = 0; kk < VPW / 2; ++kk) {
-          const int vox = kwv * VPW + 2 * kk + lh;
-          const float a = dyl[vox * LDY + cw * 32 + li];
-          const float* xb = &xl[(vox * S) * LDX + iw * 32 + li];
+      for (int kk = 0; kk < VPW / 2; ++kk) {
+        const int vox = kwv * VPW + 2 * kk + lh;
+        const float a = dyl[vox * LDY + cw * 32 + li];
+        const float* xb = &xl[(vox * S) * LDX + iw * 32 + li];
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const int ty = t / 3, tx = t % 3;
-            const float bvv = xb[(ty * XW + tx * DIL) * LDX];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc[t], 0, 0, 0);
-          }
-        }
-      }
-      cur = nxt;
-    }
-  } else {
-    for (int q = q0; q < q1; ++q) {
-      const bool cur = load_chunk(q);   // uniform
-      if (!cur) continue;
-      __syncthreads();                  // previous chunk's LDS readers are done
-      store_chunk();
-      __syncthreads();
-      {
-        constexpr int VPW = 32 / KW;  // voxels per wave
-#pragma unroll 4
-        for (int kk = 0; kk < VPW / 2; ++kk) {
-          const int vox = kwv * VPW + 2 * kk + lh;
-          const float a = dyl[vox * LDY + cw * 32 + li];
-          const float* xb = &xl[(vox * S) * LDX + iw * 32 + li];
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const int ty = t / 3, tx = t % 3;
-            const float bvv = xb[(ty * XW + tx * DIL) * LDX];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc[t], 0, 0, 0);
-          }
+        for (int t = 0; t < NT; ++t) {
+          const int ty = t / 3, tx = t % 3;
+          const float bvv = xb[(ty * XW + tx * DIL) * LDX];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc[t], 0, 0, 0);
         }
       }
     }
+    cur = nxt;
+  }
+
+  // ---- fold the KW voxel-groups into group 0 (one tap per pass through LDS) -----------
+  if (KW > 1) {
+    const int pair = cw + COW * iw;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      __syncthreads();
+      if (kwv > 0) {
+        float* dst = &lds[((kwv - 1) * PAIRS + pair) * 1024 + lane];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dst[e * 64] = acc[t][e];
+      }
+      __syncthreads();
+      if (kwv == 0) {
+#pragma unroll
+        for (int gq = 1; gq < KW; ++gq) {
+          const float* src = &lds[((gq - 1) * PAIRS + pair) * 1024 + lane];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[t][e] += src[e * 64];
+        }
+      }
+    }
+    if (kwv != 0) return;
   }
 
   // ---- write the slab slice ---------------------------------------------------------
-  const int sidx = split * KW + kwv;
   const long tap_stride = (long)g.Cout * g.Cin;
-  float* sl = slab + ((long)sidx * g.k + tz) * NT * tap_stride;
+  float* sl = slab + ((long)split * g.k + tz) * NT * tap_stride;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -209,12 +211,12 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   }
 }
 
-// A/B switch (tuning): DRAM_WGRAD_PREFETCH=0 selects the 2-workgroups-per-CU variant
-bool wgrad_prefetch() {
+// A/B switch (tuning): DRAM_WGRAD_WAVES=4 selects the 4-wave (one wave per SIMD) variant
+bool wgrad_8waves() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("DRAM_WGRAD_PREFETCH");
-    v = (e && e[0] == '0') ? 0 : 1;
+    const char* e = getenv("DRAM_WGRAD_WAVES");
+    v = (e && e[0] == '4') ? 0 : 1;
   }
   return v != 0;
 }
@@ -248,7 +250,7 @@ bool make_plan(const DramConvDesc* d, Plan& p) {
   }
   const bool narrow = (d->Cout % 64 != 0);
   p.cow = narrow ? 1 : 2;
-  p.kw = narrow ? 2 : 1;
+  p.kw = 1;   // voxel groups are folded in-kernel: one slab slice per split
   g.co_tiles = d->Cout / (32 * p.cow);
   g.ci_tiles = d->Cin / 64;
   g.XC = (d->Wo + 31) / 32;
@@ -292,19 +294,19 @@ extern "C" int dram_conv3d_bwd_weight(const float* x, const float* dy, float* dw
   if (!workspace || workspace_bytes < need) return DRAM_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   float* slab = (float*)workspace;
-  dim3 grid(p.nblk), block(256);
+  dim3 grid(p.nblk);
   const bool narrow = (p.cow == 1);
-  const bool pf = wgrad_prefetch();
-#define WG_LAUNCH(S_, D_, K3_)                                                                             \
-  do {                                                                                                     \
-    if (narrow && pf)                                                                                      \
-      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 1, 2, 2, 1>), grid, block, 0, s, x, dy, slab, p.g); \
-    else if (narrow)                                                                                       \
-      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 1, 2, 2, 0>), grid, block, 0, s, x, dy, slab, p.g); \
-    else if (pf)                                                                                           \
-      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 2, 2, 1, 1>), grid, block, 0, s, x, dy, slab, p.g); \
-    else                                                                                                   \
-      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 2, 2, 1, 0>), grid, block, 0, s, x, dy, slab, p.g); \
+  const bool w8 = wgrad_8waves();
+#define WG_LAUNCH(S_, D_, K3_)                                                                              \
+  do {                                                                                                      \
+    if (narrow && w8)                                                                                       \
+      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 1, 2, 4>), grid, dim3(512), 0, s, x, dy, slab, p.g); \
+    else if (narrow)                                                                                        \
+      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 1, 2, 2>), grid, dim3(256), 0, s, x, dy, slab, p.g); \
+    else if (w8)                                                                                            \
+      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 2, 2, 2>), grid, dim3(512), 0, s, x, dy, slab, p.g); \
+    else                                                                                                    \
+      hipLaunchKernelGGL((conv_wgrad_kernel<S_, D_, K3_, 2, 2, 1>), grid, dim3(256), 0, s, x, dy, slab, p.g); \
   } while (0)
   switch (p.variant) {
     case 0: WG_LAUNCH(1, 1, 1); break;
