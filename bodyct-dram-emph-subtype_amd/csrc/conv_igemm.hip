@@ -21,6 +21,7 @@
 // multiplies A[.][8g+4h+e] x B[8g+4h+e][.] for both halves (k order inside the
 // reduction is free as long as A and B agree).  LDS rows are padded to 36 floats:
 // conflict-free for the ds_read_b128 lane groups.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -29,6 +30,16 @@ constexpr int BM = 256;
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;  // padded LDS row (floats)
 constexpr int TZ = 4, TY = 8, TX = 8;
+
+__device__ __forceinline__ float4 mask4(const float4 t, const bool v) {
+  const unsigned m = v ? 0xffffffffu : 0u;
+  float4 r;
+  r.x = __uint_as_float(__float_as_uint(t.x) & m);
+  r.y = __uint_as_float(__float_as_uint(t.y) & m);
+  r.z = __uint_as_float(__float_as_uint(t.z) & m);
+  r.w = __uint_as_float(__float_as_uint(t.w) & m);
+  return r;
+}
 
 struct IGemmGeom {
   int B, Do, Ho, Wo, No;  // tensor written (M rows x N cols)
@@ -45,7 +56,14 @@ struct IGemmGeom {
 
 // MODE 0: forward (any stride/dilation) and MODE 1: data-gradient with stride 1 share
 // the affine source map; MODE 2: data-gradient with stride > 1 (divisibility test).
-template <int BN, int MODE>
+// LV (A-tile prefetch form; A/B measured on one MI355X, fwd 64->64 @64x128x128 / 512->512 d4):
+//   0  `valid ? *p : 0`   -> hipcc emits flat_load from a selected address; FLAT ops also count
+//      on lgkmcnt, so the prefetch completes before the MFMA phase starts: 112 / 128 TFLOP/s
+//   1  unconditional global_load + bit-mask at store time, in flight during the MFMAs: 109 / 117
+//   2  as 1 but issued after the first k-group of MFMAs: 111 / 124
+// Memory returns landing in VGPRs during the fp32 MFMA phase cost more than the exposed latency
+// (which the other 2 workgroups on the CU cover), so 0 is the default; DRAM_IGEMM_LV selects.
+template <int BN, int MODE, int LV>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, float* __restrict__ stats, const float* __restrict__ add,
@@ -136,11 +154,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
   float4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7;
   float4 rb0, rb1, rb2, rb3;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  ra0 = ra1 = ra2 = ra3 = ra4 = ra5 = ra6 = ra7 = zero4;
-  rb0 = rb1 = rb2 = rb3 = zero4;
+  ra0 = ra1 = ra2 = ra3 = ra4 = ra5 = ra6 = ra7 = make_float4(0.f, 0.f, 0.f, 0.f);
+  rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+// Always a global_load from an in-bounds address (offset 0 when the tap falls outside the
+// volume) followed by a select of the VALUE: selecting between addresses made hipcc emit
+// flat_load against a scratch-resident zero, and FLAT ops also count on lgkmcnt, so the
+// ds_read wait in front of the MFMAs drained the prefetch.
 #define IG_LOAD_A01(P)                                                                              \
-  ra##P = ((rmask[P] & vb) == vb) ? *reinterpret_cast<const float4*>(in + (long)(rbase[P] + toff)) : zero4;
+  if (LV == 0) {                                                                                    \
+    ra##P = ((rmask[P] & vb) == vb) ? *reinterpret_cast<const float4*>(in + (long)(rbase[P] + toff)) : zero4; \
+  } else {                                                                                          \
+    const bool v = (rmask[P] & vb) == vb;                                                           \
+    const float4 t_ = *reinterpret_cast<const float4*>(in + (v ? (long)(rbase[P] + toff) : (long)koff)); \
+    ra##P = t_;                                                                                     \
+    amask |= v ? (1u << P) : 0u;                                                                    \
+  }
 #define IG_LOAD_A2(P)                                                                               \
   {                                                                                                 \
     const int nz_ = rmask[P] - tz * g.dil, ny_ = rcy[P] - ty * g.dil, nx_ = rcx[P] - tx * g.dil;    \
@@ -149,10 +178,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
                    (sy * g.stride == ny_) & (sx * g.stride == nx_) & (sz < g.Di) & (sy < g.Hi) &     \
                    (sx < g.Wi);                                                                      \
     const long o = ((((long)b * g.Di + sz) * g.Hi + sy) * g.Wi + sx) * g.Ci + koff;                  \
-    ra##P = v ? *reinterpret_cast<const float4*>(in + o) : zero4;                                    \
+    const float4 t_ = *reinterpret_cast<const float4*>(in + (v ? o : (long)koff));                   \
+    ra##P = t_;                                                                                      \
+    amask |= v ? (1u << P) : 0u;                                                                     \
   }
 
+  unsigned amask = 0;  // validity of the 8 prefetched A rows (applied when they are stored)
   auto load_tile = [&](int it) __attribute__((always_inline)) {
+    amask = 0;
     const int c = it / ntv;
     const int tap = (MODE == 2) ? taplist[it - c * ntv] : it - c * ntv;
     const int tz = tap / (g.kh * g.kw);
@@ -180,14 +213,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
 
   auto store_tile = [&]() __attribute__((always_inline)) {
     float* ap = &As[row0 * LDK + col4 * 4];
-    *reinterpret_cast<float4*>(ap + 0 * 32 * LDK) = ra0;
-    *reinterpret_cast<float4*>(ap + 1 * 32 * LDK) = ra1;
-    *reinterpret_cast<float4*>(ap + 2 * 32 * LDK) = ra2;
-    *reinterpret_cast<float4*>(ap + 3 * 32 * LDK) = ra3;
-    *reinterpret_cast<float4*>(ap + 4 * 32 * LDK) = ra4;
-    *reinterpret_cast<float4*>(ap + 5 * 32 * LDK) = ra5;
-    *reinterpret_cast<float4*>(ap + 6 * 32 * LDK) = ra6;
-    *reinterpret_cast<float4*>(ap + 7 * 32 * LDK) = ra7;
+    *reinterpret_cast<float4*>(ap + 0 * 32 * LDK) = (LV == 0) ? ra0 : mask4(ra0, amask & 1u);
+    *reinterpret_cast<float4*>(ap + 1 * 32 * LDK) = (LV == 0) ? ra1 : mask4(ra1, amask & 2u);
+    *reinterpret_cast<float4*>(ap + 2 * 32 * LDK) = (LV == 0) ? ra2 : mask4(ra2, amask & 4u);
+    *reinterpret_cast<float4*>(ap + 3 * 32 * LDK) = (LV == 0) ? ra3 : mask4(ra3, amask & 8u);
+    *reinterpret_cast<float4*>(ap + 4 * 32 * LDK) = (LV == 0) ? ra4 : mask4(ra4, amask & 16u);
+    *reinterpret_cast<float4*>(ap + 5 * 32 * LDK) = (LV == 0) ? ra5 : mask4(ra5, amask & 32u);
+    *reinterpret_cast<float4*>(ap + 6 * 32 * LDK) = (LV == 0) ? ra6 : mask4(ra6, amask & 64u);
+    *reinterpret_cast<float4*>(ap + 7 * 32 * LDK) = (LV == 0) ? ra7 : mask4(ra7, amask & 128u);
     float* bp = &Bs[row0 * LDK + col4 * 4];
     *reinterpret_cast<float4*>(bp) = rb0;
     if (BQ > 1) *reinterpret_cast<float4*>(bp + 32 * LDK) = rb1;
@@ -215,9 +248,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
     __syncthreads();  // every wave has finished reading the previous tile
     store_tile();
     __syncthreads();
-    if (it + 1 < niter) load_tile(it + 1);  // in flight during the MFMAs below
+    if (LV != 2 && it + 1 < niter) load_tile(it + 1);  // in flight during the MFMAs below
 #pragma unroll
     for (int gk = 0; gk < BK / 8; ++gk) {
+      if (LV == 2 && gk == 1 && it + 1 < niter) load_tile(it + 1);
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(a_rd + gk * 8);
       const f32x4 a1 = *reinterpret_cast<const f32x4*>(a_rd + 32 * LDK + gk * 8);
       f32x4 bf[NJ];
@@ -343,6 +377,7 @@ bool desc_ok(const DramConvDesc* d) {
 // = 1.33 rounds) but a good multiple of 2 per CU, pad the launch with dynamic LDS so that only
 // two workgroups fit per CU: 1024 tiles then run as exactly two full rounds.
 int lds_pad_for_balance(int BN, int nblk) {
+  if (const char* e = getenv("DRAM_IGEMM_PAD")) return atoi(e);   // tuning knob
   if (BN == 128) return 0;
   auto eff = [&](int slots) { return (double)nblk / (double)(((nblk + slots - 1) / slots) * slots); };
   const double e3 = eff(768), e2 = eff(512) * 0.97;  // 2/CU overlaps slightly less
@@ -358,19 +393,27 @@ int launch(int BN, const float* in, const float* wp, const float* bias, float* o
   fill_tiles(g, BN);
   dim3 grid(g.nblk), block(256);
   const int pad = lds_pad_for_balance(BN, g.nblk);
-  switch (BN) {
-    case 128:
-      hipLaunchKernelGGL((conv_igemm_kernel<128, MODE>), grid, block, pad, s, in, wp, bias, out, stats, add, gate, g);
-      break;
-    case 64:
-      hipLaunchKernelGGL((conv_igemm_kernel<64, MODE>), grid, block, pad, s, in, wp, bias, out, stats, add, gate, g);
-      break;
-    case 32:
-      hipLaunchKernelGGL((conv_igemm_kernel<32, MODE>), grid, block, pad, s, in, wp, bias, out, stats, add, gate, g);
-      break;
-    default:
-      return DRAM_ERR_UNSUPPORTED;
+  static int lv = -1;
+  if (lv < 0) {
+    const char* e = getenv("DRAM_IGEMM_LV");
+    lv = e ? atoi(e) : 0;
   }
+#define IG_LAUNCH(BN_, LV_) \
+  hipLaunchKernelGGL((conv_igemm_kernel<BN_, MODE, LV_>), grid, block, pad, s, in, wp, bias, out, stats, add, gate, g)
+#define IG_LAUNCH_LV(BN_)          \
+  do {                             \
+    if (lv == 1) IG_LAUNCH(BN_, 1); \
+    else if (lv == 2) IG_LAUNCH(BN_, 2); \
+    else IG_LAUNCH(BN_, 0);        \
+  } while (0)
+  switch (BN) {
+    case 128: IG_LAUNCH_LV(128); break;
+    case 64: IG_LAUNCH_LV(64); break;
+    case 32: IG_LAUNCH_LV(32); break;
+    default: return DRAM_ERR_UNSUPPORTED;
+  }
+#undef IG_LAUNCH_LV
+#undef IG_LAUNCH
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

@@ -1,0 +1,41 @@
+"""Single-layer micro-benchmark of the conv kernels (HIP events), for A/B tuning.
+   python tools/conv_bench.py B D H W Cin Cout k stride dil [fwd|dgrad|wgrad] [iters]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bodyct_dram_emph_subtype_amd import ops
+import bodyct_dram_emph_subtype_amd as dram
+
+dram.load_library()
+B, D, H, W, Cin, Cout, k, stride, dil = [int(v) for v in sys.argv[1:10]]
+modes = sys.argv[10].split(",") if len(sys.argv) > 10 else ["fwd", "dgrad", "wgrad"]
+iters = int(sys.argv[11]) if len(sys.argv) > 11 else 10
+pad = dil * (k - 1) // 2
+g = ops.ConvGeom(B, D, H, W, Cin, Cout, k, stride, pad, dil)
+dev = "cuda:0"
+x = torch.randn(g.in_shape, device=dev)
+w = torch.randn(Cout, Cin, k, k, k, device=dev) * 0.05
+dy = torch.randn(g.out_shape, device=dev)
+wf, wb = ops.pack_conv_weight(w)
+
+
+def run(mode):
+    if mode == "fwd":
+        return ops.conv3d_fwd(x, wf, None, g, True)
+    if mode == "dgrad":
+        return ops.conv3d_bwd_data(dy, wb, g)
+    return ops.conv3d_bwd_weight(x, dy, g)
+
+
+for mode in modes:
+    for _ in range(2):
+        run(mode)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        run(mode)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    print(f"{mode:6s} {g}  {ms:8.3f} ms  {g.flops / ms / 1e9:7.1f} TFLOP/s", flush=True)
