@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
                    (sx < g.Wi);                                                                      \
     const long o = ((((long)b * g.Di + sz) * g.Hi + sy) * g.Wi + sx) * g.Ci + koff;                  \
     const float4 t_ = *reinterpret_cast<const float4*>(in + (v ? o : (long)koff));                   \
-    ra##P = t_;                                                                                      \
+    ra##P = (LV == 0) ? mask4(t_, v) : t_;   /* LV 0 stores unmasked: mask here */                   \
     amask |= v ? (1u << P) : 0u;                                                                     \
   }
 

@@ -28,7 +28,7 @@ def _loss(rank, dense, outs):
     return (1.0 + rank) * outs[0].sum() - 0.5 * outs[1].sum() + 0.1 * (dense[0] * dense[1]).mean()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, outdir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -45,7 +45,9 @@ def _worker(rank, world, port, q):
         torch.cuda.synchronize()
         grads = {n: p.grad.cpu() for n, p in m.named_parameters()}
         stats = {k: v.cpu() for k, v in m.state_dict().items() if "running" in k}
-        q.put((rank, grads, stats, [float(o) for o in outs]))
+        # results go through a file: passing torch tensors through mp.Queue hands over fds that
+        # die with the worker process
+        torch.save((rank, grads, stats, [float(o.detach()) for o in outs]), os.path.join(outdir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -53,15 +55,17 @@ def _worker(rank, world, port, q):
 def test_two_rank_engine_matches_ddp_syncbn_emulation():
     from oracle import med3d_oracle as orc
     from bodyct_dram_emph_subtype_amd import med3d
+    import tempfile
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
     port = 33500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(60)
+    with tempfile.TemporaryDirectory() as outdir:
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, outdir)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0, f"rank process failed with {p.exitcode}"
+        res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(2)]
     torch.manual_seed(21)                        # rank 0's initial weights
     sd = {k: v.clone() for k, v in med3d.resnet18segreg().state_dict().items()}
     xs, ls = zip(*[_inputs(r) for r in range(2)])
