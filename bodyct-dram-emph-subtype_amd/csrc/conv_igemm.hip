@@ -325,6 +325,219 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
   }
 }
 
+// =====================================================================================
+// v2: the same implicit GEMM with the tiles staged by LDS-DMA (global_load_lds_dwordx4)
+// instead of registers.  No VGPR staging and no ds_write pass: the prefetch of tile it+1 is
+// truly asynchronous to the MFMAs of tile it (it never touches the register file), LDS is
+// double-buffered and one barrier per K-step remains.
+//   * LDS rows are the raw 128-B lines (no padding: an LDS-DMA wave-instruction writes 1 KiB
+//     contiguously = 8 rows); bank conflicts are removed by an XOR swizzle of the 16-B slot,
+//     slot' = slot ^ ((row >> 1) & 7), applied on the per-lane SOURCE address and on the
+//     ds_read_b128 address (the DMA destination stays linear).
+//   * taps that fall outside the volume read from a zero line in global memory.
+//   * each wave DMAs exactly the 64 A rows it later multiplies; the B tile is shared.
+__device__ __attribute__((aligned(128))) float g_zero_line[32];
+
+template <int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(
+    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ out, float* __restrict__ stats, const float* __restrict__ add,
+    const float* __restrict__ gate, const IGemmGeom g) {
+  static_assert(MODE == 0 || MODE == 1, "v2 covers the affine source maps");
+  constexpr int NJ = BN / 32;
+  constexpr int STAGE = (BM + BN) * 32;           // floats per stage
+  __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int L = xcd_remap(blockIdx.x, g.nblk);
+  const int n_tile = L % g.n_tiles;
+  int mt = L / g.n_tiles;
+  const int b = mt / g.tiles_per_b;
+  int r = mt - b * g.tiles_per_b;
+  const int txi = r % g.nx; r /= g.nx;
+  const int tyi = r % g.ny; r /= g.ny;
+  const int tzi = r % g.nz; r /= g.nz;
+  const int rx = r % g.lat; r /= g.lat;
+  const int ry = r % g.lat;
+  const int rz = r / g.lat;
+  const int n0 = n_tile * BN;
+
+  // ---- the 8 A rows this lane feeds (DMA instruction j covers rows 64*wave + 8j .. +7) ----
+  const int sub = lane >> 3;           // row within the 8-row DMA piece
+  const int pslot = lane & 7;          // physical 16-B slot written by this lane
+  const int s_even = pslot ^ (lane >> 4);   // logical slot for even j  ((row>>1)&7 = (4j + lane>>4)&7)
+  const int s_odd = s_even ^ 4;
+  int rbase[8], rmask[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = wave * 64 + j * 8 + sub;
+    const int zo = ((tzi * TZ + (row >> 6)) * g.lat + rz);
+    const int yo = ((tyi * TY + ((row >> 3) & 7)) * g.lat + ry);
+    const int xo = ((txi * TX + (row & 7)) * g.lat + rx);
+    const bool rv = (zo < g.Do) & (yo < g.Ho) & (xo < g.Wo);
+    const int cz = zo * g.mul + g.off, cy = yo * g.mul + g.off, cx = xo * g.mul + g.off;
+    rbase[j] = (((b * g.Di + cz) * g.Hi + cy) * g.Wi + cx) * g.Ci + ((j & 1) ? s_odd : s_even) * 4;
+    int m = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int z = cz + t * g.step, y = cy + t * g.step, x = cx + t * g.step;
+      m |= ((z >= 0) & (z < g.Di)) ? (1 << t) : 0;
+      m |= ((y >= 0) & (y < g.Hi)) ? (8 << t) : 0;
+      m |= ((x >= 0) & (x < g.Wi)) ? (64 << t) : 0;
+    }
+    rmask[j] = rv ? m : 0;
+  }
+  // B rows of this lane: piece jj covers rows (BN/4)*wave + 8*jj .. +7
+  constexpr int BJ = BN / 32;
+  int boff[BJ];
+#pragma unroll
+  for (int jj = 0; jj < BJ; ++jj) {
+    const int nrow = wave * (BN / 4) + jj * 8 + sub;
+    const int sl = pslot ^ ((nrow >> 1) & 7);
+    boff[jj] = (n0 + nrow) * g.Ci + sl * 4;
+  }
+
+  const int nchunk = g.Ci / BK;
+  const int niter = nchunk * g.taps;
+  const float* zline = g_zero_line + pslot * 4;
+
+  // DMA pieces of one tile: 8 A pieces (this wave's 64 rows) + BJ B pieces; piece p is issued
+  // by issue_piece so that the K-loop can drop one piece into each MFMA step's shadow.
+  constexpr int NP = 8 + BJ;
+  int n_toff = 0, n_vb = 0;          // tap offset / validity bits of the tile being prefetched
+  const float* n_wt = wp;
+  float* n_as = lds;
+  float* n_bs = lds;
+  auto begin_tile = [&](int it, int stage) __attribute__((always_inline)) {
+    const int c = it / g.taps;
+    const int tap = it - c * g.taps;
+    const int tz = tap / (g.kh * g.kw);
+    const int trem = tap - tz * (g.kh * g.kw);
+    const int ty = trem / g.kw;
+    const int tx = trem - ty * g.kw;
+    n_toff = (((tz * g.step) * g.Hi + ty * g.step) * g.Wi + tx * g.step) * g.Ci + c * BK;
+    n_vb = (1 << tz) | (8 << ty) | (64 << tx);
+    n_as = lds + stage * STAGE + wave * 64 * 32;
+    n_bs = lds + stage * STAGE + BM * 32 + wave * (BN / 4) * 32;
+    n_wt = wp + (long)tap * g.No * g.Ci + c * BK;
+  };
+#define IG2_PIECE(P)                                                                                   \
+  if ((P) < 8) {                                                                                        \
+    const bool v_ = (rmask[(P) & 7] & n_vb) == n_vb;                                                    \
+    const float* src_ = v_ ? in + (long)(rbase[(P) & 7] + n_toff) : zline;                              \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,               \
+                                     (__attribute__((address_space(3))) void*)(n_as + ((P) & 7) * 8 * 32), 16, 0, 0); \
+  } else if ((P) < NP) {                                                                                \
+    constexpr int jj_ = ((P) - 8) < BJ ? ((P) - 8) : 0;                                                 \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(n_wt + boff[jj_]), \
+                                     (__attribute__((address_space(3))) void*)(n_bs + jj_ * 8 * 32), 16, 0, 0); \
+  }
+  auto issue = [&](int it, int stage) __attribute__((always_inline)) {
+    begin_tile(it, stage);
+    IG2_PIECE(0) IG2_PIECE(1) IG2_PIECE(2) IG2_PIECE(3) IG2_PIECE(4) IG2_PIECE(5) IG2_PIECE(6) IG2_PIECE(7)
+    IG2_PIECE(8) IG2_PIECE(9) IG2_PIECE(10) IG2_PIECE(11)
+  };
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
+
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int rsw = (li >> 1) & 7;   // swizzle of the rows this lane reads (row offsets are multiples of 32)
+  const int a_row = (wave * 64 + li) * 32;
+  const int b_row = BM * 32 + li * 32;
+
+  // All DMA pieces of tile it+1 are issued right behind the barrier, ahead of the MFMAs of tile
+  // it.  (Dropping one piece into each MFMA step's shadow measured 3-4 % SLOWER on the same
+  // device: an LDS-DMA issue among ds_reads + MFMAs costs 100-185 cycles.)
+  if (niter > 0) issue(0, 0);
+  for (int it = 0; it < niter; ++it) {
+    __syncthreads();  // tile `it` has landed (vmcnt(0) + barrier); stage (it+1)&1 is free again
+    if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
+    const float* st = lds + (it & 1) * STAGE;
+#pragma unroll
+    for (int gk = 0; gk < BK / 8; ++gk) {
+      const int so = ((2 * gk + lh) ^ rsw) * 4;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(st + a_row + so);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(st + a_row + 32 * 32 + so);
+      f32x4 bf[NJ];
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) bf[nj] = *reinterpret_cast<const f32x4*>(st + b_row + nj * 32 * 32 + so);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+          acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bf[nj][e], acc[0][nj], 0, 0, 0);
+          acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bf[nj][e], acc[1][nj], 0, 0, 0);
+        }
+      }
+    }
+  }
+#undef IG2_PIECE
+
+  // ---- epilogue (identical to v1) --------------------------------------------------------
+  float s1[NJ], s2[NJ], bv[NJ];
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj) {
+    s1[nj] = 0.f;
+    s2[nj] = 0.f;
+    bv[nj] = bias ? bias[n0 + nj * 32 + li] : 0.f;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wave * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      const int zo = ((tzi * TZ + (row >> 6)) * g.lat + rz);
+      const int yo = ((tyi * TY + ((row >> 3) & 7)) * g.lat + ry);
+      const int xo = ((txi * TX + (row & 7)) * g.lat + rx);
+      const bool rv = (zo < g.Do) & (yo < g.Ho) & (xo < g.Wo);
+      const long o = ((((long)b * g.Do + zo) * g.Ho + yo) * g.Wo + xo) * g.No + n0 + li;
+      if (rv) {
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+          float v = acc[mi][nj][e] + bv[nj];
+          if (add) {
+            const float av = add[o + nj * 32];
+            v += gate ? (gate[o + nj * 32] > 0.f ? av : 0.f) : av;
+          }
+          out[o + nj * 32] = v;
+          s1[nj] += v;
+          s2[nj] += v * v;
+        }
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    float* red = lds;  // [4 waves][2][BN]
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+      const float t1 = s1[nj] + __shfl_xor(s1[nj], 32, 64);
+      const float t2 = s2[nj] + __shfl_xor(s2[nj], 32, 64);
+      if (lh == 0) {
+        red[(wave * 2 + 0) * BN + nj * 32 + li] = t1;
+        red[(wave * 2 + 1) * BN + nj * 32 + li] = t2;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, c = tid - which * BN;
+      const float v = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c] +
+                      red[(2 * 2 + which) * BN + c] + red[(3 * 2 + which) * BN + c];
+      stats[((long)mt * 2 + which) * g.No + n0 + c] = v;
+    }
+  }
+}
+
 int pick_bn(int N) {
   if (N % 128 == 0) return 128;
   if (N % 64 == 0) return 64;
@@ -393,10 +606,30 @@ int launch(int BN, const float* in, const float* wp, const float* bias, float* o
   fill_tiles(g, BN);
   dim3 grid(g.nblk), block(256);
   const int pad = lds_pad_for_balance(BN, g.nblk);
-  static int lv = -1;
+  static int lv = -1, ver = -1;
   if (lv < 0) {
     const char* e = getenv("DRAM_IGEMM_LV");
     lv = e ? atoi(e) : 0;
+    const char* v = getenv("DRAM_IGEMM_V");
+    ver = v ? atoi(v) : 0;   // 0 = auto: LDS-DMA kernel for BN <= 64, register-staged for BN = 128
+  }
+  if ((ver == 2 || (ver == 0 && BN <= 64)) && MODE != 2) {
+    constexpr int M2 = MODE == 2 ? 0 : MODE;
+    switch (BN) {
+      case 128:
+        hipLaunchKernelGGL((conv_igemm2_kernel<128, M2>), grid, block, 0, s, in, wp, bias, out, stats, add, gate, g);
+        break;
+      case 64:
+        hipLaunchKernelGGL((conv_igemm2_kernel<64, M2>), grid, block, 0, s, in, wp, bias, out, stats, add, gate, g);
+        break;
+      case 32:
+        hipLaunchKernelGGL((conv_igemm2_kernel<32, M2>), grid, block, 0, s, in, wp, bias, out, stats, add, gate, g);
+        break;
+      default:
+        return DRAM_ERR_UNSUPPORTED;
+    }
+    DRAM_LAUNCH_CHECK();
+    return DRAM_OK;
   }
 #define IG_LAUNCH(BN_, LV_) \
   hipLaunchKernelGGL((conv_igemm_kernel<BN_, MODE, LV_>), grid, block, pad, s, in, wp, bias, out, stats, add, gate, g)
