@@ -103,3 +103,35 @@ def test_loss_host_algebra_matches_oracle():
     assert torch.allclose(a, b)
     assert torch.equal(models.ratio_to_label(outs, "cle"), orc.ratio_to_label(outs, orc.CLE_RATIO_MAP))
     assert torch.equal(models.ratio_to_label(outs, "pse"), orc.ratio_to_label(outs, orc.PSE_RATIO_MAP))
+
+
+def test_trainer_harness_flags_and_checkpoint_roundtrip(tmp_path):
+    """train.py surface: reference flag names/defaults, Lightning-shaped checkpoints, newest-file
+    discovery, --reload_only_weights (greedy weights, fresh optimizer) vs full resume."""
+    import time
+    from bodyct_dram_emph_subtype_amd import models, train
+    a = train.build_parser().parse_args([])
+    assert (a.model_arch, a.lr, a.ngpus, a.batch_size, a.num_samples, a.reload_only_weights, a.max_epochs) == \
+        ("med3ddram50", 1e-4, 1, 1, 128, 1, 120)
+    assert tuple(a.target_size) == (128, 224, 288) and a.momentum == 0.9 and a.weight_decay == 1e-5
+    args = train.build_parser().parse_args(["--model_arch", "med3ddram18", "--lr", "3e-4"])
+    mod = models.ScanRegLightningModule(args)
+    assert all(k.startswith("model.") for k in mod.state_dict())          # Lightning ckpt key contract
+    opt = torch.optim.Adam(mod.parameters(), lr=args.lr)                  # CPU stand-in for the optimizer state
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.95)
+    ck = train.checkpoint_dict(mod, opt, sched, 3, 42, args)
+    assert set(ck) >= {"epoch", "global_step", "state_dict", "optimizer_states", "lr_schedulers"}
+    assert train.find_checkpoint(tmp_path) is None
+    torch.save(ck, tmp_path / "epoch=03.ckpt")
+    time.sleep(0.05)
+    torch.save({k: v + 1 for k, v in ck["state_dict"].items() if v.is_floating_point()}, tmp_path / "weights.pth")
+    assert train.find_checkpoint(tmp_path).endswith("weights.pth")        # newest by ctime
+    assert train.find_checkpoint(tmp_path, "epoch=03.ckpt").endswith("epoch=03.ckpt")
+    fresh = models.ScanRegLightningModule(args)
+    o2 = torch.optim.Adam(fresh.parameters(), lr=1.0)
+    s2 = torch.optim.lr_scheduler.ExponentialLR(o2, gamma=0.95)
+    assert train.restore(fresh, o2, s2, str(tmp_path / "epoch=03.ckpt"), reload_only_weights=False) == 4
+    assert torch.equal(fresh.state_dict()["model.conv1.weight"], mod.state_dict()["model.conv1.weight"])
+    assert abs(o2.param_groups[0]["lr"] - args.lr) < 1e-12               # optimizer state restored
+    assert train.restore(fresh, o2, s2, str(tmp_path / "weights.pth"), reload_only_weights=True) == 0
+    assert torch.allclose(fresh.state_dict()["model.conv1.weight"], mod.state_dict()["model.conv1.weight"] + 1)

@@ -113,3 +113,22 @@ def test_metrics_dropins():
     bce = metrics.BinaryCrossEntropy()(tgt.to(DEV), (0.4 * a).to(DEV), (0.4 * b).to(DEV), mask.to(DEV), smoothness=0.85)
     ref = orc.balanced_bce(tgt, torch.clamp(0.4 * a + 0.4 * b, 0, 1), mask, smoothness=0.85)
     assert abs(float(bce) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+
+
+def test_trainer_harness_two_epochs_and_resume(tmp_path):
+    """End to end through train.run_training_job on synthetic batches: per-epoch checkpoints named
+    like Lightning's '{epoch:02d}', loss finite, full resume continues at the next epoch."""
+    import os
+    from bodyct_dram_emph_subtype_amd import train
+    argv = ["--model_arch", "med3ddram18", "--model_path", str(tmp_path), "--num_samples", "2", "--batch_size", "1",
+            "--target_size", "16", "32", "32", "--max_epochs", "2", "--log_every_n_steps", "1"]
+    mod = train.run_training_job(argv)
+    ck = tmp_path / "subtyping_med3ddram18" / "checkpoints"
+    assert sorted(os.listdir(ck)) == ["epoch=00.ckpt", "epoch=01.ckpt"]
+    c1 = torch.load(ck / "epoch=01.ckpt", map_location="cpu", weights_only=False)
+    assert c1["epoch"] == 1 and c1["global_step"] == 4
+    assert abs(c1["optimizer_states"][0]["param_groups"][0]["lr"] - 1e-4 * 0.95 ** 2) < 1e-12
+    assert all(torch.isfinite(v).all() for v in c1["state_dict"].values() if v.is_floating_point())
+    mod2 = train.run_training_job(argv[:-4] + ["--max_epochs", "3", "--reload_only_weights", "0"])
+    assert sorted(os.listdir(ck))[-1] == "epoch=02.ckpt"
+    assert int(mod2.model.state_dict()["bn1.num_batches_tracked"]) == 6      # 3 epochs x 2 steps, buffers resumed
