@@ -538,6 +538,195 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(
   }
 }
 
+// =====================================================================================
+// v3: 3-D halo resident in LDS.  For stride-1 3x3x3 convolutions (and their data gradient)
+// a workgroup of 8 waves owns an 8x8x8 block of the output lattice; per 32-channel chunk it
+// DMAs the 10x10x10 input halo (1000 rows x 128 B) into LDS ONCE and runs all 27 taps out
+// of it (the A fragment of tap (a,b,c) is the same image read at row offset (a,b,c)); only
+// the small weight tile (BN rows) is streamed per tap, double-buffered, one piece per wave.
+// Vector-memory instructions per MFMA: 0.156 (v1/v2) -> ~0.025, which is what bounds the
+// fp32-MFMA loop on gfx950 (tools/mfma_ablate.hip).  LDS image: raw 128-B rows, 16-B slot
+// XOR-swizzled with ((x_halo >> 1) + 4*(y_halo & 1)) & 7 -- conflict-free for the
+// ds_read_b128 lane groups at every tap offset (checked exhaustively); the swizzle is
+// applied on the DMA source address and on the read address, the DMA destination is linear.
+template <int BN, int MODE>
+__global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(
+    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ out, float* __restrict__ stats, const float* __restrict__ add,
+    const float* __restrict__ gate, const IGemmGeom g) {
+  static_assert(MODE == 0 || MODE == 1, "v3: stride-1 forward / data gradient");
+  static_assert(BN == 32 || BN == 64, "v3: N tile 32 or 64");
+  constexpr int NJ = BN / 32;
+  constexpr int T3 = 8;                         // lattice tile edge
+  constexpr int HP = 10;                        // halo pitch (T3 + 2)
+  constexpr int HROWS = HP * HP * HP;           // 1000
+  constexpr int NPIECE = HROWS / 8;             // 125 DMA pieces of 8 rows
+  constexpr int HALO = HROWS * 32;              // floats
+  constexpr int BST = BN * 32;                  // floats per weight stage
+  __shared__ __attribute__((aligned(1024))) float lds[HALO + 2 * BST];
+  float* halo = lds;
+  float* bst = lds + HALO;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 == tile z of this wave's rows
+
+  int L = xcd_remap(blockIdx.x, g.nblk);
+  const int n_tile = L % g.n_tiles;
+  int mt = L / g.n_tiles;
+  const int b = mt / g.tiles_per_b;
+  int r = mt - b * g.tiles_per_b;
+  const int txi = r % g.nx; r /= g.nx;
+  const int tyi = r % g.ny; r /= g.ny;
+  const int tzi = r % g.nz; r /= g.nz;
+  const int rx = r % g.lat; r /= g.lat;
+  const int ry = r % g.lat;
+  const int rz = r / g.lat;
+  const int n0 = n_tile * BN;
+
+  // ---- halo DMA pieces of this lane: p = wave + 8q -----------------------------------------
+  const int sub = lane >> 3, pslot = lane & 7;
+  int hoff[16];  // element offset of (row, logical slot) at channel chunk 0, or -1 (zero row)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int row = 8 * (wave + 8 * q) + sub;
+    const int zh = row / (HP * HP), yh = (row / HP) % HP, xh = row % HP;
+    const int zi = (tzi * T3 + zh - 1) * g.lat + rz;
+    const int yi = (tyi * T3 + yh - 1) * g.lat + ry;
+    const int xi = (txi * T3 + xh - 1) * g.lat + rx;
+    const bool v = (row < HROWS) & (zh >= 0) & (tzi * T3 + zh >= 1) & (tyi * T3 + yh >= 1) & (txi * T3 + xh >= 1) &
+                   (zi < g.Di) & (yi < g.Hi) & (xi < g.Wi);
+    const int sl = pslot ^ (((xh >> 1) + 4 * (yh & 1)) & 7);
+    hoff[q] = v ? (((b * g.Di + zi) * g.Hi + yi) * g.Wi + xi) * g.Ci + sl * 4 : -1;
+  }
+  const float* zline = g_zero_line + pslot * 4;
+  // weight piece of this wave (waves >= BN/8 have none)
+  const int nrow = wave * 8 + sub;
+  const int boff = (n0 + (nrow < BN ? nrow : 0)) * g.Ci + (pslot ^ ((nrow >> 1) & 7)) * 4;
+
+  auto issue_halo = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      if (wave + 8 * q < NPIECE) {  // wave-uniform
+        const float* src = hoff[q] >= 0 ? in + (long)(hoff[q] + c * BK) : zline;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(halo + (wave + 8 * q) * 256), 16, 0, 0);
+      }
+    }
+  };
+  auto issue_b = [&](int c, int tap, int stage) __attribute__((always_inline)) {
+    if (wave < BN / 8) {
+      const float* src = wp + (long)tap * g.No * g.Ci + c * BK + boff;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(bst + stage * BST + wave * 256), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  const int tyl0 = li >> 3, txl = li & 7;       // mi adds 4 to tyl
+  const int rsw = (li >> 1) & 7;                // weight rows: swizzle of row (nj*32 + li)
+  const int nchunk = g.Ci / BK;
+
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();                            // every wave is done with the previous chunk's halo
+    issue_halo(c);
+    issue_b(c, 0, 0);
+    for (int t = 0; t < 27; ++t) {
+      __syncthreads();                          // weight tile t (and, at t = 0, the halo) has landed
+      if (t + 1 < 27) issue_b(c, t + 1, (t + 1) & 1);
+      const int tz = t / 9, ty = (t / 3) % 3, tx = t % 3;
+      const int oz = (MODE == 0) ? tz : 2 - tz, oy = (MODE == 0) ? ty : 2 - ty, ox = (MODE == 0) ? tx : 2 - tx;
+      const int xh = txl + ox;
+      const int yh0 = tyl0 + oy, yh1 = yh0 + 4;
+      const int ra0 = (((wave + oz) * HP + yh0) * HP + xh) * 32;
+      const int ra1 = ra0 + 4 * HP * 32;
+      const int g0 = ((xh >> 1) + 4 * (yh0 & 1)) & 7;   // yh1 = yh0 + 4: same parity, same swizzle
+      const float* sb = bst + (t & 1) * BST + li * 32;
+#pragma unroll
+      for (int gk = 0; gk < BK / 8; ++gk) {
+        const int sa = ((2 * gk + lh) ^ g0) * 4;
+        const int sw = ((2 * gk + lh) ^ rsw) * 4;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(halo + ra0 + sa);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(halo + ra1 + sa);
+        f32x4 bf[NJ];
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) bf[nj] = *reinterpret_cast<const f32x4*>(sb + nj * 32 * 32 + sw);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int nj = 0; nj < NJ; ++nj) {
+            acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bf[nj][e], acc[0][nj], 0, 0, 0);
+            acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bf[nj][e], acc[1][nj], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: rows of this wave are (z = wave, y = 4*mi + .., x) of the 8x8x8 tile -------
+  float s1[NJ], s2[NJ], bv[NJ];
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj) {
+    s1[nj] = 0.f;
+    s2[nj] = 0.f;
+    bv[nj] = bias ? bias[n0 + nj * 32 + li] : 0.f;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;   // within the wave's 64 rows
+      const int zo = ((tzi * T3 + wave) * g.lat + rz);
+      const int yo = ((tyi * T3 + (row >> 3)) * g.lat + ry);
+      const int xo = ((txi * T3 + (row & 7)) * g.lat + rx);
+      const bool rv = (zo < g.Do) & (yo < g.Ho) & (xo < g.Wo);
+      const long o = ((((long)b * g.Do + zo) * g.Ho + yo) * g.Wo + xo) * g.No + n0 + li;
+      if (rv) {
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+          float v = acc[mi][nj][e] + bv[nj];
+          if (add) {
+            const float av = add[o + nj * 32];
+            v += gate ? (gate[o + nj * 32] > 0.f ? av : 0.f) : av;
+          }
+          out[o + nj * 32] = v;
+          s1[nj] += v;
+          s2[nj] += v * v;
+        }
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    float* red = lds;  // [8 waves][2][BN]
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+      const float t1 = s1[nj] + __shfl_xor(s1[nj], 32, 64);
+      const float t2 = s2[nj] + __shfl_xor(s2[nj], 32, 64);
+      if (lh == 0) {
+        red[(wave * 2 + 0) * BN + nj * 32 + li] = t1;
+        red[(wave * 2 + 1) * BN + nj * 32 + li] = t2;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, c = tid - which * BN;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += red[(w * 2 + which) * BN + c];
+      stats[((long)mt * 2 + which) * g.No + n0 + c] = v;
+    }
+  }
+}
+
 int pick_bn(int N) {
   if (N % 128 == 0) return 128;
   if (N % 64 == 0) return 64;
@@ -547,6 +736,24 @@ int pick_bn(int N) {
 
 // Narrow the N tile while the launch would not fill the chip (256 CUs x 2-3 workgroups):
 // the 16x32x32 stages have only 128 M tiles at batch 2.
+int igemm_version() {   // DRAM_IGEMM_V: 0 auto, 1 register-staged, 2 LDS-DMA tiles, 3 LDS-resident halo
+  static int ver = -1;
+  if (ver < 0) {
+    const char* v = getenv("DRAM_IGEMM_V");
+    ver = v ? atoi(v) : 0;
+  }
+  return ver;
+}
+
+// v3 applies to stride-1 3x3x3 "same" convolutions whose N tile is <= 64 (decoder, layer1).
+bool use_v3(const DramConvDesc* d, int N, bool bwd_data) {
+  const int ver = igemm_version();
+  if (ver != 0 && ver != 3) return false;
+  if (d->k != 3 || d->stride != 1 || d->pad != d->dil) return false;
+  (void)bwd_data;
+  return (N % 64 == 0 && N % 128 != 0) || N == 32 || N == 64;
+}
+
 int pick_bn_for(const IGemmGeom& g0) {
   int BN = pick_bn(g0.No);
   if (!BN) return 0;
@@ -560,9 +767,9 @@ int pick_bn_for(const IGemmGeom& g0) {
   return BN;
 }
 
-void fill_tiles(IGemmGeom& g, int BN) {
+void fill_tiles(IGemmGeom& g, int BN, int tz_edge = TZ) {
   const int sz = (g.Do + g.lat - 1) / g.lat, sy = (g.Ho + g.lat - 1) / g.lat, sx = (g.Wo + g.lat - 1) / g.lat;
-  g.nz = (sz + TZ - 1) / TZ;
+  g.nz = (sz + tz_edge - 1) / tz_edge;
   g.ny = (sy + TY - 1) / TY;
   g.nx = (sx + TX - 1) / TX;
   g.tiles_per_b = g.lat * g.lat * g.lat * g.nz * g.ny * g.nx;
@@ -606,14 +813,13 @@ int launch(int BN, const float* in, const float* wp, const float* bias, float* o
   fill_tiles(g, BN);
   dim3 grid(g.nblk), block(256);
   const int pad = lds_pad_for_balance(BN, g.nblk);
-  static int lv = -1, ver = -1;
+  static int lv = -1;
   if (lv < 0) {
     const char* e = getenv("DRAM_IGEMM_LV");
     lv = e ? atoi(e) : 0;
-    const char* v = getenv("DRAM_IGEMM_V");
-    ver = v ? atoi(v) : 0;   // 0 = auto: LDS-DMA kernel for BN <= 64, register-staged for BN = 128
   }
-  if ((ver == 2 || (ver == 0 && BN <= 64)) && MODE != 2) {
+  const int ver = igemm_version();   // 0 = auto: LDS-DMA kernel for BN <= 64, register-staged for BN = 128
+  if ((ver == 2 || ((ver == 0 || ver == 3) && BN <= 64)) && MODE != 2) {
     constexpr int M2 = MODE == 2 ? 0 : MODE;
     switch (BN) {
       case 128:
@@ -651,6 +857,20 @@ int launch(int BN, const float* in, const float* wp, const float* bias, float* o
   return DRAM_OK;
 }
 
+template <int MODE>
+int launch3(const float* in, const float* wp, const float* bias, float* out, float* stats, const float* add,
+            const float* gate, IGemmGeom& g, hipStream_t s) {
+  const int BN = g.No % 64 == 0 ? 64 : 32;
+  fill_tiles(g, BN, 8);
+  dim3 grid(g.nblk), block(512);
+  if (BN == 64)
+    hipLaunchKernelGGL((conv_igemm3_kernel<64, MODE>), grid, block, 0, s, in, wp, bias, out, stats, add, gate, g);
+  else
+    hipLaunchKernelGGL((conv_igemm3_kernel<32, MODE>), grid, block, 0, s, in, wp, bias, out, stats, add, gate, g);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
 }  // namespace
 
 extern "C" int dram_conv_num_mtiles(const DramConvDesc* d) {
@@ -660,7 +880,12 @@ extern "C" int dram_conv_num_mtiles(const DramConvDesc* d) {
   g.lat = d->dil;
   const int BN = pick_bn(d->Cout);
   if (!BN) return DRAM_ERR_UNSUPPORTED;
-  fill_tiles(g, BN);  // the M-tile count does not depend on the N tile
+  // the M-tile count does not depend on the N tile, but it does on the kernel: v3 owns 8x8x8 tiles
+  if (use_v3(d, d->Cout, false)) {
+    fill_tiles(g, d->Cout % 64 == 0 ? 64 : 32, 8);
+    return g.B * g.tiles_per_b;
+  }
+  fill_tiles(g, BN);
   return g.B * g.tiles_per_b;
 }
 
@@ -675,6 +900,7 @@ extern "C" int dram_conv3d_fwd(const float* x, const float* wf, const float* bia
   g.lat = d->dil;
   g.mul = d->stride; g.off = -d->pad; g.step = d->dil;
   g.stride = d->stride; g.pad = d->pad; g.dil = d->dil;
+  if (use_v3(d, d->Cout, false)) return launch3<0>(x, wf, bias, y, stats_partial, nullptr, nullptr, g, (hipStream_t)stream);
   const int BN = pick_bn_for(g);
   if (!BN) return DRAM_ERR_UNSUPPORTED;
   return launch<0>(BN, x, wf, bias, y, stats_partial, nullptr, nullptr, g, (hipStream_t)stream);
@@ -695,6 +921,7 @@ extern "C" int dram_conv3d_bwd_data(const float* dy, const float* wb, float* dx,
   if (d->stride == 1) {
     g.lat = d->dil;
     g.mul = 1; g.off = d->pad; g.step = -d->dil;
+    if (use_v3(d, d->Cin, true)) return launch3<1>(dy, wb, nullptr, dx, nullptr, add, gate, g, (hipStream_t)stream);
     return launch<1>(pick_bn_for(g), dy, wb, nullptr, dx, nullptr, add, gate, g, (hipStream_t)stream);
   }
   g.lat = d->stride;
