@@ -37,6 +37,18 @@ CONFIGS = {
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters
 
 
+def measured_traffic():
+    """HBM bytes per launch of the dominant family from rocprofv3 PMC passes (FETCH_SIZE x2
+    gfx950 correction + WRITE_SIZE), recorded offline for this exact command (config 1) in
+    profiles/r01_pmc_hbm_traffic.json -- PMC counters cannot be read from inside bench.py."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["conv_igemm"]["total"])
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def synth_batch(B, dims, rank, device):
     """image ~ N(0,1) seed 1234+rank; centred-ellipsoid lung mask with
     semi-axes (0.4D, 0.35H, 0.4W); em = (image < -1) & lung; labels randint seed 4321+rank."""
@@ -209,9 +221,11 @@ def main():
                        "train_gflop_per_volume": gflop_per_vol},
             "loss": float(loss),
             "roofline": {
-                "kernel": fam + " (fwd + dgrad, fp32 MFMA 32x32x2)",
+                "kernel": "conv_igemm*_kernel family (conv fwd + dgrad, fp32 MFMA 32x32x2)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": measured_traffic() if args.config == 1 else None,
+                "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.json)",
                 "launches_per_step": s["launches"] / max(args.steps, 1),
                 "avg_launch_ms": s["ms"] / max(s["launches"], 1),
                 "step_time_share": (s["ms"] / 1e3) / dt if dt > 0 else 0.0,
