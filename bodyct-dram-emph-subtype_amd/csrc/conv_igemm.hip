@@ -21,6 +21,7 @@
 // multiplies A[.][8g+4h+e] x B[8g+4h+e][.] for both halves (k order inside the
 // reduction is free as long as A and B agree).  LDS rows are padded to 36 floats:
 // conflict-free for the ds_read_b128 lane groups.
+#include <stdio.h>
 #include <stdlib.h>
 #include "common.h"
 
@@ -549,18 +550,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(
 // XOR-swizzled with ((x_halo >> 1) + 4*(y_halo & 1)) & 7 -- conflict-free for the
 // ds_read_b128 lane groups at every tap offset (checked exhaustively); the swizzle is
 // applied on the DMA source address and on the read address, the DMA destination is linear.
-template <int BN, int MODE>
+// Template: NJ = 32-column accumulator blocks per wave, TZ3 = tile depth (8: 8x8x8 tile, waves
+// 8(M) x 1(N); 4: 4x8x8 tile -- one dilation-4 residue sub-volume of the 16x32x32 stages -- waves
+// 4(M) x 2(N)), so a workgroup covers 32*NJ*WN output channels.
+template <int NJ, int MODE, int TZ3>
 __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, float* __restrict__ stats, const float* __restrict__ add,
     const float* __restrict__ gate, const IGemmGeom g) {
   static_assert(MODE == 0 || MODE == 1, "v3: stride-1 forward / data gradient");
-  static_assert(BN == 32 || BN == 64, "v3: N tile 32 or 64");
-  constexpr int NJ = BN / 32;
-  constexpr int T3 = 8;                         // lattice tile edge
-  constexpr int HP = 10;                        // halo pitch (T3 + 2)
-  constexpr int HROWS = HP * HP * HP;           // 1000
-  constexpr int NPIECE = HROWS / 8;             // 125 DMA pieces of 8 rows
+  static_assert(TZ3 == 8 || TZ3 == 4, "tile depth");
+  constexpr int WN = (TZ3 == 8) ? 1 : 2;        // waves along N
+  constexpr int WM = 8 / WN;                    // waves along M (= tile depth)
+  constexpr int BNW = NJ * 32;                  // columns per wave
+  constexpr int BN = BNW * WN;                  // columns per workgroup
+  constexpr int HP = 10;                        // halo pitch in y and x (8 + 2)
+  constexpr int HROWS = (TZ3 + 2) * HP * HP;    // 1000 / 600
+  constexpr int NPIECE = HROWS / 8;             // DMA pieces of 8 rows
+  constexpr int HQ = (NPIECE + 7) / 8;          // halo pieces per wave
+  constexpr int PB = (BN / 8 + 7) / 8;          // weight pieces per wave and tap
   constexpr int HALO = HROWS * 32;              // floats
   constexpr int BST = BN * 32;                  // floats per weight stage
   __shared__ __attribute__((aligned(1024))) float lds[HALO + 2 * BST];
@@ -569,7 +577,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 == tile z of this wave's rows
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM;                     // tile z-plane of this wave's 64 rows
+  const int wn = wave / WM;                     // N half
 
   int L = xcd_remap(blockIdx.x, g.nblk);
   const int n_tile = L % g.n_tiles;
@@ -586,27 +596,31 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(
 
   // ---- halo DMA pieces of this lane: p = wave + 8q -----------------------------------------
   const int sub = lane >> 3, pslot = lane & 7;
-  int hoff[16];  // element offset of (row, logical slot) at channel chunk 0, or -1 (zero row)
+  int hoff[HQ];  // element offset of (row, logical slot) at channel chunk 0, or -1 (zero row)
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
+  for (int q = 0; q < HQ; ++q) {
     const int row = 8 * (wave + 8 * q) + sub;
     const int zh = row / (HP * HP), yh = (row / HP) % HP, xh = row % HP;
-    const int zi = (tzi * T3 + zh - 1) * g.lat + rz;
-    const int yi = (tyi * T3 + yh - 1) * g.lat + ry;
-    const int xi = (txi * T3 + xh - 1) * g.lat + rx;
-    const bool v = (row < HROWS) & (zh >= 0) & (tzi * T3 + zh >= 1) & (tyi * T3 + yh >= 1) & (txi * T3 + xh >= 1) &
+    const int zi = (tzi * TZ3 + zh - 1) * g.lat + rz;
+    const int yi = (tyi * 8 + yh - 1) * g.lat + ry;
+    const int xi = (txi * 8 + xh - 1) * g.lat + rx;
+    const bool v = (row < HROWS) & (tzi * TZ3 + zh >= 1) & (tyi * 8 + yh >= 1) & (txi * 8 + xh >= 1) &
                    (zi < g.Di) & (yi < g.Hi) & (xi < g.Wi);
     const int sl = pslot ^ (((xh >> 1) + 4 * (yh & 1)) & 7);
     hoff[q] = v ? (((b * g.Di + zi) * g.Hi + yi) * g.Wi + xi) * g.Ci + sl * 4 : -1;
   }
   const float* zline = g_zero_line + pslot * 4;
-  // weight piece of this wave (waves >= BN/8 have none)
-  const int nrow = wave * 8 + sub;
-  const int boff = (n0 + (nrow < BN ? nrow : 0)) * g.Ci + (pslot ^ ((nrow >> 1) & 7)) * 4;
+  // weight pieces of this wave: piece pb = wave + 8j covers rows 8*pb .. 8*pb+7 of the BN-row tile
+  int boff[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int nrow = (wave + 8 * j) * 8 + sub;
+    boff[j] = (n0 + (nrow < BN ? nrow : 0)) * g.Ci + (pslot ^ ((nrow >> 1) & 7)) * 4;
+  }
 
   auto issue_halo = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < HQ; ++q) {
       if (wave + 8 * q < NPIECE) {  // wave-uniform
         const float* src = hoff[q] >= 0 ? in + (long)(hoff[q] + c * BK) : zline;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -615,10 +629,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(
     }
   };
   auto issue_b = [&](int c, int tap, int stage) __attribute__((always_inline)) {
-    if (wave < BN / 8) {
-      const float* src = wp + (long)tap * g.No * g.Ci + c * BK + boff;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(bst + stage * BST + wave * 256), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      if ((wave + 8 * j) * 8 < BN) {  // wave-uniform
+        const float* src = wp + (long)tap * g.No * g.Ci + c * BK + boff[j];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(bst + stage * BST + (wave + 8 * j) * 256), 16, 0, 0);
+      }
     }
   };
 
@@ -632,7 +649,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(
 
   const int li = lane & 31, lh = lane >> 5;
   const int tyl0 = li >> 3, txl = li & 7;       // mi adds 4 to tyl
-  const int rsw = (li >> 1) & 7;                // weight rows: swizzle of row (nj*32 + li)
+  const int rsw = (li >> 1) & 7;                // weight rows: swizzle of row (.. + li), offsets are multiples of 32
   const int nchunk = g.Ci / BK;
 
   for (int c = 0; c < nchunk; ++c) {
@@ -645,11 +662,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(
       const int tz = t / 9, ty = (t / 3) % 3, tx = t % 3;
       const int oz = (MODE == 0) ? tz : 2 - tz, oy = (MODE == 0) ? ty : 2 - ty, ox = (MODE == 0) ? tx : 2 - tx;
       const int xh = txl + ox;
-      const int yh0 = tyl0 + oy, yh1 = yh0 + 4;
-      const int ra0 = (((wave + oz) * HP + yh0) * HP + xh) * 32;
+      const int yh0 = tyl0 + oy;
+      const int ra0 = (((wm + oz) * HP + yh0) * HP + xh) * 32;
       const int ra1 = ra0 + 4 * HP * 32;
-      const int g0 = ((xh >> 1) + 4 * (yh0 & 1)) & 7;   // yh1 = yh0 + 4: same parity, same swizzle
-      const float* sb = bst + (t & 1) * BST + li * 32;
+      const int g0 = ((xh >> 1) + 4 * (yh0 & 1)) & 7;   // rows yh0 and yh0+4: same parity, same swizzle
+      const float* sb = bst + (t & 1) * BST + (wn * BNW + li) * 32;
 #pragma unroll
       for (int gk = 0; gk < BK / 8; ++gk) {
         const int sa = ((2 * gk + lh) ^ g0) * 4;
@@ -671,24 +688,25 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(
     }
   }
 
-  // ---- epilogue: rows of this wave are (z = wave, y = 4*mi + .., x) of the 8x8x8 tile -------
+  // ---- epilogue: this wave's rows are (z = wm, y = 4*mi + .., x), columns n0 + wn*BNW .. ------
+  const int nb = n0 + wn * BNW;
   float s1[NJ], s2[NJ], bv[NJ];
 #pragma unroll
   for (int nj = 0; nj < NJ; ++nj) {
     s1[nj] = 0.f;
     s2[nj] = 0.f;
-    bv[nj] = bias ? bias[n0 + nj * 32 + li] : 0.f;
+    bv[nj] = bias ? bias[nb + nj * 32 + li] : 0.f;
   }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;   // within the wave's 64 rows
-      const int zo = ((tzi * T3 + wave) * g.lat + rz);
-      const int yo = ((tyi * T3 + (row >> 3)) * g.lat + ry);
-      const int xo = ((txi * T3 + (row & 7)) * g.lat + rx);
+      const int zo = ((tzi * TZ3 + wm) * g.lat + rz);
+      const int yo = ((tyi * 8 + (row >> 3)) * g.lat + ry);
+      const int xo = ((txi * 8 + (row & 7)) * g.lat + rx);
       const bool rv = (zo < g.Do) & (yo < g.Ho) & (xo < g.Wo);
-      const long o = ((((long)b * g.Do + zo) * g.Ho + yo) * g.Wo + xo) * g.No + n0 + li;
+      const long o = ((((long)b * g.Do + zo) * g.Ho + yo) * g.Wo + xo) * g.No + nb + li;
       if (rv) {
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj) {
@@ -706,22 +724,23 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(
   }
   if (stats) {
     __syncthreads();
-    float* red = lds;  // [8 waves][2][BN]
+    float* red = lds;  // [8 waves][2][BNW]
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
       const float t1 = s1[nj] + __shfl_xor(s1[nj], 32, 64);
       const float t2 = s2[nj] + __shfl_xor(s2[nj], 32, 64);
       if (lh == 0) {
-        red[(wave * 2 + 0) * BN + nj * 32 + li] = t1;
-        red[(wave * 2 + 1) * BN + nj * 32 + li] = t2;
+        red[(wave * 2 + 0) * BNW + nj * 32 + li] = t1;
+        red[(wave * 2 + 1) * BNW + nj * 32 + li] = t2;
       }
     }
     __syncthreads();
     if (tid < 2 * BN) {
-      const int which = tid / BN, c = tid - which * BN;
+      const int which = tid / BN, c = tid - which * BN;   // c: column within the workgroup's BN
+      const int cwn = c / BNW, cc = c - cwn * BNW;
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) v += red[(w * 2 + which) * BN + c];
+      for (int w = 0; w < WM; ++w) v += red[((cwn * WM + w) * 2 + which) * BNW + cc];
       stats[((long)mt * 2 + which) * g.No + n0 + c] = v;
     }
   }
@@ -745,13 +764,36 @@ int igemm_version() {   // DRAM_IGEMM_V: 0 auto, 1 register-staged, 2 LDS-DMA ti
   return ver;
 }
 
-// v3 applies to stride-1 3x3x3 "same" convolutions whose N tile is <= 64 (decoder, layer1).
-bool use_v3(const DramConvDesc* d, int N, bool bwd_data) {
+// v3 plan for a stride-1 3x3x3 "same" convolution writing N channels: tile depth and N per
+// workgroup.  Returns false when v3 does not apply.
+struct V3Plan { int tz3, bn; };
+bool plan_v3(const DramConvDesc* d, int N, int Do, int Ho, int Wo, V3Plan& p) {
   const int ver = igemm_version();
   if (ver != 0 && ver != 3) return false;
   if (d->k != 3 || d->stride != 1 || d->pad != d->dil) return false;
-  (void)bwd_data;
-  return (N % 64 == 0 && N % 128 != 0) || N == 32 || N == 64;
+  if (const char* f = getenv("DRAM_IGEMM_V3_FORCE")) {   // tests / tuning: "tz3,bn", e.g. "4,256"
+    int tz = 0, bn = 0;
+    if (sscanf(f, "%d,%d", &tz, &bn) == 2 && (tz == 4 || tz == 8) && N % bn == 0 &&
+        ((tz == 8 && (bn == 32 || bn == 64)) || (tz == 4 && (bn == 128 || bn == 256)))) {
+      p = {tz, bn};
+      return true;
+    }
+    return false;
+  }
+  const int lat = d->dil;
+  const int sz = (Do + lat - 1) / lat, sy = (Ho + lat - 1) / lat, sx = (Wo + lat - 1) / lat;
+  if (N == 32) { p = {8, 32}; return true; }
+  if (N % 64 != 0) return false;
+  const long sub8 = (long)d->B * lat * lat * lat * ((sz + 7) / 8) * ((sy + 7) / 8) * ((sx + 7) / 8);
+  const long sub4 = (long)d->B * lat * lat * lat * ((sz + 3) / 4) * ((sy + 7) / 8) * ((sx + 7) / 8);
+  // wide layers on small volumes (16x32x32 stages): 4x8x8 tiles, 128 or 256 columns per workgroup
+  if (N % 256 == 0 && sub4 * (N / 256) >= 192 && sub8 * (N / 64) < 4096 && sz % 8 != 0) { p = {4, 256}; return true; }
+  if (N % 128 == 0 && sub8 * (N / 64) < 1024) {
+    if (sub4 * (N / 128) >= 192) { p = {4, 128}; return true; }
+    return false;
+  }
+  if (sub8 * (N / 64) >= 256) { p = {8, 64}; return true; }
+  return false;
 }
 
 int pick_bn_for(const IGemmGeom& g0) {
@@ -858,15 +900,18 @@ int launch(int BN, const float* in, const float* wp, const float* bias, float* o
 }
 
 template <int MODE>
-int launch3(const float* in, const float* wp, const float* bias, float* out, float* stats, const float* add,
-            const float* gate, IGemmGeom& g, hipStream_t s) {
-  const int BN = g.No % 64 == 0 ? 64 : 32;
-  fill_tiles(g, BN, 8);
+int launch3(const V3Plan& p, const float* in, const float* wp, const float* bias, float* out, float* stats,
+            const float* add, const float* gate, IGemmGeom& g, hipStream_t s) {
+  fill_tiles(g, p.bn, p.tz3);
   dim3 grid(g.nblk), block(512);
-  if (BN == 64)
-    hipLaunchKernelGGL((conv_igemm3_kernel<64, MODE>), grid, block, 0, s, in, wp, bias, out, stats, add, gate, g);
-  else
-    hipLaunchKernelGGL((conv_igemm3_kernel<32, MODE>), grid, block, 0, s, in, wp, bias, out, stats, add, gate, g);
+#define IG3(NJ_, TZ_) \
+  hipLaunchKernelGGL((conv_igemm3_kernel<NJ_, MODE, TZ_>), grid, block, 0, s, in, wp, bias, out, stats, add, gate, g)
+  if (p.tz3 == 8 && p.bn == 64) IG3(2, 8);
+  else if (p.tz3 == 8 && p.bn == 32) IG3(1, 8);
+  else if (p.tz3 == 4 && p.bn == 128) IG3(2, 4);
+  else if (p.tz3 == 4 && p.bn == 256) IG3(4, 4);
+  else return DRAM_ERR_UNSUPPORTED;
+#undef IG3
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
@@ -880,9 +925,10 @@ extern "C" int dram_conv_num_mtiles(const DramConvDesc* d) {
   g.lat = d->dil;
   const int BN = pick_bn(d->Cout);
   if (!BN) return DRAM_ERR_UNSUPPORTED;
-  // the M-tile count does not depend on the N tile, but it does on the kernel: v3 owns 8x8x8 tiles
-  if (use_v3(d, d->Cout, false)) {
-    fill_tiles(g, d->Cout % 64 == 0 ? 64 : 32, 8);
+  // the M-tile count does not depend on the N tile, but it does on the kernel: v3 owns 8x8x8 / 4x8x8 tiles
+  V3Plan p3;
+  if (plan_v3(d, d->Cout, d->Do, d->Ho, d->Wo, p3)) {
+    fill_tiles(g, p3.bn, p3.tz3);
     return g.B * g.tiles_per_b;
   }
   fill_tiles(g, BN);
@@ -900,7 +946,9 @@ extern "C" int dram_conv3d_fwd(const float* x, const float* wf, const float* bia
   g.lat = d->dil;
   g.mul = d->stride; g.off = -d->pad; g.step = d->dil;
   g.stride = d->stride; g.pad = d->pad; g.dil = d->dil;
-  if (use_v3(d, d->Cout, false)) return launch3<0>(x, wf, bias, y, stats_partial, nullptr, nullptr, g, (hipStream_t)stream);
+  V3Plan p3;
+  if (plan_v3(d, d->Cout, d->Do, d->Ho, d->Wo, p3))
+    return launch3<0>(p3, x, wf, bias, y, stats_partial, nullptr, nullptr, g, (hipStream_t)stream);
   const int BN = pick_bn_for(g);
   if (!BN) return DRAM_ERR_UNSUPPORTED;
   return launch<0>(BN, x, wf, bias, y, stats_partial, nullptr, nullptr, g, (hipStream_t)stream);
@@ -921,7 +969,9 @@ extern "C" int dram_conv3d_bwd_data(const float* dy, const float* wb, float* dx,
   if (d->stride == 1) {
     g.lat = d->dil;
     g.mul = 1; g.off = d->pad; g.step = -d->dil;
-    if (use_v3(d, d->Cin, true)) return launch3<1>(dy, wb, nullptr, dx, nullptr, add, gate, g, (hipStream_t)stream);
+    V3Plan p3;
+    if (plan_v3(d, d->Cin, d->D, d->H, d->W, p3))
+      return launch3<1>(p3, dy, wb, nullptr, dx, nullptr, add, gate, g, (hipStream_t)stream);
     return launch<1>(pick_bn_for(g), dy, wb, nullptr, dx, nullptr, add, gate, g, (hipStream_t)stream);
   }
   g.lat = d->stride;

@@ -96,6 +96,48 @@ def test_conv3d_fwd_bwd(ops, case):
         assert rel_l2(dw.cpu(), gw_ref) < 5e-6
 
 
+V3_CASES = [
+    # forced v3 plan "tz3,bn", then (B, D, H, W, Cin, Cout, dil)
+    ("8,64", (1, 9, 10, 17, 64, 64, 1)),
+    ("8,64", (2, 6, 8, 8, 32, 128, 2)),
+    ("8,32", (1, 8, 8, 9, 64, 32, 1)),
+    ("4,128", (1, 8, 16, 16, 64, 128, 2)),
+    ("4,128", (2, 5, 9, 10, 32, 256, 1)),
+    ("4,256", (1, 4, 8, 8, 64, 256, 1)),
+    ("4,256", (1, 16, 32, 32, 64, 512, 4)),
+]
+
+
+@pytest.mark.parametrize("plan,case", V3_CASES, ids=[f"{p}-{c}" for p, c in V3_CASES])
+def test_conv3d_v3_halo_kernel_variants(ops, monkeypatch, plan, case):
+    """Every template instance of the LDS-resident-halo kernel (8x8x8 and 4x8x8 tiles, 32..256
+    columns per workgroup), forward with fused BN statistics and data gradient with the fused
+    shortcut-gradient epilogue, incl. ragged volumes and dilation lattices."""
+    monkeypatch.setenv("DRAM_IGEMM_V3_FORCE", plan)
+    B, D, H, W, Cin, Cout, dil = case
+    x = rnd(B, Cin, D, H, W, seed=1).requires_grad_(True)
+    w = (rnd(Cout, Cin, 3, 3, 3, seed=2) * 0.1).requires_grad_(True)
+    bias = rnd(Cout, seed=3)
+    y_ref = F.conv3d(x, w, bias, 1, dil, dil)
+    gy = rnd(*y_ref.shape, seed=4)
+    (gx_ref,) = torch.autograd.grad(y_ref, [x], gy)
+    g = ops.ConvGeom(B, D, H, W, Cin, Cout, 3, 1, dil, dil)
+    wf, wb = ops.pack_conv_weight(w.detach().to(DEV))
+    y, stats = ops.conv3d_fwd(to_ndhwc(x.detach()), wf, bias.to(DEV), g, True)
+    assert rel_l2(to_ncdhw(y), y_ref.detach()) < 2e-6
+    s = ops.reduce_partials(stats).cpu()
+    yr = y_ref.detach().double()
+    assert torch.allclose(s[0], yr.sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[1], (yr * yr).sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    if Cin % 64 == 0 or Cin == 32:       # the data gradient writes N = Cin channels
+        bn = int(plan.split(",")[1])
+        if Cin % bn == 0:
+            add = rnd(B, Cin, D, H, W, seed=5)
+            gate = rnd(B, Cin, D, H, W, seed=6)
+            dx = ops.conv3d_bwd_data(to_ndhwc(gy), wb, g, to_ndhwc(add), to_ndhwc(gate))
+            assert rel_l2(to_ncdhw(dx), gx_ref + add * (gate > 0).float()) < 2e-6
+
+
 def test_conv_linearity_at_scale(ops):
     """size-independent property at a BASELINE-sized layer (us2.1: 64->64 @ 64x128x128):
     conv(a*x1 + x2) == a*conv(x1) + conv(x2), and a checksum against a strided CPU probe."""
