@@ -195,6 +195,148 @@ __global__ __launch_bounds__(64 * COW * CIW * KW, (COW * CIW * KW) / 4) void con
   }
 }
 
+// =====================================================================================
+// v2 (stride 1, dilation 1): z-walking weight gradient.  A workgroup of 8 waves owns a
+// (32 co x 32 ci) block and walks a column of 8x8 output voxels through all Do planes.  LDS
+// holds a ring of 4 input planes (10x10 halo rows x 32 ci) and 2 dy planes (64 voxels x 32 co),
+// filled by LDS-DMA one plane ahead: one new input plane + one dy plane per step
+// (~0.024 vector-memory instructions per MFMA, one barrier per step, no VGPR staging).
+// Wave w accumulates taps {w, w+8, w+16, w+24}; operands are ds_read_b32 rows
+// (lanes = consecutive channels: conflict-free, no swizzle needed).
+__device__ __attribute__((aligned(128))) float g_wzero_line[32];
+
+struct W2Geom {
+  int B, D, H, W, Cin, Cout;       // stride 1 / pad 1: output dims == input dims
+  int ny, nx, ncols;               // 8x8 columns per plane, total columns = B*ny*nx
+  int ci_tiles, nslab, cpw;        // 32-wide ci tiles, workgroups per (co,ci) pair, columns per workgroup
+};
+
+__global__ __launch_bounds__(512, 4) void conv_wgrad2_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ dy,
+                                                             float* __restrict__ slab, const W2Geom g) {
+  constexpr int PR = 104;                 // rows per halo plane slot (100 used, 13 DMA pieces of 8)
+  constexpr int HPL = PR * 32;            // floats per halo plane
+  constexpr int DPL = 64 * 32;            // floats per dy plane
+  __shared__ __attribute__((aligned(1024))) float lds[4 * HPL + 2 * DPL];
+  float* halo = lds;
+  float* dyl = lds + 4 * HPL;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int sub = lane >> 3, pslot = lane & 7;
+
+  const int pair = blockIdx.x / g.nslab, sidx = blockIdx.x - pair * g.nslab;
+  const int co0 = (pair / g.ci_tiles) * 32, ci0 = (pair % g.ci_tiles) * 32;
+  const int c_begin = sidx * g.cpw;
+  const int c_end = (c_begin + g.cpw < g.ncols) ? c_begin + g.cpw : g.ncols;
+
+  // this wave's taps
+  int tbase[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = wave + 8 * j;
+    const int ty = (t / 3) % 3, tx = t % 3;
+    tbase[j] = (ty * 10 + tx) * 32 + li + lh * 32;   // in-plane operand offset (+ the lh voxel)
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  const float* zline = g_wzero_line + pslot * 4;
+  const long plane_x = (long)g.H * g.W * g.Cin, plane_dy = (long)g.H * g.W * g.Cout;
+
+  for (int col = c_begin; col < c_end; ++col) {
+    int r = col;
+    const int txi = r % g.nx; r /= g.nx;
+    const int tyi = r % g.ny;
+    const int b = r / g.ny;
+    const int y0 = tyi * 8, x0 = txi * 8;
+    // in-plane source offsets of this lane's DMA rows (-1: outside the volume -> zero line)
+    long hsrc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = 8 * (wave + 8 * q) + sub;       // halo row 0..103
+      const int yh = row / 10, xh = row - yh * 10;
+      const int yi = y0 - 1 + yh, xi = x0 - 1 + xh;
+      const bool v = (row < 100) & (yi >= 0) & (yi < g.H) & (xi >= 0) & (xi < g.W);
+      hsrc[q] = v ? ((long)yi * g.W + xi) * g.Cin + ci0 + pslot * 4 : -1;
+    }
+    long dsrc;
+    {
+      const int vox = 8 * wave + sub;                 // dy row 0..63
+      const int yo = y0 + (vox >> 3), xo = x0 + (vox & 7);
+      dsrc = (yo < g.H && xo < g.W) ? ((long)yo * g.W + xo) * g.Cout + co0 + pslot * 4 : -1;
+    }
+    const float* xb = x + (long)b * g.D * plane_x;
+    const float* db = dy + (long)b * g.D * plane_dy;
+
+    auto issue_halo = [&](int zi) __attribute__((always_inline)) {   // input plane zi -> ring slot (zi+1)&3
+      float* dst = halo + ((zi + 1) & 3) * HPL;
+      const bool zin = (zi >= 0) & (zi < g.D);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (wave + 8 * q < 13) {
+          const float* src = (zin && hsrc[q] >= 0) ? xb + (long)zi * plane_x + hsrc[q] : zline;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(dst + (wave + 8 * q) * 256), 16, 0, 0);
+        }
+      }
+    };
+    auto issue_dy = [&](int zo) __attribute__((always_inline)) {     // dy plane zo -> slot zo&1
+      const float* src = (zo < g.D && dsrc >= 0) ? db + (long)zo * plane_dy + dsrc : zline;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dyl + (zo & 1) * DPL + wave * 256), 16, 0, 0);
+    };
+
+    __syncthreads();                    // previous column fully consumed
+    issue_halo(-1); issue_halo(0); issue_halo(1);
+    issue_dy(0);
+    for (int zo = 0; zo < g.D; ++zo) {
+      __syncthreads();                  // planes for step zo have landed; step zo-1 is finished everywhere
+      if (zo + 2 <= g.D) issue_halo(zo + 2);   // slot (zo+3)&3 held plane zo-2 (plane D = zero padding)
+      if (zo + 1 < g.D) issue_dy(zo + 1);      // slot (zo+1)&1 held dy plane zo-1
+      const float* dp = dyl + (zo & 1) * DPL + li + lh * 32;
+      const float* hp[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = wave + 8 * j;
+        hp[j] = halo + ((zo + t / 9) & 3) * HPL + tbase[j];
+      }
+#pragma unroll 8
+      for (int kk = 0; kk < 32; ++kk) {
+        // voxel 2kk+lh of the plane: (y, x) = (kk>>2, 2(kk&3)+lh); the lh part lives in tbase/dp
+        const int voff = ((kk >> 2) * 10 + 2 * (kk & 3)) * 32;
+        const float a = dp[kk * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (wave + 8 * j < 27) {      // wave-uniform
+            const float bv = hp[j][voff];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- write this workgroup's slab slice: slab[sidx][tap][co][ci] ---------------------------
+  const long tap_stride = (long)g.Cout * g.Cin;
+  float* sl = slab + (long)sidx * 27 * tap_stride;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = wave + 8 * j;
+    if (t < 27) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        sl[t * tap_stride + (long)co * g.Cin + ci0 + li] = acc[j][e];
+      }
+    }
+  }
+}
+
 // dW[co][ci][tap] = sum_s slab[s][tap][co][ci]   (one thread per output element: small layers
 // have few (co,ci) pairs but hundreds of slabs, so parallelism must come from every element)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslab,
@@ -279,7 +421,38 @@ bool make_plan(const DramConvDesc* d, Plan& p) {
 
 }  // namespace
 
+// z-walking plan (v2): stride 1, dilation 1, 3x3x3, pad 1, channels multiple of 32
+bool make_plan2(const DramConvDesc* d, W2Geom& g) {
+  if (const char* e = getenv("DRAM_WGRAD_V")) { if (e[0] == '1') return false; }
+  if (!d || d->k != 3 || d->stride != 1 || d->dil != 1 || d->pad != 1) return false;
+  if (d->Cin % 32 != 0 || d->Cout % 32 != 0) return false;
+  g.B = d->B; g.D = d->D; g.H = d->H; g.W = d->W; g.Cin = d->Cin; g.Cout = d->Cout;
+  g.ny = (d->H + 7) / 8; g.nx = (d->W + 7) / 8;
+  g.ncols = d->B * g.ny * g.nx;
+  g.ci_tiles = d->Cin / 32;
+  const int pairs = g.ci_tiles * (d->Cout / 32);
+  // Columns per workgroup (cpw): every slab is a full [27][Cout][Cin] image, workgroups =
+  // pairs * ceil(ncols / cpw) run two per CU (512 slots).  Pick the cpw that maximises
+  // useful work / (rounds * 512 * cpw) under a 256 MB slab cap; ties go to fewer slabs.
+  const double slab1 = 27.0 * d->Cout * d->Cin * 4.0;
+  double best = -1.0;
+  int best_cpw = g.ncols;
+  for (int cpw = g.ncols; cpw >= 1; --cpw) {
+    const int ns = (g.ncols + cpw - 1) / cpw;
+    if (slab1 * ns > 256e6) break;
+    const long wgs = (long)pairs * ns;
+    const long rounds = (wgs + 511) / 512;
+    const double eff = (double)g.ncols * pairs / ((double)rounds * 512.0 * cpw);
+    if (eff > best + 1e-9) { best = eff; best_cpw = cpw; }
+  }
+  g.cpw = best_cpw;
+  g.nslab = (g.ncols + g.cpw - 1) / g.cpw;
+  return true;
+}
+
 extern "C" size_t dram_conv3d_bwd_weight_workspace(const DramConvDesc* d) {
+  W2Geom g2{};
+  if (make_plan2(d, g2)) return (size_t)g2.nslab * 27 * d->Cout * d->Cin * sizeof(float);
   Plan p{};
   if (!make_plan(d, p)) return 0;
   return (size_t)p.nslab * d->k * d->k * d->k * d->Cout * d->Cin * sizeof(float);
@@ -289,6 +462,23 @@ extern "C" int dram_conv3d_bwd_weight(const float* x, const float* dy, float* dw
                                       void* workspace, size_t workspace_bytes, dram_stream_t stream) {
   Plan p{};
   if (!x || !dy || !dw || !d) return DRAM_ERR_BAD_ARG;
+  {
+    W2Geom g2{};
+    if (make_plan2(d, g2)) {
+      const size_t need2 = (size_t)g2.nslab * 27 * d->Cout * d->Cin * sizeof(float);
+      if (!workspace || workspace_bytes < need2) return DRAM_ERR_WORKSPACE;
+      hipStream_t s2 = (hipStream_t)stream;
+      const int pairs = g2.ci_tiles * (d->Cout / 32);
+      hipLaunchKernelGGL(conv_wgrad2_kernel, dim3(pairs * g2.nslab), dim3(512), 0, s2, x, dy, (float*)workspace, g2);
+      DRAM_LAUNCH_CHECK();
+      const long per2 = (long)27 * d->Cout * d->Cin;
+      const int rg2 = (int)((per2 + 255) / 256 > 8192 ? 8192 : (per2 + 255) / 256);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg2), dim3(256), 0, s2, (const float*)workspace, dw, g2.nslab, 27,
+                         d->Cout, d->Cin);
+      DRAM_LAUNCH_CHECK();
+      return DRAM_OK;
+    }
+  }
   if (!make_plan(d, p)) return DRAM_ERR_UNSUPPORTED;
   const size_t need = (size_t)p.nslab * d->k * d->k * d->k * d->Cout * d->Cin * sizeof(float);
   if (!workspace || workspace_bytes < need) return DRAM_ERR_WORKSPACE;
