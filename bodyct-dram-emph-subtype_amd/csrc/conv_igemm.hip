@@ -746,6 +746,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm3_kernel(
   }
 }
 
+// Tile the dilation lattice only when a sub-lattice fills a 4x8x8 tile; on small volumes
+// (e.g. dilation 4 on 8x16x16) lattice tiles would be mostly empty, plain tiles are denser.
+int choose_lat(int dil, int Do, int Ho, int Wo) {
+  if (dil <= 1) return 1;
+  const int sz = (Do + dil - 1) / dil, sy = (Ho + dil - 1) / dil, sx = (Wo + dil - 1) / dil;
+  return (sz >= TZ && sy >= TY && sx >= TX) ? dil : 1;
+}
+
 int pick_bn(int N) {
   if (N % 128 == 0) return 128;
   if (N % 64 == 0) return 64;
@@ -931,6 +939,7 @@ extern "C" int dram_conv_num_mtiles(const DramConvDesc* d) {
     fill_tiles(g, p3.bn, p3.tz3);
     return g.B * g.tiles_per_b;
   }
+  g.lat = choose_lat(d->dil, d->Do, d->Ho, d->Wo);
   fill_tiles(g, BN);
   return g.B * g.tiles_per_b;
 }
@@ -949,6 +958,7 @@ extern "C" int dram_conv3d_fwd(const float* x, const float* wf, const float* bia
   V3Plan p3;
   if (plan_v3(d, d->Cout, d->Do, d->Ho, d->Wo, p3))
     return launch3<0>(p3, x, wf, bias, y, stats_partial, nullptr, nullptr, g, (hipStream_t)stream);
+  g.lat = choose_lat(d->dil, d->Do, d->Ho, d->Wo);
   const int BN = pick_bn_for(g);
   if (!BN) return DRAM_ERR_UNSUPPORTED;
   return launch<0>(BN, x, wf, bias, y, stats_partial, nullptr, nullptr, g, (hipStream_t)stream);
@@ -972,6 +982,7 @@ extern "C" int dram_conv3d_bwd_data(const float* dy, const float* wb, float* dx,
     V3Plan p3;
     if (plan_v3(d, d->Cin, d->D, d->H, d->W, p3))
       return launch3<1>(p3, dy, wb, nullptr, dx, nullptr, add, gate, g, (hipStream_t)stream);
+    g.lat = choose_lat(d->dil, d->D, d->H, d->W);
     return launch<1>(pick_bn_for(g), dy, wb, nullptr, dx, nullptr, add, gate, g, (hipStream_t)stream);
   }
   g.lat = d->stride;
