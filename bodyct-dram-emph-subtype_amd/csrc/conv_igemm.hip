@@ -57,14 +57,14 @@ struct IGemmGeom {
 
 // MODE 0: forward (any stride/dilation) and MODE 1: data-gradient with stride 1 share
 // the affine source map; MODE 2: data-gradient with stride > 1 (divisibility test).
-// LV (A-tile prefetch form; A/B measured on one MI355X, fwd 64->64 @64x128x128 / 512->512 d4):
-//   0  `valid ? *p : 0`   -> hipcc emits flat_load from a selected address; FLAT ops also count
-//      on lgkmcnt, so the prefetch completes before the MFMA phase starts: 112 / 128 TFLOP/s
-//   1  unconditional global_load + bit-mask at store time, in flight during the MFMAs: 109 / 117
-//   2  as 1 but issued after the first k-group of MFMAs: 111 / 124
-// Memory returns landing in VGPRs during the fp32 MFMA phase cost more than the exposed latency
-// (which the other 2 workgroups on the CU cover), so 0 is the default; DRAM_IGEMM_LV selects.
-template <int BN, int MODE, int LV>
+// A-tile prefetch form (measured on one MI355X, fwd 64->64 @64x128x128 / 512->512 d4):
+// `valid ? *p : 0` makes hipcc emit a flat_load from a selected address; FLAT ops also count on
+// lgkmcnt, so the prefetch completes before the MFMA phase starts: 112 / 128 TFLOP/s.  The two
+// "cleaner" forms that keep the loads in flight during the MFMAs (unconditional global_load +
+// bit-mask at store time: 109 / 117; the same issued after the first k-group: 111 / 124) were
+// slower: memory returns landing in VGPRs during the fp32 MFMA phase cost more than the
+// exposed latency, which the other 2 workgroups on the CU cover.
+template <int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, float* __restrict__ stats, const float* __restrict__ add,
@@ -163,14 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
 // flat_load against a scratch-resident zero, and FLAT ops also count on lgkmcnt, so the
 // ds_read wait in front of the MFMAs drained the prefetch.
 #define IG_LOAD_A01(P)                                                                              \
-  if (LV == 0) {                                                                                    \
-    ra##P = ((rmask[P] & vb) == vb) ? *reinterpret_cast<const float4*>(in + (long)(rbase[P] + toff)) : zero4; \
-  } else {                                                                                          \
-    const bool v = (rmask[P] & vb) == vb;                                                           \
-    const float4 t_ = *reinterpret_cast<const float4*>(in + (v ? (long)(rbase[P] + toff) : (long)koff)); \
-    ra##P = t_;                                                                                     \
-    amask |= v ? (1u << P) : 0u;                                                                    \
-  }
+  ra##P = ((rmask[P] & vb) == vb) ? *reinterpret_cast<const float4*>(in + (long)(rbase[P] + toff)) : zero4;
 #define IG_LOAD_A2(P)                                                                               \
   {                                                                                                 \
     const int nz_ = rmask[P] - tz * g.dil, ny_ = rcy[P] - ty * g.dil, nx_ = rcx[P] - tx * g.dil;    \
@@ -180,13 +173,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
                    (sx < g.Wi);                                                                      \
     const long o = ((((long)b * g.Di + sz) * g.Hi + sy) * g.Wi + sx) * g.Ci + koff;                  \
     const float4 t_ = *reinterpret_cast<const float4*>(in + (v ? o : (long)koff));                   \
-    ra##P = (LV == 0) ? mask4(t_, v) : t_;   /* LV 0 stores unmasked: mask here */                   \
-    amask |= v ? (1u << P) : 0u;                                                                     \
+    ra##P = mask4(t_, v);                                                                            \
   }
 
-  unsigned amask = 0;  // validity of the 8 prefetched A rows (applied when they are stored)
   auto load_tile = [&](int it) __attribute__((always_inline)) {
-    amask = 0;
     const int c = it / ntv;
     const int tap = (MODE == 2) ? taplist[it - c * ntv] : it - c * ntv;
     const int tz = tap / (g.kh * g.kw);
@@ -214,14 +204,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
 
   auto store_tile = [&]() __attribute__((always_inline)) {
     float* ap = &As[row0 * LDK + col4 * 4];
-    *reinterpret_cast<float4*>(ap + 0 * 32 * LDK) = (LV == 0) ? ra0 : mask4(ra0, amask & 1u);
-    *reinterpret_cast<float4*>(ap + 1 * 32 * LDK) = (LV == 0) ? ra1 : mask4(ra1, amask & 2u);
-    *reinterpret_cast<float4*>(ap + 2 * 32 * LDK) = (LV == 0) ? ra2 : mask4(ra2, amask & 4u);
-    *reinterpret_cast<float4*>(ap + 3 * 32 * LDK) = (LV == 0) ? ra3 : mask4(ra3, amask & 8u);
-    *reinterpret_cast<float4*>(ap + 4 * 32 * LDK) = (LV == 0) ? ra4 : mask4(ra4, amask & 16u);
-    *reinterpret_cast<float4*>(ap + 5 * 32 * LDK) = (LV == 0) ? ra5 : mask4(ra5, amask & 32u);
-    *reinterpret_cast<float4*>(ap + 6 * 32 * LDK) = (LV == 0) ? ra6 : mask4(ra6, amask & 64u);
-    *reinterpret_cast<float4*>(ap + 7 * 32 * LDK) = (LV == 0) ? ra7 : mask4(ra7, amask & 128u);
+    *reinterpret_cast<float4*>(ap + 0 * 32 * LDK) = ra0;
+    *reinterpret_cast<float4*>(ap + 1 * 32 * LDK) = ra1;
+    *reinterpret_cast<float4*>(ap + 2 * 32 * LDK) = ra2;
+    *reinterpret_cast<float4*>(ap + 3 * 32 * LDK) = ra3;
+    *reinterpret_cast<float4*>(ap + 4 * 32 * LDK) = ra4;
+    *reinterpret_cast<float4*>(ap + 5 * 32 * LDK) = ra5;
+    *reinterpret_cast<float4*>(ap + 6 * 32 * LDK) = ra6;
+    *reinterpret_cast<float4*>(ap + 7 * 32 * LDK) = ra7;
     float* bp = &Bs[row0 * LDK + col4 * 4];
     *reinterpret_cast<float4*>(bp) = rb0;
     if (BQ > 1) *reinterpret_cast<float4*>(bp + 32 * LDK) = rb1;
@@ -249,10 +239,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
     __syncthreads();  // every wave has finished reading the previous tile
     store_tile();
     __syncthreads();
-    if (LV != 2 && it + 1 < niter) load_tile(it + 1);  // in flight during the MFMAs below
+    if (it + 1 < niter) load_tile(it + 1);  // issued ahead of the MFMAs below
 #pragma unroll
     for (int gk = 0; gk < BK / 8; ++gk) {
-      if (LV == 2 && gk == 1 && it + 1 < niter) load_tile(it + 1);
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(a_rd + gk * 8);
       const f32x4 a1 = *reinterpret_cast<const f32x4*>(a_rd + 32 * LDK + gk * 8);
       f32x4 bf[NJ];
@@ -847,7 +836,6 @@ bool desc_ok(const DramConvDesc* d) {
 // = 1.33 rounds) but a good multiple of 2 per CU, pad the launch with dynamic LDS so that only
 // two workgroups fit per CU: 1024 tiles then run as exactly two full rounds.
 int lds_pad_for_balance(int BN, int nblk) {
-  if (const char* e = getenv("DRAM_IGEMM_PAD")) return atoi(e);   // tuning knob
   if (BN == 128) return 0;
   auto eff = [&](int slots) { return (double)nblk / (double)(((nblk + slots - 1) / slots) * slots); };
   const double e3 = eff(768), e2 = eff(512) * 0.97;  // 2/CU overlaps slightly less
@@ -863,11 +851,6 @@ int launch(int BN, const float* in, const float* wp, const float* bias, float* o
   fill_tiles(g, BN);
   dim3 grid(g.nblk), block(256);
   const int pad = lds_pad_for_balance(BN, g.nblk);
-  static int lv = -1;
-  if (lv < 0) {
-    const char* e = getenv("DRAM_IGEMM_LV");
-    lv = e ? atoi(e) : 0;
-  }
   const int ver = igemm_version();   // 0 = auto: LDS-DMA kernel for BN <= 64, register-staged for BN = 128
   if ((ver == 2 || ((ver == 0 || ver == 3) && BN <= 64)) && MODE != 2) {
     constexpr int M2 = MODE == 2 ? 0 : MODE;
@@ -887,21 +870,14 @@ int launch(int BN, const float* in, const float* wp, const float* bias, float* o
     DRAM_LAUNCH_CHECK();
     return DRAM_OK;
   }
-#define IG_LAUNCH(BN_, LV_) \
-  hipLaunchKernelGGL((conv_igemm_kernel<BN_, MODE, LV_>), grid, block, pad, s, in, wp, bias, out, stats, add, gate, g)
-#define IG_LAUNCH_LV(BN_)          \
-  do {                             \
-    if (lv == 1) IG_LAUNCH(BN_, 1); \
-    else if (lv == 2) IG_LAUNCH(BN_, 2); \
-    else IG_LAUNCH(BN_, 0);        \
-  } while (0)
+#define IG_LAUNCH(BN_) \
+  hipLaunchKernelGGL((conv_igemm_kernel<BN_, MODE>), grid, block, pad, s, in, wp, bias, out, stats, add, gate, g)
   switch (BN) {
-    case 128: IG_LAUNCH_LV(128); break;
-    case 64: IG_LAUNCH_LV(64); break;
-    case 32: IG_LAUNCH_LV(32); break;
+    case 128: IG_LAUNCH(128); break;
+    case 64: IG_LAUNCH(64); break;
+    case 32: IG_LAUNCH(32); break;
     default: return DRAM_ERR_UNSUPPORTED;
   }
-#undef IG_LAUNCH_LV
 #undef IG_LAUNCH
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
