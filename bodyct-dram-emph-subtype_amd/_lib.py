@@ -70,6 +70,10 @@ SIGNATURES = {
     "dram_upproject": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "dram_adam_multi": (I, [P, P, I, F, F, F, F, F, F, F, F, P]),
     "dram_sgd_multi": (I, [P, P, I, F, F, F, I, F, P]),
+    "dram_window_stats_nblk": (I, [LL]),
+    "dram_window_stats": (I, [P, P, LL, F, F, P]),
+    "dram_prep_image": (I, [P, P, P, P, I, I, I, I, I, I, F, F, P]),
+    "dram_prep_mask": (I, [P, P, P, I, I, I, I, I, I, P]),
     "dram_add": (I, [P, P, P, LL, P]),
 }
 

@@ -222,6 +222,21 @@ int dram_sgd_multi(const DramTensorRef* table, const DramChunkRef* chunks, int n
                    float momentum, float weight_decay, int first_step, float grad_scale,
                    dram_stream_t stream);
 
+/* ------------------------------------------------------------------------- */
+/* Deterministic input transforms of the reference data module (models.py:59-63):
+ * IntensityWindow (functional.py:13-26), Standardize (intensity_transforms.py:108-111),
+ * Interpolate(align_corners, only_in_plane) for images / masks (spatial_transforms.py:55-98).
+ *   scan [D,H,W] raw HU as float32; zidx [Do] int32 = torch.linspace(0, D-1, Do).long();
+ *   dram_window_stats -> partial [nblk][2] (sum w, sum w^2 of the windowed values);
+ *   mean_invstd [2] (device) = {mean, 1/std(unbiased)} of the windowed volume;
+ *   dram_prep_image -> out [Do,Ho,Wo]; dram_prep_mask -> nearest-resized mask. */
+int dram_window_stats_nblk(long long n);
+int dram_window_stats(const float* scan, float* partial, long long n, float lo, float hi, dram_stream_t stream);
+int dram_prep_image(const float* scan, const int* zidx, const float* mean_invstd, float* out, int D, int H, int W,
+                    int Do, int Ho, int Wo, float lo, float hi, dram_stream_t stream);
+int dram_prep_mask(const float* mask, const int* zidx, float* out, int D, int H, int W, int Do, int Ho, int Wo,
+                   dram_stream_t stream);
+
 /* out[i] = a[i] + b[i]  (gradient accumulation where two consumers meet) */
 int dram_add(const float* a, const float* b, float* out, long long n, dram_stream_t stream);
 

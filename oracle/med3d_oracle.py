@@ -306,6 +306,29 @@ def predict_upproject(dense: Tensor, size, ess: Tensor, lungs: Tensor):
 
 
 # ---------------------------------------------------------------------------
+# deterministic input transforms (models.py:59-63)
+# ---------------------------------------------------------------------------
+def prepare_image(scan: Tensor, target_size, from_span=(-1150.0, -300.0)) -> Tensor:
+    """IntensityWindow (functional.py:13-26) -> Standardize (intensity_transforms.py:108-111)
+    -> Interpolate(align_corners=True, only_in_plane=True) (spatial_transforms.py:55-75)."""
+    img = scan.float()
+    img = torch.clamp(img, min=from_span[0], max=from_span[1])
+    img = (img - from_span[0]) / (from_span[1] - from_span[0])
+    img = img - img.mean()
+    img = img / img.std()
+    data = F.interpolate(img[None], size=tuple(target_size[1:]), mode="bilinear", align_corners=True)
+    idx = torch.linspace(0, scan.shape[0] - 1, target_size[0]).long()
+    return data[:, idx][0]
+
+
+def prepare_mask(mask: Tensor, target_size) -> Tensor:
+    """Interpolate.apply_to_mask (spatial_transforms.py:77-98): nearest in-plane + depth select."""
+    data = F.interpolate(mask[None].float(), size=tuple(target_size[1:]), mode="nearest")
+    idx = torch.linspace(0, mask.shape[0] - 1, target_size[0]).long()
+    return data[:, idx][0].type(mask.dtype)
+
+
+# ---------------------------------------------------------------------------
 # optimizers (torch.optim.Adam / SGD semantics; models.py:385-394, 689-698)
 # ---------------------------------------------------------------------------
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,

@@ -187,6 +187,23 @@ def loss_case(ref_models, seed, shape, cle_labels, pse_labels):
                 reg0=reg0.detach().numpy(), reg1=reg1.detach().numpy())
 
 
+def transform_case(ref_models):
+    """Deterministic input pipeline of SubtypeDataModule._transform (models.py:59-63) through the
+    reference's own IntensityWindow / Standardize / Interpolate classes."""
+    g = torch.Generator().manual_seed(31)
+    scan = (torch.rand(20, 37, 45, generator=g) * 1400.0 - 1300.0)          # HU-like values
+    mask = torch.rand(20, 37, 45, generator=g) > 0.5
+    target = (12, 24, 32)
+    tr = [ref_models.IntensityWindow(from_span=(-1150, -300), to_span=(0, 1), output_dtype=torch.float32),
+          ref_models.Standardize(), ref_models.Interpolate(target, None, align_corners=True)]
+    img = scan.clone()
+    for t_ in tr:
+        img = t_.apply_to_image(img)
+    m = tr[2].apply_to_mask(mask.clone())
+    return dict(scan=scan.numpy(), mask=mask.numpy(), target=np.array(target), image_out=img.numpy(),
+                mask_out=m.numpy())
+
+
 def block_cases():
     """Per-block fixtures: crop_concat, shortcut-A detach,
     UpsampleConvBlock5d."""
@@ -260,6 +277,8 @@ def main():
     for i, rec in enumerate(lc):
         np.savez_compressed(os.path.join(OUT, f"loss_{i}.npz"), **rec)
         print("loss case", i, float(rec["loss"]))
+    np.savez_compressed(os.path.join(OUT, "transforms.npz"), **transform_case(rm))
+    print("wrote transforms.npz")
 
 
 if __name__ == "__main__":

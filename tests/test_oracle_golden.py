@@ -158,3 +158,14 @@ def test_oracle_adam_matches_torch():
         opt.step()
         orc.adam_step(p, gr, m, v, step, 1e-3)
     assert torch.allclose(p, ref.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_oracle_input_transforms_match_reference():
+    """models.py:59-63 pipeline through the reference's own transform classes (transforms.npz)."""
+    z = np.load(os.path.join(GOLDEN, "transforms.npz"))
+    tgt = tuple(int(v) for v in z["target"])
+    img = orc.prepare_image(torch.from_numpy(z["scan"]), tgt)
+    msk = orc.prepare_mask(torch.from_numpy(z["mask"]), tgt)
+    assert img.shape == tuple(z["image_out"].shape)
+    assert torch.equal(img, torch.from_numpy(z["image_out"]))
+    assert msk.dtype == torch.bool and torch.equal(msk, torch.from_numpy(z["mask_out"]))
