@@ -1,0 +1,719 @@
+// conv_wino.hip -- Winograd F(2x2x2, 3x3x3) path for the wide stride-1 3x3x3 convolutions
+// (forward, data gradient and weight gradient) on the gfx950 fp32 matrix cores.
+//
+// Same call sites as conv_igemm.hip / conv_wgrad.hip (reference med3d.py:91-100 conv3x3x3 inside
+// BasicBlock / Bottleneck, dilation 1/2/4 with padding == dilation; autograd's
+// convolution_backward for them).  The direct implicit GEMM already runs at ~0.86 of the fp32
+// MFMA peak, so the remaining lever is arithmetic: the 3-D Winograd transform needs 64 instead
+// of 216 multiplies per 2x2x2 output tile and channel pair (3.375x fewer MFMA flops).
+//
+//   U[xi][co][ci] = G w G^T (3-D)                      weight transform, once per step
+//   V[xi][t][ci]  = B^T x B (3-D) of the 4x4x4 input tile t            wino_in_kernel<0>
+//   M[xi][t][co]  = sum_ci V[xi][t][ci] * U[xi][co][ci]   64 dense GEMMs  wino_gemm_nn_kernel
+//   y(tile t)     = A^T M A (3-D) + bias (+ fused epilogue, BN partial sums) wino_out_kernel
+// Data gradient: the same pipeline on dy with the tap-flipped, transposed weights.
+// Weight gradient: dU[xi][co][ci] = sum_t (A dy A^T)[xi][t][co] * V[xi][t][ci]  (TN GEMMs, split
+// over t into slabs), then dw = G^T (sum of slabs) G in a fixed order -> deterministic.
+//
+// A dilated convolution is d^3 independent dilation-1 convolutions on the residue sub-lattices,
+// so the tiles are 2x2x2 blocks of a sub-lattice (voxel step d).  V and M round-trip through HBM
+// (8x the activation bytes), which is why the path is planned only for >= 256-channel layers:
+// there the GEMMs dominate (layer4: 2.3 GB of transform traffic vs 137 GFLOP per pass).
+//
+// GEMM kernels: 512 threads (8 waves as 4(M) x 2(N)), tile 256 x (64*NJ) x 32, operands staged by
+// LDS-DMA (global_load_lds_dwordx4), double-buffered, one barrier per K-step; NN form reads both
+// operands with the ds_read_b128 k-permutation trick of conv_igemm.hip, TN form reads [t][c] rows
+// with ds_read_b32 (lanes = consecutive channels).
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+struct WinoGeom {
+  int B, D, H, W;  // voxel grid (input and output grids coincide: stride 1, pad == dil)
+  int d;           // dilation
+  int Tz, Ty, Tx;  // 2x2x2 tiles per residue sub-lattice axis
+  int T;           // B * d^3 * Tz * Ty * Tx
+  int Tpad;        // T rounded up to the GEMM M tile (256)
+};
+
+// first OUTPUT voxel of tile t; tile-local positions step by g.d
+__device__ __forceinline__ void tile_origin(const WinoGeom& g, int t, int& b, int& z0, int& y0, int& x0) {
+  int r = t;
+  const int tx = r % g.Tx; r /= g.Tx;
+  const int ty = r % g.Ty; r /= g.Ty;
+  const int tz = r % g.Tz; r /= g.Tz;
+  const int rx = r % g.d; r /= g.d;
+  const int ry = r % g.d; r /= g.d;
+  const int rz = r % g.d;
+  b = r / g.d;
+  z0 = 2 * tz * g.d + rz;
+  y0 = 2 * ty * g.d + ry;
+  x0 = 2 * tx * g.d + rx;
+}
+
+// ------------------------------------------------------------------------------------------
+// Tile transforms into the Winograd domain.  One wave per (tile, 64-channel block); lanes are
+// consecutive channels (256-B coalesced rows).  out[xi][t][c], xi = (i*4 + j)*4 + k.
+//   MODE 0:  V = B^T v B over the 4x4x4 input tile (zero outside the volume)
+//   MODE 1:  A dy A^T over the 2x2x2 output-gradient tile (weight gradient)
+// Rows t in [T, Tpad) are written as zeros (the TN GEMM contracts over t).
+template <int MODE>
+__global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                      const WinoGeom g, const int C) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cblks = C >> 6;
+  const long plane = (long)g.Tpad * C;
+  const long total = (long)g.Tpad * cblks;
+  for (long w = blockIdx.x * 4L + wave; w < total; w += gridDim.x * 4L) {
+    const int t = (int)(w / cblks);
+    const int c = (int)(w - (long)t * cblks) * 64 + lane;
+    float v[4][4][4];
+    if (t >= g.T) {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) out[i * plane + (long)t * C + c] = 0.f;
+      continue;
+    }
+    int b, z0, y0, x0;
+    tile_origin(g, t, b, z0, y0, x0);
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int z = z0 + (i - 1) * g.d;
+        const bool zo = (z >= 0) & (z < g.D);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int y = y0 + (j - 1) * g.d;
+          const bool yo = zo & (y >= 0) & (y < g.H);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int x = x0 + (k - 1) * g.d;
+            const bool ok = yo & (x >= 0) & (x < g.W);
+            const long o = ((((long)b * g.D + z) * g.H + y) * g.W + x) * C + c;
+            v[i][j][k] = ok ? in[o] : 0.f;
+          }
+        }
+      }
+      // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1] along x, y, z
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a0 = v[i][j][0], a1 = v[i][j][1], a2 = v[i][j][2], a3 = v[i][j][3];
+          v[i][j][0] = a0 - a2; v[i][j][1] = a1 + a2; v[i][j][2] = a2 - a1; v[i][j][3] = a1 - a3;
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a0 = v[i][0][k], a1 = v[i][1][k], a2 = v[i][2][k], a3 = v[i][3][k];
+          v[i][0][k] = a0 - a2; v[i][1][k] = a1 + a2; v[i][2][k] = a2 - a1; v[i][3][k] = a1 - a3;
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a0 = v[0][j][k], a1 = v[1][j][k], a2 = v[2][j][k], a3 = v[3][j][k];
+          v[0][j][k] = a0 - a2; v[1][j][k] = a1 + a2; v[2][j][k] = a2 - a1; v[3][j][k] = a1 - a3;
+        }
+    } else {
+      float u[2][2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int z = z0 + i * g.d;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int y = y0 + j * g.d;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int x = x0 + k * g.d;
+            const bool ok = (z < g.D) & (y < g.H) & (x < g.W);
+            const long o = ((((long)b * g.D + z) * g.H + y) * g.W + x) * C + c;
+            u[i][j][k] = ok ? in[o] : 0.f;
+          }
+        }
+      }
+      // A = [1 0; 1 1; 1 -1; 0 -1] along x, y, z
+      float p[2][2][4], q[2][4][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float a0 = u[i][j][0], a1 = u[i][j][1];
+          p[i][j][0] = a0; p[i][j][1] = a0 + a1; p[i][j][2] = a0 - a1; p[i][j][3] = -a1;
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a0 = p[i][0][k], a1 = p[i][1][k];
+          q[i][0][k] = a0; q[i][1][k] = a0 + a1; q[i][2][k] = a0 - a1; q[i][3][k] = -a1;
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a0 = q[0][j][k], a1 = q[1][j][k];
+          v[0][j][k] = a0; v[1][j][k] = a0 + a1; v[2][j][k] = a0 - a1; v[3][j][k] = -a1;
+        }
+    }
+    float* o = out + (long)t * C + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[((i * 4 + j) * 4 + k) * plane] = v[i][j][k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Output transform: y(tile) = A^T M A (3-D), + bias, optional fused  += add * (gate > 0)
+// (identity-shortcut gradient), per-channel BatchNorm partial sums.  A workgroup owns
+// TPB consecutive tiles x 64 channels; stats row = tile block.
+constexpr int WINO_TPB = 16;
+
+__global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ mh, const float* __restrict__ bias,
+                                                       const float* __restrict__ add, const float* __restrict__ gate,
+                                                       float* __restrict__ out, float* __restrict__ stats,
+                                                       const WinoGeom g, const int N) {
+  __shared__ float red[4][2][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cblks = N >> 6;
+  const int cb = blockIdx.x % cblks, tb = blockIdx.x / cblks;
+  const int c = cb * 64 + lane;
+  const long plane = (long)g.Tpad * N;
+  const float bv = bias ? bias[c] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  for (int q = wave; q < WINO_TPB; q += 4) {
+    const int t = tb * WINO_TPB + q;
+    if (t >= g.T) break;
+    float m[4][4][4];
+    const float* src = mh + (long)t * N + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[i][j][k] = src[((i * 4 + j) * 4 + k) * plane];
+    // A^T = [1 1 1 0; 0 1 -1 -1] along x, y, z
+    float p[4][4][2], q2[4][2][2], o[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        p[i][j][0] = m[i][j][0] + m[i][j][1] + m[i][j][2];
+        p[i][j][1] = m[i][j][1] - m[i][j][2] - m[i][j][3];
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        q2[i][0][k] = p[i][0][k] + p[i][1][k] + p[i][2][k];
+        q2[i][1][k] = p[i][1][k] - p[i][2][k] - p[i][3][k];
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        o[0][j][k] = q2[0][j][k] + q2[1][j][k] + q2[2][j][k];
+        o[1][j][k] = q2[1][j][k] - q2[2][j][k] - q2[3][j][k];
+      }
+    int b, z0, y0, x0;
+    tile_origin(g, t, b, z0, y0, x0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int z = z0 + i * g.d;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int y = y0 + j * g.d;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int x = x0 + k * g.d;
+          if ((z < g.D) & (y < g.H) & (x < g.W)) {
+            const long oo = ((((long)b * g.D + z) * g.H + y) * g.W + x) * N + c;
+            float v = o[i][j][k] + bv;
+            if (add) {
+              const float av = add[oo];
+              v += gate ? (gate[oo] > 0.f ? av : 0.f) : av;
+            }
+            out[oo] = v;
+            s1 += v;
+            s2 += v * v;
+          }
+        }
+      }
+    }
+  }
+  if (stats) {
+    red[wave][0][lane] = s1;
+    red[wave][1][lane] = s2;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int which = threadIdx.x >> 6;
+      const float v = red[0][which][lane] + red[1][which][lane] + red[2][which][lane] + red[3][which][lane];
+      stats[((long)tb * 2 + which) * N + c] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight transform  U = G w G^T (3-D), G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].
+//   blockIdx.y == 0: uf[xi][co][ci]               (forward B operand, K = ci contiguous)
+//   blockIdx.y == 1: ub[xi][ci][co], taps flipped  (data-gradient B operand, K = co contiguous)
+__device__ __forceinline__ void g4(const float a0, const float a1, const float a2, float& r0, float& r1, float& r2,
+                                   float& r3) {
+  const float h = 0.5f * (a0 + a2);
+  r0 = a0;
+  r1 = h + 0.5f * a1;
+  r2 = h - 0.5f * a1;
+  r3 = a2;
+}
+
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ uf,
+                                                          float* __restrict__ ub, const int Cout, const int Cin) {
+  const bool bwd = blockIdx.y == 1;
+  float* dst = bwd ? ub : uf;
+  if (!dst) return;
+  const long n = (long)Cout * Cin;
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= n) return;
+  int co, ci;
+  if (!bwd) { ci = (int)(i % Cin); co = (int)(i / Cin); }
+  else { co = (int)(i % Cout); ci = (int)(i / Cout); }
+  const float* src = w + ((long)co * Cin + ci) * 27;
+  float gw[3][3][3];
+#pragma unroll
+  for (int a = 0; a < 27; ++a) (&gw[0][0][0])[a] = src[bwd ? 26 - a : a];
+  float p[3][3][4], q[3][4][4], u[4][4][4];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) g4(gw[a][b][0], gw[a][b][1], gw[a][b][2], p[a][b][0], p[a][b][1], p[a][b][2], p[a][b][3]);
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g4(p[a][0][k], p[a][1][k], p[a][2][k], q[a][0][k], q[a][1][k], q[a][2][k], q[a][3][k]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g4(q[0][j][k], q[1][j][k], q[2][j][k], u[0][j][k], u[1][j][k], u[2][j][k], u[3][j][k]);
+#pragma unroll
+  for (int a = 0; a < 64; ++a) dst[a * n + i] = (&u[0][0][0])[a];
+}
+
+// dw[co][ci][27] = G^T (sum over splits of slab[split][xi][co][ci]) G   (3-D), fixed order
+__device__ __forceinline__ void gt3(const float a0, const float a1, const float a2, const float a3, float& r0,
+                                    float& r1, float& r2) {
+  r0 = a0 + 0.5f * (a1 + a2);
+  r1 = 0.5f * (a1 - a2);
+  r2 = 0.5f * (a1 + a2) + a3;
+}
+
+__global__ __launch_bounds__(256) void wino_wgrad_out_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                             const int Cout, const int Cin, const int nsplit) {
+  const long n = (long)Cout * Cin;
+  const long i = blockIdx.x * 256L + threadIdx.x;   // (co, ci), ci fastest
+  if (i >= n) return;
+  float s[4][4][4];
+#pragma unroll
+  for (int a = 0; a < 64; ++a) {
+    float acc = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) acc += slab[((long)sp * 64 + a) * n + i];
+    (&s[0][0][0])[a] = acc;
+  }
+  float p[4][4][3], q[4][3][3], r[3][3][3];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) gt3(s[a][b][0], s[a][b][1], s[a][b][2], s[a][b][3], p[a][b][0], p[a][b][1], p[a][b][2]);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gt3(p[a][0][k], p[a][1][k], p[a][2][k], p[a][3][k], q[a][0][k], q[a][1][k], q[a][2][k]);
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gt3(q[0][j][k], q[1][j][k], q[2][j][k], q[3][j][k], r[0][j][k], r[1][j][k], r[2][j][k]);
+  float* dst = dw + i * 27;
+#pragma unroll
+  for (int a = 0; a < 27; ++a) dst[a] = (&r[0][0][0])[a];
+}
+
+// ------------------------------------------------------------------------------------------
+// NN batched GEMM:  Y[xi][m][n] = sum_k A[xi][m][k] * Bw[xi][n][k]     (M = Tpad, K % 32 == 0)
+template <int NJ>
+__global__ __launch_bounds__(512) void wino_gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ Bw,
+                                                           float* __restrict__ Y, const int Mpad, const int N,
+                                                           const int K, const int m_tiles, const int n_tiles,
+                                                           const int nblk) {
+  constexpr int BN = 64 * NJ;
+  constexpr int STAGE = (256 + BN) * 32;
+  __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = xcd_remap(blockIdx.x, nblk);
+  const int nt = L % n_tiles;
+  const int r0 = L / n_tiles;
+  const int mt = r0 % m_tiles;
+  const int xi = r0 / m_tiles;
+  const float* Ab = A + ((long)xi * Mpad + (long)mt * 256) * K;
+  const float* Bb = Bw + ((long)xi * N + (long)nt * BN) * K;
+  float* Yb = Y + ((long)xi * Mpad + (long)mt * 256) * N + nt * BN;
+
+  // DMA pieces (8 rows x 128 B each): A rows 32*wave + 8j + sub, B rows 8*NJ*wave + 8jj + sub.
+  // 16-B slot swizzle slot ^ ((row >> 1) & 7) applied on the source address.
+  const int sub = lane >> 3, pslot = lane & 7;
+  const int s_even = pslot ^ (lane >> 4), s_odd = s_even ^ 4;
+  int aoff[4], boff[NJ];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) aoff[j] = (32 * wave + 8 * j + sub) * K + ((j & 1) ? s_odd : s_even) * 4;
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int nrow = 8 * NJ * wave + 8 * jj + sub;
+    boff[jj] = nrow * K + (pslot ^ ((nrow >> 1) & 7)) * 4;
+  }
+  auto issue = [&](int it, int stage) __attribute__((always_inline)) {
+    float* as = lds + stage * STAGE + 32 * wave * 32;
+    float* bs = lds + stage * STAGE + 256 * 32 + 8 * NJ * wave * 32;
+    const float* ag = Ab + it * 32;
+    const float* bg = Bb + it * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ag + aoff[j]),
+                                       (__attribute__((address_space(3))) void*)(as + j * 8 * 32), 16, 0, 0);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bg + boff[jj]),
+                                       (__attribute__((address_space(3))) void*)(bs + jj * 8 * 32), 16, 0, 0);
+  };
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int rsw = (li >> 1) & 7;
+  const int a_row = (wm * 64 + li) * 32;
+  const int b_row = 256 * 32 + (wn * NJ * 32 + li) * 32;
+  const int niter = K / 32;
+
+  issue(0, 0);
+  for (int it = 0; it < niter; ++it) {
+    __syncthreads();   // tile `it` has landed; stage (it+1)&1 is free again
+    if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
+    const float* st = lds + (it & 1) * STAGE;
+#pragma unroll
+    for (int gk = 0; gk < 4; ++gk) {
+      const int so = ((2 * gk + lh) ^ rsw) * 4;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(st + a_row + so);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(st + a_row + 32 * 32 + so);
+      f32x4 bf[NJ];
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) bf[nj] = *reinterpret_cast<const f32x4*>(st + b_row + nj * 32 * 32 + so);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+          acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bf[nj][e], acc[0][nj], 0, 0, 0);
+          acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bf[nj][e], acc[1][nj], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      float* o = Yb + (long)row * N + wn * NJ * 32 + li;
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) o[nj * 32] = acc[mi][nj][e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TN batched GEMM (weight gradient):
+//   slab[split][xi][m][n] = sum_{t in split} Ah[xi][t][m] * Bh[xi][t][n]      (M % 256 == 0)
+template <int NJ>
+__global__ __launch_bounds__(512) void wino_gemm_tn_kernel(const float* __restrict__ Ah, const float* __restrict__ Bh,
+                                                           float* __restrict__ slab, const int Tpad, const int M,
+                                                           const int N, const int m_tiles, const int n_tiles,
+                                                           const int nsplit, const int kper, const int nblk) {
+  constexpr int BN = 64 * NJ;
+  constexpr int STAGE = 32 * (256 + BN);
+  constexpr int BQ = BN / 4;          // 16-B slots per B row
+  constexpr int RPP = 64 / BQ;        // B rows per DMA piece
+  __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int L = xcd_remap(blockIdx.x, nblk);
+  const int nt = L % n_tiles; L /= n_tiles;
+  const int mt = L % m_tiles; L /= m_tiles;
+  const int split = L % nsplit;
+  const int xi = L / nsplit;
+  const int t0 = split * kper;
+  const int t1 = (t0 + kper < Tpad) ? t0 + kper : Tpad;
+  const float* Ab = Ah + ((long)xi * Tpad + t0) * M + mt * 256 + lane * 4;
+  const float* Bb = Bh + ((long)xi * Tpad + t0) * N + nt * BN + (lane % BQ) * 4;
+  const int brow = lane / BQ;
+
+  auto issue = [&](int it, int stage) __attribute__((always_inline)) {
+    float* as = lds + stage * STAGE;
+    float* bs = as + 32 * 256;
+    const float* ag = Ab + (long)it * 32 * M;
+    const float* bg = Bb + (long)it * 32 * N;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = 4 * wave + j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ag + (long)row * M),
+                                       (__attribute__((address_space(3))) void*)(as + row * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int p = NJ * wave + jj;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bg + (long)(p * RPP + brow) * N),
+                                       (__attribute__((address_space(3))) void*)(bs + p * 256), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int niter = (t1 - t0) / 32;
+
+  if (niter > 0) issue(0, 0);
+  for (int it = 0; it < niter; ++it) {
+    __syncthreads();
+    if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
+    const float* as = lds + (it & 1) * STAGE + wm * 64 + li;
+    const float* bs = lds + (it & 1) * STAGE + 32 * 256 + wn * NJ * 32 + li;
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+      const int kr = 2 * kk + lh;
+      const float a0 = as[kr * 256], a1 = as[kr * 256 + 32];
+      float bf[NJ];
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) bf[nj] = bs[kr * BN + nj * 32];
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) {
+        acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[nj], acc[0][nj], 0, 0, 0);
+        acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[nj], acc[1][nj], 0, 0, 0);
+      }
+    }
+  }
+
+  float* sb = slab + (((long)split * 64 + xi) * M + mt * 256) * N + nt * BN;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      float* o = sb + (long)row * N + wn * NJ * 32 + li;
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) o[nj * 32] = acc[mi][nj][e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+bool wino_geom_ok(const DramConvDesc* d) {
+  if (!d) return false;
+  if (d->B < 1 || d->D < 1 || d->H < 1 || d->W < 1) return false;
+  if (d->k != 3 || d->stride != 1 || d->dil < 1 || d->pad != d->dil) return false;
+  if (d->Do != d->D || d->Ho != d->H || d->Wo != d->W) return false;
+  if (d->Cin < 64 || d->Cout < 64 || d->Cin % 64 != 0 || d->Cout % 64 != 0) return false;
+  return true;
+}
+
+WinoGeom make_geom(const DramConvDesc* d) {
+  WinoGeom g{};
+  g.B = d->B; g.D = d->D; g.H = d->H; g.W = d->W; g.d = d->dil;
+  auto tiles = [&](int n) { return ((n + g.d - 1) / g.d + 1) / 2; };
+  g.Tz = tiles(g.D); g.Ty = tiles(g.H); g.Tx = tiles(g.W);
+  const long long T = (long long)g.B * g.d * g.d * g.d * g.Tz * g.Ty * g.Tx;
+  g.T = (int)T;
+  g.Tpad = (int)((T + 255) / 256 * 256);
+  return g;
+}
+
+bool wino_size_ok(const DramConvDesc* d) {   // int32 offsets inside one xi plane of the GEMM operands
+  const WinoGeom g = make_geom(d);
+  const long long T = (long long)g.B * g.d * g.d * g.d * g.Tz * g.Ty * g.Tx;
+  const long long cmax = d->Cin > d->Cout ? d->Cin : d->Cout;
+  return T > 0 && (T + 255) * cmax < (1LL << 31);
+}
+
+int nj_for(int N) { return N % 256 == 0 ? 4 : (N % 128 == 0 ? 2 : 1); }
+
+// wgrad: M = Cout (tile 256), N = Cin; split over t so that >= ~512 workgroups are in flight
+struct TnPlan { int nj, m_tiles, n_tiles, nsplit, kper; };
+bool plan_tn(const DramConvDesc* d, const WinoGeom& g, TnPlan& p) {
+  if (d->Cout % 256 != 0) return false;
+  p.nj = nj_for(d->Cin);
+  p.m_tiles = d->Cout / 256;
+  p.n_tiles = d->Cin / (64 * p.nj);
+  const int base = 64 * p.m_tiles * p.n_tiles;
+  const int k32 = g.Tpad / 32;
+  int ns = 1;
+  while (base * ns < 512 && ns * 2 <= k32 / 4 && ns < 16) ns *= 2;
+  p.nsplit = ns;
+  p.kper = ((k32 + ns - 1) / ns) * 32;
+  return true;
+}
+
+int grid_for(long waves) {
+  long b = (waves + 3) / 4;
+  return (int)(b > 65536 ? 65536 : (b < 1 ? 1 : b));
+}
+
+int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, int K, hipStream_t s) {
+  const int nj = nj_for(N);
+  const int m_tiles = g.Tpad / 256, n_tiles = N / (64 * nj);
+  const int nblk = 64 * m_tiles * n_tiles;
+#define WNN(NJ_) \
+  hipLaunchKernelGGL((wino_gemm_nn_kernel<NJ_>), dim3(nblk), dim3(512), 0, s, A, U, Y, g.Tpad, N, K, m_tiles, n_tiles, nblk)
+  if (nj == 4) WNN(4);
+  else if (nj == 2) WNN(2);
+  else WNN(1);
+#undef WNN
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+// shared by forward (x, uf) and data gradient (dy, ub): in[..., K] -> out[..., N]
+int run_conv(const float* in, const float* U, const float* bias, const float* add, const float* gate, float* out,
+             float* stats, const DramConvDesc* d, int K, int N, void* ws, size_t ws_bytes, hipStream_t s) {
+  const WinoGeom g = make_geom(d);
+  const size_t need = (size_t)64 * g.Tpad * ((size_t)K + N) * sizeof(float);
+  if (!ws || ws_bytes < need) return DRAM_ERR_WORKSPACE;
+  float* V = (float*)ws;
+  float* Mh = V + (size_t)64 * g.Tpad * K;
+  hipLaunchKernelGGL((wino_in_kernel<0>), dim3(grid_for((long)g.Tpad * (K / 64))), dim3(256), 0, s, in, V, g, K);
+  DRAM_LAUNCH_CHECK();
+  const int rc = run_nn(V, U, Mh, g, N, K, s);
+  if (rc != DRAM_OK) return rc;
+  const int ntb = (g.T + WINO_TPB - 1) / WINO_TPB;
+  hipLaunchKernelGGL(wino_out_kernel, dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add, gate, out, stats, g, N);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+extern "C" int dram_wino_applicable(const DramConvDesc* d) {
+  return (wino_geom_ok(d) && wino_size_ok(d)) ? 1 : 0;
+}
+
+// Plan: Winograd where the 8x transform traffic is small next to the GEMMs (>= 256 channels on
+// one side and >= 128 on the other).  DRAM_CONV_ALGO: 0/unset auto, 1 always direct, 2 Winograd
+// wherever applicable (tests).
+extern "C" int dram_conv_use_wino(const DramConvDesc* d) {
+  if (!dram_wino_applicable(d)) return 0;
+  const char* v = getenv("DRAM_CONV_ALGO");   // read per call: tests switch it between cases
+  const int algo = v ? atoi(v) : 0;
+  if (algo == 1) return 0;
+  if (algo == 2) return 1;
+  const int cmin = d->Cin < d->Cout ? d->Cin : d->Cout, cmax = d->Cin < d->Cout ? d->Cout : d->Cin;
+  const WinoGeom g = make_geom(d);
+  return (cmax >= 256 && cmin >= 128 && g.T >= 1024) ? 1 : 0;
+}
+
+extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, int Cout, int Cin, dram_stream_t stream) {
+  if (!w || (!uf && !ub) || Cout < 1 || Cin < 1) return DRAM_ERR_BAD_ARG;
+  const long n = (long)Cout * Cin;
+  hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream, w, uf,
+                     ub, Cout, Cin);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_wino_num_stat_rows(const DramConvDesc* d) {
+  if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
+  const WinoGeom g = make_geom(d);
+  return (g.T + WINO_TPB - 1) / WINO_TPB;
+}
+
+/* pass: 0 forward, 1 data gradient, 2 weight gradient */
+extern "C" size_t dram_wino_workspace(const DramConvDesc* d, int pass) {
+  if (!dram_wino_applicable(d) || pass < 0 || pass > 2) return 0;
+  const WinoGeom g = make_geom(d);
+  size_t n = (size_t)64 * g.Tpad * ((size_t)d->Cin + d->Cout);
+  if (pass == 2) {
+    TnPlan p;
+    if (!plan_tn(d, g, p)) return 0;
+    n += (size_t)p.nsplit * 64 * d->Cout * d->Cin;
+  }
+  return n * sizeof(float);
+}
+
+extern "C" int dram_wino_conv3d_fwd(const float* x, const float* uf, const float* bias, float* y, float* stats_partial,
+                                    const DramConvDesc* d, void* workspace, size_t workspace_bytes,
+                                    dram_stream_t stream) {
+  if (!x || !uf || !y) return DRAM_ERR_BAD_ARG;
+  if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
+  return run_conv(x, uf, bias, nullptr, nullptr, y, stats_partial, d, d->Cin, d->Cout, workspace, workspace_bytes,
+                  (hipStream_t)stream);
+}
+
+extern "C" int dram_wino_conv3d_bwd_data(const float* dy, const float* ub, float* dx, const float* add,
+                                         const float* gate, const DramConvDesc* d, void* workspace,
+                                         size_t workspace_bytes, dram_stream_t stream) {
+  if (!dy || !ub || !dx || (gate && !add)) return DRAM_ERR_BAD_ARG;
+  if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
+  return run_conv(dy, ub, nullptr, add, gate, dx, nullptr, d, d->Cout, d->Cin, workspace, workspace_bytes,
+                  (hipStream_t)stream);
+}
+
+extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* dy, float* dw, const DramConvDesc* d,
+                                           void* workspace, size_t workspace_bytes, dram_stream_t stream) {
+  if (!x || !dy || !dw) return DRAM_ERR_BAD_ARG;
+  if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
+  const WinoGeom g = make_geom(d);
+  TnPlan p;
+  if (!plan_tn(d, g, p)) return DRAM_ERR_UNSUPPORTED;
+  const size_t need = dram_wino_workspace(d, 2);
+  if (!workspace || workspace_bytes < need) return DRAM_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* V = (float*)workspace;                               // [64][Tpad][Cin]
+  float* Dh = V + (size_t)64 * g.Tpad * d->Cin;               // [64][Tpad][Cout]
+  float* slab = Dh + (size_t)64 * g.Tpad * d->Cout;           // [nsplit][64][Cout][Cin]
+  hipLaunchKernelGGL((wino_in_kernel<0>), dim3(grid_for((long)g.Tpad * (d->Cin / 64))), dim3(256), 0, s, x, V, g,
+                     d->Cin);
+  DRAM_LAUNCH_CHECK();
+  hipLaunchKernelGGL((wino_in_kernel<1>), dim3(grid_for((long)g.Tpad * (d->Cout / 64))), dim3(256), 0, s, dy, Dh, g,
+                     d->Cout);
+  DRAM_LAUNCH_CHECK();
+  const int nblk = 64 * p.nsplit * p.m_tiles * p.n_tiles;
+#define WTN(NJ_)                                                                                                  \
+  hipLaunchKernelGGL((wino_gemm_tn_kernel<NJ_>), dim3(nblk), dim3(512), 0, s, Dh, V, slab, g.Tpad, d->Cout, d->Cin, \
+                     p.m_tiles, p.n_tiles, p.nsplit, p.kper, nblk)
+  if (p.nj == 4) WTN(4);
+  else if (p.nj == 2) WTN(2);
+  else WTN(1);
+#undef WTN
+  DRAM_LAUNCH_CHECK();
+  const long n = (long)d->Cout * d->Cin;
+  hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slab, dw, d->Cout,
+                     d->Cin, p.nsplit);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}

@@ -92,7 +92,7 @@ class Engine:
         w = st.P[wname]
         B, D, H, W, Cin = x.shape
         g = ConvGeom(B, D, H, W, Cin, w.shape[0], k, stride, pad, dil)
-        wf, wb = ops.pack_conv_weight(w, True, st.need_grad)
+        wf, wb = ops.pack_conv_weight(w, True, st.need_grad, g)
         y, sp = ops.conv3d_fwd(x, wf, st.P[bname] if bname else None, g, st.training)
         z, mean, invstd, count = self._bn_fwd(st, y, sp, bnp, residual, rs)
         c = None

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import ctypes
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 
@@ -169,30 +169,66 @@ class ConvGeom:
 
 
 # --------------------------------------------------------------------------- conv
-def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True) -> Tuple[Optional[Tensor], Optional[Tensor]]:
-    """[Cout,Cin,k,k,k] -> wf [taps,Cout,Cin], wb [taps,Cin,Cout]."""
+_WORKSPACE: Dict[torch.device, Tensor] = {}
+
+
+def _workspace(nbytes: int, device) -> Tensor:
+    """Grow-only scratch shared by the conv passes (they run back to back on one stream)."""
+    device = torch.device(device)
+    n = (nbytes + 3) // 4
+    ws = _WORKSPACE.get(device)
+    if ws is None or ws.numel() < n:
+        _WORKSPACE.pop(device, None)
+        ws = None
+        ws = torch.empty((n,), device=device, dtype=torch.float32)
+        _WORKSPACE[device] = ws
+    return ws
+
+
+def conv_use_wino(g: "ConvGeom") -> bool:
+    """Library plan: Winograd F(2x2x2,3x3x3) path for this geometry (dram_conv_use_wino)."""
+    return bool(_L().dram_conv_use_wino(ctypes.byref(g.desc())))
+
+
+def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True, g: Optional["ConvGeom"] = None
+                     ) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """[Cout,Cin,k,k,k] -> wf [taps,Cout,Cin], wb [taps,Cin,Cout]; for a geometry the library plans
+    on the Winograd path the packed copies are the transformed weights (64 'taps', wb tap-flipped)."""
     _req(w, "w")
     Cout, Cin = w.shape[0], w.shape[1]
     taps = w.shape[2] * w.shape[3] * w.shape[4]
-    wf = torch.empty((taps, Cout, Cin), device=w.device, dtype=torch.float32) if want_fwd else None
-    wb = torch.empty((taps, Cin, Cout), device=w.device, dtype=torch.float32) if want_bwd else None
-    _chk(_L().dram_pack_conv_weight(_p(w), _p(wf), _p(wb), Cout, Cin, taps, _stream()), "dram_pack_conv_weight")
+    wino = g is not None and conv_use_wino(g)
+    pt = 64 if wino else taps
+    wf = torch.empty((pt, Cout, Cin), device=w.device, dtype=torch.float32) if want_fwd else None
+    wb = torch.empty((pt, Cin, Cout), device=w.device, dtype=torch.float32) if want_bwd else None
+    if wino:
+        _chk(_L().dram_wino_pack_weight(_p(w), _p(wf), _p(wb), Cout, Cin, _stream()), "dram_wino_pack_weight")
+    else:
+        _chk(_L().dram_pack_conv_weight(_p(w), _p(wf), _p(wb), Cout, Cin, taps, _stream()), "dram_pack_conv_weight")
     return wf, wb
 
 
 def conv3d_fwd(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, want_stats: bool):
     _req(x, "x", shape=g.in_shape)
-    _req(wf, "wf", shape=(g.taps, g.Cout, g.Cin))
+    wino = conv_use_wino(g)
+    _req(wf, "wf", shape=(64 if wino else g.taps, g.Cout, g.Cin))
     if bias is not None:
         _req(bias, "bias", shape=(g.Cout,))
     d = g.desc()
     y = torch.empty(g.out_shape, device=x.device, dtype=torch.float32)
     stats = None
     if want_stats:
-        nt = _L().dram_conv_num_mtiles(ctypes.byref(d))
+        nt = (_L().dram_wino_num_stat_rows if wino else _L().dram_conv_num_mtiles)(ctypes.byref(d))
         if nt <= 0:
             raise RuntimeError(f"dram_conv_num_mtiles rejected {g}")
         stats = torch.empty((nt, 2, g.Cout), device=x.device, dtype=torch.float32)
+    if wino:
+        nbytes = _L().dram_wino_workspace(ctypes.byref(d), 0)
+        ws = _workspace(nbytes, x.device)
+        with _span("conv_wino_kernels", g.flops, f"fwd {g}"):
+            _chk(_L().dram_wino_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), ctypes.byref(d), _p(ws), nbytes,
+                                           _stream()), f"dram_wino_conv3d_fwd{g}")
+        return y, stats
     with _span("conv_igemm_kernel", g.flops, f"fwd {g}"):
         _chk(_L().dram_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), ctypes.byref(d), _stream()),
              f"dram_conv3d_fwd{g}")
@@ -202,13 +238,21 @@ def conv3d_fwd(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, want_
 def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] = None,
                     gate: Optional[Tensor] = None) -> Tensor:
     _req(dy, "dy", shape=g.out_shape)
-    _req(wb, "wb", shape=(g.taps, g.Cin, g.Cout))
+    wino = conv_use_wino(g)
+    _req(wb, "wb", shape=(64 if wino else g.taps, g.Cin, g.Cout))
     if add is not None:
         _req(add, "add", shape=g.in_shape)
     if gate is not None:
         _req(gate, "gate", shape=g.in_shape)
     d = g.desc()
     dx = torch.empty(g.in_shape, device=dy.device, dtype=torch.float32)
+    if wino:
+        nbytes = _L().dram_wino_workspace(ctypes.byref(d), 1)
+        ws = _workspace(nbytes, dy.device)
+        with _span("conv_wino_kernels", g.flops, f"dgrad {g}"):
+            _chk(_L().dram_wino_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d), _p(ws),
+                                                nbytes, _stream()), f"dram_wino_conv3d_bwd_data{g}")
+        return dx
     with _span("conv_igemm_kernel", g.flops, f"dgrad {g}"):
         _chk(_L().dram_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d), _stream()),
              f"dram_conv3d_bwd_data{g}")
@@ -219,13 +263,21 @@ def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] 
     _req(x, "x", shape=g.in_shape)
     _req(dy, "dy", shape=g.out_shape)
     d = g.desc()
+    shape = (g.Cout, g.Cin, g.k, g.k, g.k)
+    dw = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
+    _req(dw, "dw", shape=shape)
+    if conv_use_wino(g):
+        nbytes = _L().dram_wino_workspace(ctypes.byref(d), 2)
+        if nbytes:                                   # 0: this geometry's weight gradient stays on the direct path
+            ws = _workspace(nbytes, x.device)
+            with _span("conv_wino_kernels", g.flops, f"wgrad {g}"):
+                _chk(_L().dram_wino_conv3d_bwd_weight(_p(x), _p(dy), _p(dw), ctypes.byref(d), _p(ws), nbytes,
+                                                      _stream()), f"dram_wino_conv3d_bwd_weight{g}")
+            return dw
     nbytes = _L().dram_conv3d_bwd_weight_workspace(ctypes.byref(d))
     if nbytes == 0:
         raise RuntimeError(f"dram_conv3d_bwd_weight: unsupported geometry {g}")
     ws = torch.empty(((nbytes + 3) // 4,), device=x.device, dtype=torch.float32)
-    shape = (g.Cout, g.Cin, g.k, g.k, g.k)
-    dw = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
-    _req(dw, "dw", shape=shape)
     with _span("conv_wgrad_kernel+reduce", g.flops, f"wgrad {g}"):
         _chk(_L().dram_conv3d_bwd_weight(_p(x), _p(dy), _p(dw), ctypes.byref(d), _p(ws), nbytes, _stream()),
              f"dram_conv3d_bwd_weight{g}")

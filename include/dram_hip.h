@@ -83,6 +83,35 @@ int dram_conv3d_bwd_weight(const float* x, const float* dy, float* dw, const Dra
 int dram_conv_num_mtiles(const DramConvDesc* desc);
 
 /* ------------------------------------------------------------------------- */
+/* Winograd F(2x2x2, 3x3x3) path for stride-1 3x3x3 convolutions with pad == dil and
+ * Cin, Cout multiples of 64 (the BasicBlock / Bottleneck conv3x3x3 sites, med3d.py:91-100,
+ * and their autograd gradients): 64 instead of 216 multiplies per 2x2x2 output tile and
+ * channel pair.  Same tensors and layouts as dram_conv3d_*; the packed weights are the
+ * transformed ones and every pass needs a caller-owned workspace.
+ *   dram_wino_applicable: 1 when the geometry is supported.
+ *   dram_conv_use_wino:   1 when the library's plan prefers this path for desc (wide layers;
+ *                         env DRAM_CONV_ALGO: 1 = never, 2 = wherever applicable).
+ *   dram_wino_pack_weight: w [Cout][Cin][27] -> uf [64][Cout][Cin], ub [64][Cin][Cout]
+ *                         (taps flipped, data-gradient operand); either may be NULL.
+ *   dram_wino_workspace(desc, pass): bytes for pass 0 forward, 1 data gradient, 2 weight
+ *                         gradient (0 when unsupported).
+ *   dram_wino_num_stat_rows: rows of stats_partial written by dram_wino_conv3d_fwd.
+ * Deterministic (no atomics; the weight gradient sums its slabs in a fixed order). */
+int dram_wino_applicable(const DramConvDesc* desc);
+int dram_conv_use_wino(const DramConvDesc* desc);
+int dram_wino_pack_weight(const float* w, float* uf, float* ub, int Cout, int Cin, dram_stream_t stream);
+size_t dram_wino_workspace(const DramConvDesc* desc, int pass);
+int dram_wino_num_stat_rows(const DramConvDesc* desc);
+int dram_wino_conv3d_fwd(const float* x, const float* uf, const float* bias, float* y,
+                         float* stats_partial, const DramConvDesc* desc, void* workspace,
+                         size_t workspace_bytes, dram_stream_t stream);
+int dram_wino_conv3d_bwd_data(const float* dy, const float* ub, float* dx, const float* add,
+                              const float* gate, const DramConvDesc* desc, void* workspace,
+                              size_t workspace_bytes, dram_stream_t stream);
+int dram_wino_conv3d_bwd_weight(const float* x, const float* dy, float* dw, const DramConvDesc* desc,
+                                void* workspace, size_t workspace_bytes, dram_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
 /* Stem: Conv3d(1,64,k=7,s=2,p=3,bias=False)  (med3d.py:196-202 / :296-302).
  *   x [B,D,H,W] (C=1), w [64][1][7][7][7], y [B,Do,Ho,Wo,64], Do=(D+6-7)/2+1 ...
  *   stats_partial [dram_stem_num_tiles][2][64] or NULL. */
