@@ -623,18 +623,30 @@ extern "C" int dram_wino_applicable(const DramConvDesc* d) {
   return (wino_geom_ok(d) && wino_size_ok(d)) ? 1 : 0;
 }
 
-// Plan: Winograd where the 8x transform traffic is small next to the GEMMs (>= 256 channels on
-// one side and >= 128 on the other).  DRAM_CONV_ALGO: 0/unset auto, 1 always direct, 2 Winograd
-// wherever applicable (tests).
+// Plan: a cost model calibrated on one MI355X (rocprofv3, round 1).  The direct implicit GEMM
+// runs at ~135 TFLOP/s; the Winograd pipeline costs, per voxel of the padded tile grid, the
+// input transform (36 B x K at ~4.9 TB/s), the 64 GEMMs (16 K N flops at ~118 TFLOP/s, or their
+// 32 (K + N) B of operand traffic at ~4.7 TB/s, whichever is larger) and the output transform
+// (36 B x N at ~3.4 TB/s).  Forward and data gradient (K and N swapped) are averaged; Winograd is
+// planned when it is at least 8 % cheaper.  DRAM_CONV_ALGO: 0/unset auto, 1 always direct,
+// 2 Winograd wherever applicable (tests).
+static double wino_cost_per_voxel(double K, double N) {
+  const double gemm = 16.0 * K * N / 118e12, traffic = 32.0 * (K + N) / 4.7e12;
+  return 36.0 * K / 4.9e12 + (gemm > traffic ? gemm : traffic) + 36.0 * N / 3.4e12;
+}
+
 extern "C" int dram_conv_use_wino(const DramConvDesc* d) {
   if (!dram_wino_applicable(d)) return 0;
   const char* v = getenv("DRAM_CONV_ALGO");   // read per call: tests switch it between cases
   const int algo = v ? atoi(v) : 0;
   if (algo == 1) return 0;
   if (algo == 2) return 1;
-  const int cmin = d->Cin < d->Cout ? d->Cin : d->Cout, cmax = d->Cin < d->Cout ? d->Cout : d->Cin;
   const WinoGeom g = make_geom(d);
-  return (cmax >= 256 && cmin >= 128 && g.T >= 1024) ? 1 : 0;
+  if (g.T < 1024) return 0;
+  const double vox = (double)d->B * d->D * d->H * d->W, vpad = 8.0 * g.Tpad;
+  const double direct = vox * 54.0 * d->Cin * d->Cout / 135e12;
+  const double wino = vpad * 0.5 * (wino_cost_per_voxel(d->Cin, d->Cout) + wino_cost_per_voxel(d->Cout, d->Cin));
+  return wino < 0.92 * direct ? 1 : 0;
 }
 
 extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, int Cout, int Cin, dram_stream_t stream) {

@@ -56,7 +56,8 @@ def conv_ref(x, w, b, k, stride, dil):
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
-def test_conv3d_fwd_bwd(ops, case):
+def test_conv3d_fwd_bwd(ops, monkeypatch, case):
+    monkeypatch.setenv("DRAM_CONV_ALGO", "1")          # the direct kernels (Winograd: test_conv3d_winograd_path)
     B, D, H, W, Cin, Cout, k, stride, dil = case
     pad = dil * (k - 1) // 2
     x = rnd(B, Cin, D, H, W, seed=1).requires_grad_(True)
@@ -114,6 +115,7 @@ def test_conv3d_v3_halo_kernel_variants(ops, monkeypatch, plan, case):
     columns per workgroup), forward with fused BN statistics and data gradient with the fused
     shortcut-gradient epilogue, incl. ragged volumes and dilation lattices."""
     monkeypatch.setenv("DRAM_IGEMM_V3_FORCE", plan)
+    monkeypatch.setenv("DRAM_CONV_ALGO", "1")
     B, D, H, W, Cin, Cout, dil = case
     x = rnd(B, Cin, D, H, W, seed=1).requires_grad_(True)
     w = (rnd(Cout, Cin, 3, 3, 3, seed=2) * 0.1).requires_grad_(True)
@@ -189,9 +191,35 @@ def test_conv3d_winograd_path(ops, monkeypatch, case):
     assert rel_l2(y.cpu(), y1.cpu()) < 1e-5
 
 
-def test_conv_linearity_at_scale(ops):
+def test_winograd_linearity_at_scale(ops):
+    """BASELINE-sized layer4 conv (512->512, dilation 4 @ 2x16x32x32) on the library's own plan
+    (Winograd): linearity, a probe of one residue sub-lattice against the CPU op, and bitwise
+    reproducibility of the weight gradient (fixed-order slab sum, no atomics)."""
+    B, D, H, W, C = 2, 16, 32, 32, 512
+    g = ops.ConvGeom(B, D, H, W, C, C, 3, 1, 4, 4)
+    assert ops.conv_use_wino(g)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    x1 = torch.randn(g.in_shape, device=DEV, generator=gen)
+    x2 = torch.randn(g.in_shape, device=DEV, generator=gen)
+    w = torch.randn(C, C, 3, 3, 3, device=DEV, generator=gen) * 0.02
+    wf, _ = ops.pack_conv_weight(w, True, False, g)
+    y1, _ = ops.conv3d_fwd(x1, wf, None, g, False)
+    y2, _ = ops.conv3d_fwd(x2, wf, None, g, False)
+    y3, _ = ops.conv3d_fwd(0.5 * x1 + x2, wf, None, g, False)
+    assert rel_l2((0.5 * y1 + y2).cpu(), y3.cpu()) < 1e-5
+    # residue (1, 2, 3) of batch 0 is an ordinary dilation-1 convolution of a 4x8x8 volume
+    sub = x1[0, 1::4, 2::4, 3::4].permute(3, 0, 1, 2)[None].cpu()
+    ref = F.conv3d(sub, w.cpu(), None, 1, 1)
+    assert rel_l2(y1[0, 1::4, 2::4, 3::4].permute(3, 0, 1, 2)[None].cpu(), ref) < 1e-5
+    dw1 = ops.conv3d_bwd_weight(x1, y2, g)
+    dw2 = ops.conv3d_bwd_weight(x1, y2, g)
+    assert torch.equal(dw1, dw2)
+
+
+def test_conv_linearity_at_scale(ops, monkeypatch):
     """size-independent property at a BASELINE-sized layer (us2.1: 64->64 @ 64x128x128):
     conv(a*x1 + x2) == a*conv(x1) + conv(x2), and a checksum against a strided CPU probe."""
+    monkeypatch.setenv("DRAM_CONV_ALGO", "1")
     B, D, H, W, C = 1, 64, 128, 128, 64
     g = ops.ConvGeom(B, D, H, W, C, C, 3, 1, 1, 1)
     gen = torch.Generator(device=DEV).manual_seed(0)

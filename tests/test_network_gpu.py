@@ -54,9 +54,17 @@ def assert_close_rel(a, b, tol, what):
     assert err < tol, f"{what}: max-rel {err:.3e} >= {tol}"
 
 
-@pytest.mark.parametrize("path", NET_FILES, ids=[os.path.basename(p)[:-4] for p in NET_FILES])
-def test_train_step_matches_reference_golden(path):
+# every golden network on the library's own plan, and once more with the Winograd path forced
+# onto every 3x3x3 stride-1 convolution it supports (DRAM_CONV_ALGO=2)
+NET_RUNS = [(p, "") for p in NET_FILES] + [(p, "2") for p in NET_FILES]
+
+
+@pytest.mark.parametrize("path,algo", NET_RUNS,
+                         ids=[os.path.basename(p)[:-4] + ("-winograd" if a else "") for p, a in NET_RUNS])
+def test_train_step_matches_reference_golden(path, algo, monkeypatch):
     from bodyct_dram_emph_subtype_amd.optim import FusedAdam
+    if algo:
+        monkeypatch.setenv("DRAM_CONV_ALGO", algo)
     g = np.load(path)
     factory = str(g["factory"])
     shape = tuple(int(v) for v in g["meta"][3:])
