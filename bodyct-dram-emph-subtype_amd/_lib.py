@@ -48,9 +48,10 @@ SIGNATURES = {
     "dram_wino_pack_weight": (I, [P, P, P, I, I, P]),
     "dram_wino_workspace": (SZ, [DP, I]),
     "dram_wino_num_stat_rows": (I, [DP]),
-    "dram_wino_conv3d_fwd": (I, [P, P, P, P, P, DP, P, SZ, P]),
+    "dram_wino_v_elems": (SZ, [DP]),
+    "dram_wino_conv3d_fwd": (I, [P, P, P, P, P, P, DP, P, SZ, P]),
     "dram_wino_conv3d_bwd_data": (I, [P, P, P, P, P, DP, P, SZ, P]),
-    "dram_wino_conv3d_bwd_weight": (I, [P, P, P, DP, P, SZ, P]),
+    "dram_wino_conv3d_bwd_weight": (I, [P, P, P, P, DP, P, SZ, P]),
     "dram_stem_num_tiles": (I, [I, I, I, I]),
     "dram_stem_fwd": (I, [P, P, P, P, I, I, I, I, P]),
     "dram_stem_bwd_weight_workspace": (SZ, [I, I, I, I]),

@@ -310,10 +310,10 @@ __device__ __forceinline__ void gt3(const float a0, const float a1, const float 
   r2 = 0.5f * (a1 + a2) + a3;
 }
 
-__global__ __launch_bounds__(256) void wino_wgrad_out_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+__global__ __launch_bounds__(64) void wino_wgrad_out_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                              const int Cout, const int Cin, const int nsplit) {
   const long n = (long)Cout * Cin;
-  const long i = blockIdx.x * 256L + threadIdx.x;   // (co, ci), ci fastest
+  const long i = blockIdx.x * 64L + threadIdx.x;   // (co, ci), ci fastest
   if (i >= n) return;
   float s[4][4][4];
 #pragma unroll
@@ -442,16 +442,20 @@ __global__ __launch_bounds__(512) void wino_gemm_nn_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------
 // TN batched GEMM (weight gradient):
-//   slab[split][xi][m][n] = sum_{t in split} Ah[xi][t][m] * Bh[xi][t][n]      (M % 256 == 0)
-template <int NJ>
+//   slab[split][xi][m][n] = sum_{t in split} Ah[xi][t][m] * Bh[xi][t][n]
+// 8 waves as WMW (M) x 8/WMW (N), wave tile 32*MI x 32*NJ; M % (WMW*32*MI) == 0, N may be ragged
+// (the DMA column is clamped into the row, the extra columns are never stored).
+template <int WMW, int MI, int NJ>
 __global__ __launch_bounds__(512) void wino_gemm_tn_kernel(const float* __restrict__ Ah, const float* __restrict__ Bh,
                                                            float* __restrict__ slab, const int Tpad, const int M,
                                                            const int N, const int m_tiles, const int n_tiles,
                                                            const int nsplit, const int kper, const int nblk) {
-  constexpr int BN = 64 * NJ;
-  constexpr int STAGE = 32 * (256 + BN);
-  constexpr int BQ = BN / 4;          // 16-B slots per B row
-  constexpr int RPP = 64 / BQ;        // B rows per DMA piece
+  constexpr int WNW = 8 / WMW;
+  constexpr int BM = WMW * 32 * MI, BN = WNW * 32 * NJ;
+  static_assert(BM % 64 == 0 && BM <= 256 && BN % 64 == 0 && BN <= 256, "one DMA piece = 256 floats");
+  constexpr int STAGE = 32 * (BM + BN);
+  constexpr int AQ = BM / 4, ARPP = 64 / AQ, APW = BM / 64;   // 16-B slots per row, rows per piece, pieces per wave
+  constexpr int BQ = BN / 4, BRPP = 64 / BQ, BPW = BN / 64;
   __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
 
   const int tid = threadIdx.x;
@@ -464,71 +468,74 @@ __global__ __launch_bounds__(512) void wino_gemm_tn_kernel(const float* __restri
   const int xi = L / nsplit;
   const int t0 = split * kper;
   const int t1 = (t0 + kper < Tpad) ? t0 + kper : Tpad;
-  const float* Ab = Ah + ((long)xi * Tpad + t0) * M + mt * 256 + lane * 4;
-  const float* Bb = Bh + ((long)xi * Tpad + t0) * N + nt * BN + (lane % BQ) * 4;
-  const int brow = lane / BQ;
+  int bcol = nt * BN + (lane % BQ) * 4;
+  if (bcol > N - 4) bcol = N - 4;
+  const float* Ab = Ah + ((long)xi * Tpad + t0 + lane / AQ) * M + mt * BM + (lane % AQ) * 4;
+  const float* Bb = Bh + ((long)xi * Tpad + t0 + lane / BQ) * N + bcol;
 
   auto issue = [&](int it, int stage) __attribute__((always_inline)) {
     float* as = lds + stage * STAGE;
-    float* bs = as + 32 * 256;
+    float* bs = as + 32 * BM;
     const float* ag = Ab + (long)it * 32 * M;
     const float* bg = Bb + (long)it * 32 * N;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = 4 * wave + j;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ag + (long)row * M),
-                                       (__attribute__((address_space(3))) void*)(as + row * 256), 16, 0, 0);
+    for (int j = 0; j < APW; ++j) {
+      const int p = APW * wave + j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ag + (long)(p * ARPP) * M),
+                                       (__attribute__((address_space(3))) void*)(as + p * 256), 16, 0, 0);
     }
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-      const int p = NJ * wave + jj;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bg + (long)(p * RPP + brow) * N),
+    for (int jj = 0; jj < BPW; ++jj) {
+      const int p = BPW * wave + jj;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bg + (long)(p * BRPP) * N),
                                        (__attribute__((address_space(3))) void*)(bs + p * 256), 16, 0, 0);
     }
   };
 
-  f32x16 acc[2][NJ];
+  f32x16 acc[MI][NJ];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
 
   const int li = lane & 31, lh = lane >> 5;
-  const int wm = wave & 3, wn = wave >> 2;
+  const int wm = wave % WMW, wn = wave / WMW;
   const int niter = (t1 - t0) / 32;
 
   if (niter > 0) issue(0, 0);
   for (int it = 0; it < niter; ++it) {
     __syncthreads();
     if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
-    const float* as = lds + (it & 1) * STAGE + wm * 64 + li;
-    const float* bs = lds + (it & 1) * STAGE + 32 * 256 + wn * NJ * 32 + li;
+    const float* as = lds + (it & 1) * STAGE + wm * 32 * MI + li;
+    const float* bs = lds + (it & 1) * STAGE + 32 * BM + wn * 32 * NJ + li;
 #pragma unroll 4
     for (int kk = 0; kk < 16; ++kk) {
       const int kr = 2 * kk + lh;
-      const float a0 = as[kr * 256], a1 = as[kr * 256 + 32];
-      float bf[NJ];
+      float af[MI], bf[NJ];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[mi] = as[kr * BM + mi * 32];
 #pragma unroll
       for (int nj = 0; nj < NJ; ++nj) bf[nj] = bs[kr * BN + nj * 32];
 #pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) {
-        acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[nj], acc[0][nj], 0, 0, 0);
-        acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[nj], acc[1][nj], 0, 0, 0);
-      }
+      for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
     }
   }
 
-  float* sb = slab + (((long)split * 64 + xi) * M + mt * 256) * N + nt * BN;
+  float* sb = slab + (((long)split * 64 + xi) * M + mt * BM) * N + nt * BN;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-      float* o = sb + (long)row * N + wn * NJ * 32 + li;
+      const int row = wm * 32 * MI + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      float* o = sb + (long)row * N + wn * 32 * NJ + li;
 #pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) o[nj * 32] = acc[mi][nj][e];
+      for (int nj = 0; nj < NJ; ++nj)
+        if (nt * BN + wn * 32 * NJ + nj * 32 + li < N) o[nj * 32] = acc[mi][nj][e];
     }
 }
 
@@ -563,13 +570,23 @@ bool wino_size_ok(const DramConvDesc* d) {   // int32 offsets inside one xi plan
 
 int nj_for(int N) { return N % 256 == 0 ? 4 : (N % 128 == 0 ? 2 : 1); }
 
-// wgrad: M = Cout (tile 256), N = Cin; split over t so that >= ~512 workgroups are in flight
-struct TnPlan { int nj, m_tiles, n_tiles, nsplit, kper; };
+// wgrad: M = Cout, N = Cin.  Tile = the largest (BM, BN) that divides M and wastes < 13 % of N;
+// split over t so that >= ~512 workgroups are in flight.
+struct TnPlan { int bm, bn, m_tiles, n_tiles, nsplit, kper; };
 bool plan_tn(const DramConvDesc* d, const WinoGeom& g, TnPlan& p) {
-  if (d->Cout % 256 != 0) return false;
-  p.nj = nj_for(d->Cin);
-  p.m_tiles = d->Cout / 256;
-  p.n_tiles = d->Cin / (64 * p.nj);
+  const int M = d->Cout, N = d->Cin;
+  p.bm = M % 256 == 0 ? 256 : (M % 128 == 0 ? 128 : 64);
+  const int ncand = p.bm == 256 ? 3 : 2;             // 64-column tiles only exist for BM = 256
+  const int cand[3] = {256, 128, 64};
+  p.bn = 0;
+  int best_pad = 1 << 30;
+  for (int i = 0; i < ncand; ++i) {
+    const int padded = (N + cand[i] - 1) / cand[i] * cand[i];
+    if (padded * 100 <= N * 113) { p.bn = cand[i]; break; }
+    if (padded < best_pad) { best_pad = padded; p.bn = cand[i]; }
+  }
+  p.m_tiles = M / p.bm;
+  p.n_tiles = (N + p.bn - 1) / p.bn;
   const int base = 64 * p.m_tiles * p.n_tiles;
   const int k32 = g.Tpad / 32;
   int ns = 1;
@@ -600,12 +617,13 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
 
 // shared by forward (x, uf) and data gradient (dy, ub): in[..., K] -> out[..., N]
 int run_conv(const float* in, const float* U, const float* bias, const float* add, const float* gate, float* out,
-             float* stats, const DramConvDesc* d, int K, int N, void* ws, size_t ws_bytes, hipStream_t s) {
+             float* stats, float* v_keep, const DramConvDesc* d, int K, int N, void* ws, size_t ws_bytes,
+             hipStream_t s) {
   const WinoGeom g = make_geom(d);
   const size_t need = (size_t)64 * g.Tpad * ((size_t)K + N) * sizeof(float);
   if (!ws || ws_bytes < need) return DRAM_ERR_WORKSPACE;
-  float* V = (float*)ws;
-  float* Mh = V + (size_t)64 * g.Tpad * K;
+  float* V = v_keep ? v_keep : (float*)ws;          // kept for the weight gradient when the caller asks
+  float* Mh = (float*)ws + (size_t)64 * g.Tpad * K;
   hipLaunchKernelGGL((wino_in_kernel<0>), dim3(grid_for((long)g.Tpad * (K / 64))), dim3(256), 0, s, in, V, g, K);
   DRAM_LAUNCH_CHECK();
   const int rc = run_nn(V, U, Mh, g, N, K, s);
@@ -678,12 +696,17 @@ extern "C" size_t dram_wino_workspace(const DramConvDesc* d, int pass) {
 }
 
 extern "C" int dram_wino_conv3d_fwd(const float* x, const float* uf, const float* bias, float* y, float* stats_partial,
-                                    const DramConvDesc* d, void* workspace, size_t workspace_bytes,
+                                    float* v_keep, const DramConvDesc* d, void* workspace, size_t workspace_bytes,
                                     dram_stream_t stream) {
   if (!x || !uf || !y) return DRAM_ERR_BAD_ARG;
   if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
-  return run_conv(x, uf, bias, nullptr, nullptr, y, stats_partial, d, d->Cin, d->Cout, workspace, workspace_bytes,
-                  (hipStream_t)stream);
+  return run_conv(x, uf, bias, nullptr, nullptr, y, stats_partial, v_keep, d, d->Cin, d->Cout, workspace,
+                  workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t dram_wino_v_elems(const DramConvDesc* d) {
+  if (!dram_wino_applicable(d)) return 0;
+  return (size_t)64 * make_geom(d).Tpad * (size_t)d->Cin;
 }
 
 extern "C" int dram_wino_conv3d_bwd_data(const float* dy, const float* ub, float* dx, const float* add,
@@ -691,13 +714,14 @@ extern "C" int dram_wino_conv3d_bwd_data(const float* dy, const float* ub, float
                                          size_t workspace_bytes, dram_stream_t stream) {
   if (!dy || !ub || !dx || (gate && !add)) return DRAM_ERR_BAD_ARG;
   if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
-  return run_conv(dy, ub, nullptr, add, gate, dx, nullptr, d, d->Cout, d->Cin, workspace, workspace_bytes,
+  return run_conv(dy, ub, nullptr, add, gate, dx, nullptr, nullptr, d, d->Cout, d->Cin, workspace, workspace_bytes,
                   (hipStream_t)stream);
 }
 
-extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* dy, float* dw, const DramConvDesc* d,
-                                           void* workspace, size_t workspace_bytes, dram_stream_t stream) {
-  if (!x || !dy || !dw) return DRAM_ERR_BAD_ARG;
+extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache, const float* dy, float* dw,
+                                           const DramConvDesc* d, void* workspace, size_t workspace_bytes,
+                                           dram_stream_t stream) {
+  if ((!x && !v_cache) || !dy || !dw) return DRAM_ERR_BAD_ARG;
   if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
   const WinoGeom g = make_geom(d);
   TnPlan p;
@@ -708,23 +732,31 @@ extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* dy, floa
   float* V = (float*)workspace;                               // [64][Tpad][Cin]
   float* Dh = V + (size_t)64 * g.Tpad * d->Cin;               // [64][Tpad][Cout]
   float* slab = Dh + (size_t)64 * g.Tpad * d->Cout;           // [nsplit][64][Cout][Cin]
-  hipLaunchKernelGGL((wino_in_kernel<0>), dim3(grid_for((long)g.Tpad * (d->Cin / 64))), dim3(256), 0, s, x, V, g,
-                     d->Cin);
-  DRAM_LAUNCH_CHECK();
+  if (v_cache) V = const_cast<float*>(v_cache);
+  else {
+    hipLaunchKernelGGL((wino_in_kernel<0>), dim3(grid_for((long)g.Tpad * (d->Cin / 64))), dim3(256), 0, s, x, V, g,
+                       d->Cin);
+    DRAM_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL((wino_in_kernel<1>), dim3(grid_for((long)g.Tpad * (d->Cout / 64))), dim3(256), 0, s, dy, Dh, g,
                      d->Cout);
   DRAM_LAUNCH_CHECK();
   const int nblk = 64 * p.nsplit * p.m_tiles * p.n_tiles;
-#define WTN(NJ_)                                                                                                  \
-  hipLaunchKernelGGL((wino_gemm_tn_kernel<NJ_>), dim3(nblk), dim3(512), 0, s, Dh, V, slab, g.Tpad, d->Cout, d->Cin, \
-                     p.m_tiles, p.n_tiles, p.nsplit, p.kper, nblk)
-  if (p.nj == 4) WTN(4);
-  else if (p.nj == 2) WTN(2);
-  else WTN(1);
+#define WTN(WM_, MI_, NJ_)                                                                                       \
+  hipLaunchKernelGGL((wino_gemm_tn_kernel<WM_, MI_, NJ_>), dim3(nblk), dim3(512), 0, s, Dh, V, slab, g.Tpad, d->Cout, \
+                     d->Cin, p.m_tiles, p.n_tiles, p.nsplit, p.kper, nblk)
+  if (p.bm == 256 && p.bn == 256) WTN(4, 2, 4);
+  else if (p.bm == 256 && p.bn == 128) WTN(4, 2, 2);
+  else if (p.bm == 256 && p.bn == 64) WTN(4, 2, 1);
+  else if (p.bm == 128 && p.bn == 256) WTN(2, 2, 2);
+  else if (p.bm == 128 && p.bn == 128) WTN(2, 2, 1);
+  else if (p.bm == 64 && p.bn == 256) WTN(2, 1, 2);
+  else if (p.bm == 64 && p.bn == 128) WTN(2, 1, 1);
+  else return DRAM_ERR_UNSUPPORTED;
 #undef WTN
   DRAM_LAUNCH_CHECK();
   const long n = (long)d->Cout * d->Cin;
-  hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slab, dw, d->Cout,
+  hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, slab, dw, d->Cout,
                      d->Cin, p.nsplit);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;

@@ -93,16 +93,17 @@ class Engine:
         B, D, H, W, Cin = x.shape
         g = ConvGeom(B, D, H, W, Cin, w.shape[0], k, stride, pad, dil)
         wf, wb = ops.pack_conv_weight(w, True, st.need_grad, g)
-        y, sp = ops.conv3d_fwd(x, wf, st.P[bname] if bname else None, g, st.training)
+        y, sp, v = ops.conv3d_fwd_keep(x, wf, st.P[bname] if bname else None, g, st.training, st.need_grad)
         z, mean, invstd, count = self._bn_fwd(st, y, sp, bnp, residual, rs)
         c = None
         if st.need_grad:
-            c = dict(x=x, y=y, z=z, mean=mean, invstd=invstd, g=g, wb=wb, count=count, w=wname, b=bname, bn=bnp)
+            c = dict(x=x, y=y, z=z, mean=mean, invstd=invstd, g=g, wb=wb, count=count, w=wname, b=bname, bn=bnp, v=v)
         return z, c
 
     def _conv_bn_bwd(self, st: _State, c: dict, dz: Tensor, need_dx=True, add=None, gate=None):
         dy = self._bn_bwd(st, c, dz)
-        st.grads[c["w"]] = ops.conv3d_bwd_weight(c["x"], dy, c["g"])
+        st.grads[c["w"]] = ops.conv3d_bwd_weight(c["x"], dy, c["g"], v_cache=c.get("v"))
+        c["v"] = None                                   # release the cached Winograd-domain input
         if c["b"]:
             st.grads[c["b"]] = ops.reduce_partials(ops.colsum(dy))[0].float()
         self._grad_ready(st, c)

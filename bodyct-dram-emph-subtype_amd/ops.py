@@ -209,6 +209,13 @@ def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True, g: Optional["ConvG
 
 
 def conv3d_fwd(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, want_stats: bool):
+    y, stats, _ = conv3d_fwd_keep(x, wf, bias, g, want_stats, False)
+    return y, stats
+
+
+def conv3d_fwd_keep(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, want_stats: bool, keep: bool):
+    """Forward conv; with keep=True on the Winograd path also returns the transformed input V
+    (reused by conv3d_bwd_weight instead of transforming x again), else None."""
     _req(x, "x", shape=g.in_shape)
     wino = conv_use_wino(g)
     _req(wf, "wf", shape=(64 if wino else g.taps, g.Cout, g.Cin))
@@ -225,14 +232,17 @@ def conv3d_fwd(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, want_
     if wino:
         nbytes = _L().dram_wino_workspace(ctypes.byref(d), 0)
         ws = _workspace(nbytes, x.device)
+        v = None
+        if keep:
+            v = torch.empty((_L().dram_wino_v_elems(ctypes.byref(d)),), device=x.device, dtype=torch.float32)
         with _span("conv_wino_kernels", g.flops, f"fwd {g}"):
-            _chk(_L().dram_wino_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), ctypes.byref(d), _p(ws), nbytes,
-                                           _stream()), f"dram_wino_conv3d_fwd{g}")
-        return y, stats
+            _chk(_L().dram_wino_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), _p(v), ctypes.byref(d), _p(ws),
+                                           nbytes, _stream()), f"dram_wino_conv3d_fwd{g}")
+        return y, stats, v
     with _span("conv_igemm_kernel", g.flops, f"fwd {g}"):
         _chk(_L().dram_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), ctypes.byref(d), _stream()),
              f"dram_conv3d_fwd{g}")
-    return y, stats
+    return y, stats, None
 
 
 def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] = None,
@@ -259,7 +269,8 @@ def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] =
     return dx
 
 
-def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] = None) -> Tensor:
+def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] = None,
+                      v_cache: Optional[Tensor] = None) -> Tensor:
     _req(x, "x", shape=g.in_shape)
     _req(dy, "dy", shape=g.out_shape)
     d = g.desc()
@@ -270,9 +281,11 @@ def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] 
         nbytes = _L().dram_wino_workspace(ctypes.byref(d), 2)
         if nbytes:                                   # 0: this geometry's weight gradient stays on the direct path
             ws = _workspace(nbytes, x.device)
+            if v_cache is not None:
+                _req(v_cache, "v_cache", shape=(_L().dram_wino_v_elems(ctypes.byref(d)),))
             with _span("conv_wino_kernels", g.flops, f"wgrad {g}"):
-                _chk(_L().dram_wino_conv3d_bwd_weight(_p(x), _p(dy), _p(dw), ctypes.byref(d), _p(ws), nbytes,
-                                                      _stream()), f"dram_wino_conv3d_bwd_weight{g}")
+                _chk(_L().dram_wino_conv3d_bwd_weight(_p(x), _p(v_cache), _p(dy), _p(dw), ctypes.byref(d), _p(ws),
+                                                      nbytes, _stream()), f"dram_wino_conv3d_bwd_weight{g}")
             return dw
     nbytes = _L().dram_conv3d_bwd_weight_workspace(ctypes.byref(d))
     if nbytes == 0:

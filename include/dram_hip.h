@@ -96,20 +96,25 @@ int dram_conv_num_mtiles(const DramConvDesc* desc);
  *   dram_wino_workspace(desc, pass): bytes for pass 0 forward, 1 data gradient, 2 weight
  *                         gradient (0 when unsupported).
  *   dram_wino_num_stat_rows: rows of stats_partial written by dram_wino_conv3d_fwd.
+ *   v_keep / v_cache: optional [dram_wino_v_elems(desc)] floats; the forward pass leaves the
+ *                         transformed input there and the weight gradient reuses it instead of
+ *                         transforming x again (x may then be NULL).
  * Deterministic (no atomics; the weight gradient sums its slabs in a fixed order). */
 int dram_wino_applicable(const DramConvDesc* desc);
 int dram_conv_use_wino(const DramConvDesc* desc);
 int dram_wino_pack_weight(const float* w, float* uf, float* ub, int Cout, int Cin, dram_stream_t stream);
 size_t dram_wino_workspace(const DramConvDesc* desc, int pass);
 int dram_wino_num_stat_rows(const DramConvDesc* desc);
+size_t dram_wino_v_elems(const DramConvDesc* desc);
 int dram_wino_conv3d_fwd(const float* x, const float* uf, const float* bias, float* y,
-                         float* stats_partial, const DramConvDesc* desc, void* workspace,
+                         float* stats_partial, float* v_keep, const DramConvDesc* desc, void* workspace,
                          size_t workspace_bytes, dram_stream_t stream);
 int dram_wino_conv3d_bwd_data(const float* dy, const float* ub, float* dx, const float* add,
                               const float* gate, const DramConvDesc* desc, void* workspace,
                               size_t workspace_bytes, dram_stream_t stream);
-int dram_wino_conv3d_bwd_weight(const float* x, const float* dy, float* dw, const DramConvDesc* desc,
-                                void* workspace, size_t workspace_bytes, dram_stream_t stream);
+int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache, const float* dy, float* dw,
+                                const DramConvDesc* desc, void* workspace, size_t workspace_bytes,
+                                dram_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* Stem: Conv3d(1,64,k=7,s=2,p=3,bias=False)  (med3d.py:196-202 / :296-302).

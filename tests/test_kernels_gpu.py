@@ -182,8 +182,12 @@ def test_conv3d_winograd_path(ops, monkeypatch, case):
     assert rel_l2(to_ncdhw(dx), gx_ref) < 1e-5
     dx2 = ops.conv3d_bwd_data(gyd, wb, g, to_ndhwc(add), to_ndhwc(gate))
     assert rel_l2(to_ncdhw(dx2), gx_ref + add * (gate > 0).float()) < 1e-5
-    dw = ops.conv3d_bwd_weight(xd, gyd, g)       # Cout % 256 != 0 falls back to the direct kernel
+    dw = ops.conv3d_bwd_weight(xd, gyd, g)
     assert rel_l2(dw.cpu(), gw_ref) < 2e-5
+    # the forward pass can hand its transformed input to the weight gradient (bitwise same result)
+    y_k, _, v = ops.conv3d_fwd_keep(xd, wf, bias.to(DEV), g, False, True)
+    assert v is not None and torch.equal(y_k, y)
+    assert torch.equal(ops.conv3d_bwd_weight(xd, gyd, g, v_cache=v), dw)
     # the direct path on the same inputs (plan switched off) agrees with the Winograd result
     monkeypatch.setenv("DRAM_CONV_ALGO", "1")
     wf1, _ = ops.pack_conv_weight(w.detach().to(DEV), True, False, g)
