@@ -43,6 +43,12 @@ SIGNATURES = {
     "dram_conv3d_bwd_weight_workspace": (SZ, [DP]),
     "dram_conv3d_bwd_weight": (I, [P, P, P, DP, P, SZ, P]),
     "dram_conv_num_mtiles": (I, [DP]),
+    "dram_conv_algo": (I, [DP]),
+    "dram_wino2d_applicable": (I, [DP]),
+    "dram_wino2d_num_stat_rows": (I, [DP]),
+    "dram_wino2d_pack_weight": (I, [P, P, P, I, I, P]),
+    "dram_wino2d_conv3d_fwd": (I, [P, P, P, P, P, DP, P]),
+    "dram_wino2d_conv3d_bwd_data": (I, [P, P, P, P, P, DP, P]),
     "dram_wino_applicable": (I, [DP]),
     "dram_conv_use_wino": (I, [DP]),
     "dram_wino_pack_weight": (I, [P, P, P, I, I, P]),

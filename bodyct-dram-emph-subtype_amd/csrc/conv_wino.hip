@@ -653,19 +653,38 @@ static double wino_cost_per_voxel(double K, double N) {
   return 36.0 * K / 4.9e12 + (gemm > traffic ? gemm : traffic) + 36.0 * N / 3.4e12;
 }
 
-extern "C" int dram_conv_use_wino(const DramConvDesc* d) {
-  if (!dram_wino_applicable(d)) return 0;
+extern "C" int dram_conv_algo(const DramConvDesc* d) {
   const char* v = getenv("DRAM_CONV_ALGO");   // read per call: tests switch it between cases
   const int algo = v ? atoi(v) : 0;
   if (algo == 1) return 0;
-  if (algo == 2) return 1;
-  const WinoGeom g = make_geom(d);
-  if (g.T < 1024) return 0;
-  const double vox = (double)d->B * d->D * d->H * d->W, vpad = 8.0 * g.Tpad;
-  const double direct = vox * 54.0 * d->Cin * d->Cout / 135e12;
-  const double wino = vpad * 0.5 * (wino_cost_per_voxel(d->Cin, d->Cout) + wino_cost_per_voxel(d->Cout, d->Cin));
-  return wino < 0.92 * direct ? 1 : 0;
+  const bool w3 = dram_wino_applicable(d) != 0, w2 = dram_wino2d_applicable(d) != 0;
+  if (algo == 2) return w3 ? 1 : 0;
+  if (algo == 3) return w2 ? 2 : 0;
+  const double vox = d ? (double)d->B * d->D * d->H * d->W : 0.0;
+  double best = 1e30;
+  int pick = 0;
+  if (w3) {
+    const WinoGeom g = make_geom(d);
+    if (g.T >= 1024) {
+      const double vpad = 8.0 * g.Tpad;
+      const double direct = vox * 54.0 * d->Cin * d->Cout / 135e12;
+      const double wino = vpad * 0.5 * (wino_cost_per_voxel(d->Cin, d->Cout) + wino_cost_per_voxel(d->Cout, d->Cin));
+      if (wino < 0.92 * direct) { best = wino; pick = 1; }
+    }
+  }
+  if (w2 && d->D >= 12 && vox >= 65536.0) {
+    // fused in-plane Winograd: measured ~200 TFLOP/s of direct-conv-equivalent work with 64-column
+    // tiles, ~155 with 32-column tiles (forward writes Cout columns, data gradient Cin columns)
+    const int zt = (d->D + 15) / 16 * 16;
+    const double rf = d->Cout % 64 == 0 ? 200e12 : 155e12, rb = d->Cin % 64 == 0 ? 200e12 : 155e12;
+    const double w2d = vox * zt / d->D * 54.0 * d->Cin * d->Cout * 0.5 * (1.0 / rf + 1.0 / rb);
+    const double direct = vox * 54.0 * d->Cin * d->Cout / 135e12;
+    if (w2d < 0.92 * direct && w2d < best) { best = w2d; pick = 2; }
+  }
+  return pick;
 }
+
+extern "C" int dram_conv_use_wino(const DramConvDesc* d) { return dram_conv_algo(d) == 1 ? 1 : 0; }
 
 extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, int Cout, int Cin, dram_stream_t stream) {
   if (!w || (!uf && !ub) || Cout < 1 || Cin < 1) return DRAM_ERR_BAD_ARG;

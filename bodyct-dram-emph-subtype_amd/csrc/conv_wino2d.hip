@@ -1,0 +1,396 @@
+// conv_wino2d.hip -- fused in-plane Winograd F(2x2, 3x3) x direct-z convolution for the narrow
+// (<= 128-channel) stride-1 3x3x3 layers on large volumes: forward and data gradient in ONE
+// kernel, no Winograd-domain tensor in HBM.
+//
+// Same call sites as conv_igemm.hip (reference med3d.py:91-100 conv3x3x3 in layer1 and
+// med3d.py:67/:76 decoder convs; autograd's convolution_backward (input)).  The non-fused 3-D
+// Winograd path (conv_wino.hip) moves 8x the activation bytes through HBM, which only pays for
+// >= 128-channel layers; here the transforms live in registers/LDS:
+//   * workgroup = 8 waves, output tile 16(z) x 8 x 8 voxels x BN channels; per 16-channel chunk the
+//     18x10x10 input halo (1800 rows x 64 B) is DMA'd into LDS once (as in conv_igemm3_kernel);
+//   * a wave owns 2 z-planes x (4x4) in-plane 2x2 tiles = 32 MFMA rows.  For each of the 16
+//     in-plane Winograd points xi = (xi_y, xi_x) and each z-tap a, the A fragment
+//     (B^T v B)[xi] = +-v[p0][q0] +- v[p0][q1] +- v[p1][q0] +- v[p1][q1] is formed on the fly from
+//     four ds_read_b128 of the raw halo (every row of B^T has two non-zeros);
+//   * the products of one xi (3 z-taps x 16 channels) are summed in a scratch accumulator that
+//     starts from 0, then added with the +-1 coefficients of A^T into the four OUTPUT accumulators
+//     (y, x parity) -- so a wave keeps 4 output + 1 scratch accumulators per 32 columns instead of
+//     16, and the output transform costs VALU adds in the shadow of the MFMAs;
+//   * transformed weights U2[xi][a][n][k] = (G w_a G^T)[xi] are streamed per xi, double-buffered.
+// MFMA work: 16 x 3 = 48 instead of 4 x 27 = 108 products per 2x2 tile -> 2.25x fewer.
+// LDS images are raw 64-B rows; bank conflicts are removed by placing voxel row r at
+// r ^ ((y_halo >> 1) & 1) and XOR-ing the 16-B slot with (x_halo >> 1) & 3 (weights:
+// (n >> 1) & 3), applied on the DMA source side and on the reads.
+// The data gradient is the same kernel on dy with the tap-flipped, transposed weights.
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+constexpr int W2_TZ = 16;                               // tile depth
+constexpr int W2_HROWS = (W2_TZ + 2) * 10 * 10;         // 1800 halo voxels
+constexpr int W2_NPIECE = (W2_HROWS + 15) / 16;         // DMA pieces of 16 rows x 64 B
+constexpr int W2_HQ = (W2_NPIECE + 7) / 8;              // pieces per wave
+constexpr int W2_HALO = W2_NPIECE * 256;                // floats
+constexpr int W2_BK = 16;                               // channels per chunk
+
+struct W2dGeom {
+  int B, D, H, W;      // voxel grid (input == output grid)
+  int Ci, No;          // gathered channels (K), written channels (N)
+  int nz, ny, nx, tiles_per_b, n_tiles, nblk;
+};
+
+__device__ __attribute__((aligned(16))) float g_w2d_zero[4];
+
+// B^T rows: two non-zeros each -> (position, sign) pairs
+__device__ constexpr int kBP[4][2] = {{0, 2}, {1, 2}, {1, 2}, {1, 3}};
+__device__ constexpr float kBS[4][2] = {{1.f, -1.f}, {1.f, 1.f}, {-1.f, 1.f}, {1.f, -1.f}};
+// A^T = [1 1 1 0; 0 1 -1 -1]
+__device__ constexpr float kAT[2][4] = {{1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, -1.f}};
+
+// address of the second k-group: slot ^ 2, i.e. float index ^ 8 -- as an opaque VALU op at the use
+// site, so that the compiler does not keep a second copy of every address in registers
+__device__ __forceinline__ int kx(int off, int gk) {
+  if (gk == 0) return off;
+  int r;
+  asm volatile("v_xor_b32 %0, 8, %1" : "=v"(r) : "v"(off));
+  return r;
+}
+
+template <int NJ>
+__global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restrict__ in, const float* __restrict__ u2,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          float* __restrict__ stats, const float* __restrict__ add,
+                                                          const float* __restrict__ gate, const W2dGeom g) {
+  constexpr int BN = 32 * NJ;
+  constexpr int BROWS = 3 * BN;             // weight rows per xi: (z-tap, n)
+  constexpr int BST = BROWS * 16;           // floats per weight stage
+  constexpr int BPIECE = BROWS / 16;        // 6 * NJ DMA pieces
+  constexpr int PB = (BPIECE + 7) / 8;
+  __shared__ __attribute__((aligned(1024))) float lds[W2_HALO + 2 * BST];
+  __shared__ int htab[W2_NPIECE * 16];
+  float* halo = lds;
+  float* bst = lds + W2_HALO;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int L = xcd_remap(blockIdx.x, g.nblk);
+  const int n_tile = L % g.n_tiles;
+  const int mt = L / g.n_tiles;
+  const int b = mt / g.tiles_per_b;
+  int r = mt - b * g.tiles_per_b;
+  const int txi = r % g.nx; r /= g.nx;
+  const int tyi = r % g.ny;
+  const int tzi = r / g.ny;
+  const int n0 = n_tile * BN;
+  const int z0 = tzi * W2_TZ, y0 = tyi * 8, x0 = txi * 8;
+
+  // ---- halo DMA: piece p = wave + 8q, this lane feeds LDS row 16p + (lane >> 2), slot lane & 3.
+  // The (row -> source voxel) map is built once per workgroup into a small LDS table: element
+  // offset of the voxel at channel 0 with the slot swizzle (x_halo >> 1) & 3 in its two low bits
+  // (offsets are multiples of Ci >= 16), or -1 for rows outside the volume.
+  const int pslot = lane & 3;
+  for (int rp = tid; rp < W2_NPIECE * 16; rp += 512) {
+    const int yh = (rp / 10) % 10;
+    const int rl = rp ^ ((yh >> 1) & 1);                      // logical row = (zh*10 + yh)*10 + xh
+    const int zh = rl / 100, xh = rl % 10;
+    const int zi = z0 + zh - 1, yi = y0 + yh - 1, xi = x0 + xh - 1;
+    const bool v = (rp < W2_HROWS) & (zi >= 0) & (zi < g.D) & (yi >= 0) & (yi < g.H) & (xi >= 0) & (xi < g.W);
+    htab[rp] = v ? ((((b * g.D + zi) * g.H + yi) * g.W + xi) * g.Ci) | ((xh >> 1) & 3) : -1;
+  }
+  // weight pieces: piece pb = wave + 8j covers rows 16*pb .. +15 of the (3 x BN)-row tile
+  int boff[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    int row = 16 * (wave + 8 * j) + (lane >> 2);
+    if (row >= BROWS) row = 0;
+    const int a = row / BN, n = row - a * BN;
+    boff[j] = (a * g.No + n0 + n) * g.Ci + (pslot ^ ((n >> 1) & 3)) * 4;
+  }
+  const long xi_stride = 3L * g.No * g.Ci;
+
+  auto issue_halo = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < W2_HQ; ++q) {
+      if (wave + 8 * q < W2_NPIECE) {   // wave-uniform
+        const int ho = htab[16 * (wave + 8 * q) + (lane >> 2)];
+        const float* src = ho >= 0 ? in + (long)((ho & ~3) + ((pslot ^ (ho & 3)) << 2) + c * W2_BK) : g_w2d_zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(halo + (wave + 8 * q) * 256), 16, 0,
+                                         0);
+      }
+    }
+  };
+  auto issue_b = [&](int c, int xi, int stage) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      if (wave + 8 * j < BPIECE) {      // wave-uniform
+        const float* src = u2 + xi * xi_stride + c * W2_BK + boff[j];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(bst + stage * BST + (wave + 8 * j) * 256),
+                                         16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 yacc[2][2][NJ];
+#pragma unroll
+  for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+    for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) yacc[oy][ox][nj][e] = 0.f;
+
+  // ---- per-lane read addresses (floats) of the 4x4 raw positions of this lane's 2x2 tile -------
+  const int li = lane & 31, lh = lane >> 5;
+  const int zl = li >> 4, ty = (li >> 2) & 3, tx = li & 3;
+  int abase[4][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int yh = 2 * ty + p, xh = 2 * tx + q;
+      const int rl = ((2 * wave + zl) * 10 + yh) * 10 + xh;
+      abase[p][q] = (rl ^ ((yh >> 1) & 1)) * 16 + ((lh ^ ((xh >> 1) & 3)) * 4);
+    }
+  const int bbase = li * 16 + ((lh ^ ((li >> 1) & 3)) * 4);
+  const int nchunk = g.Ci / W2_BK;
+
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();                    // every wave is done with the previous chunk's halo and weights
+    issue_halo(c);
+    issue_b(c, 0, 0);
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+      __syncthreads();                  // weights of xi (and, at xi = 0, the halo) have landed
+      if (xi + 1 < 16) issue_b(c, xi + 1, (xi + 1) & 1);
+      const int xy = xi >> 2, xx = xi & 3;
+      const int p0 = kBP[xy][0], p1 = kBP[xy][1], q0 = kBP[xx][0], q1 = kBP[xx][1];
+      const float s00 = kBS[xy][0] * kBS[xx][0], s01 = kBS[xy][0] * kBS[xx][1];
+      const float s10 = kBS[xy][1] * kBS[xx][0], s11 = kBS[xy][1] * kBS[xx][1];
+      const float* bs = bst + (xi & 1) * BST;
+      f32x16 t[NJ];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int gk = 0; gk < 2; ++gk) {
+          const f32x4 r00 = *reinterpret_cast<const f32x4*>(halo + kx(abase[p0][q0], gk) + a * 1600);
+          const f32x4 r01 = *reinterpret_cast<const f32x4*>(halo + kx(abase[p0][q1], gk) + a * 1600);
+          const f32x4 r10 = *reinterpret_cast<const f32x4*>(halo + kx(abase[p1][q0], gk) + a * 1600);
+          const f32x4 r11 = *reinterpret_cast<const f32x4*>(halo + kx(abase[p1][q1], gk) + a * 1600);
+          const f32x4 av = (s00 * r00 + s01 * r01) + (s10 * r10 + s11 * r11);
+          f32x4 bf[NJ];
+#pragma unroll
+          for (int nj = 0; nj < NJ; ++nj)
+            bf[nj] = *reinterpret_cast<const f32x4*>(bs + (a * BN + nj * 32) * 16 + kx(bbase, gk));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) {
+              if (a == 0 && gk == 0 && e == 0) {
+                f32x16 zero;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+                t[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bf[nj][e], zero, 0, 0, 0);
+              } else {
+                t[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bf[nj][e], t[nj], 0, 0, 0);
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);   // keep one (tap, k-group)'s operands live at a time
+        }
+      }
+      // output transform on the fly: y[oy][ox] += A^T[oy][xi_y] * A^T[ox][xi_x] * t
+#pragma unroll
+      for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox) {
+          const float cf = kAT[oy][xy] * kAT[ox][xx];
+          if (cf != 0.f) {
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) {
+              if (cf > 0.f) yacc[oy][ox][nj] += t[nj];
+              else yacc[oy][ox][nj] -= t[nj];
+              asm volatile("" : "+v"(yacc[oy][ox][nj]));   // pin the add here (else it is sunk past 15 more xi, t spilled)
+            }
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);   // the adds stay here, in the shadow of this xi's last MFMAs
+    }
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------
+  int lhe = lh, lie = li;
+  asm volatile("" : "+v"(lhe), "+v"(lie));   // opaque: the epilogue's address math is not hoisted above the main loop
+  float s1[NJ], s2[NJ], bv[NJ];
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj) {
+    s1[nj] = 0.f;
+    s2[nj] = 0.f;
+    bv[nj] = bias ? bias[n0 + nj * 32 + lie] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = (e & 3) + 8 * (e >> 2) + 4 * lhe;         // 0..31: (zl, ty, tx)
+    const int zo = z0 + 2 * wave + (row >> 4);
+    const int yb = y0 + 2 * ((row >> 2) & 3), xb = x0 + 2 * (row & 3);
+#pragma unroll
+    for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+      for (int ox = 0; ox < 2; ++ox) {
+        const int yo = yb + oy, xo = xb + ox;
+        if ((zo < g.D) & (yo < g.H) & (xo < g.W)) {
+          const long o = ((((long)b * g.D + zo) * g.H + yo) * g.W + xo) * g.No + n0 + lie;
+#pragma unroll
+          for (int nj = 0; nj < NJ; ++nj) {
+            float v = yacc[oy][ox][nj][e] + bv[nj];
+            if (add) {
+              const float av = add[o + nj * 32];
+              v += gate ? (gate[o + nj * 32] > 0.f ? av : 0.f) : av;
+            }
+            out[o + nj * 32] = v;
+            s1[nj] += v;
+            s2[nj] += v * v;
+          }
+        }
+      }
+  }
+  if (stats) {
+    __syncthreads();
+    float* red = lds;  // [8 waves][2][BN]
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+      const float t1 = s1[nj] + __shfl_xor(s1[nj], 32, 64);
+      const float t2 = s2[nj] + __shfl_xor(s2[nj], 32, 64);
+      if (lhe == 0) {
+        red[(wave * 2 + 0) * BN + nj * 32 + lie] = t1;
+        red[(wave * 2 + 1) * BN + nj * 32 + lie] = t2;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, cc = tid - which * BN;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += red[(w * 2 + which) * BN + cc];
+      stats[((long)mt * 2 + which) * g.No + n0 + cc] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// U2[xi][a][n][k] = (G w_a G^T)[xi], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+//   blockIdx.y == 0: forward operand   n = co, k = ci
+//   blockIdx.y == 1: data-gradient operand n = ci, k = co, all three tap axes flipped
+__device__ __forceinline__ void g4_2d(const float a0, const float a1, const float a2, float* r) {
+  const float h = 0.5f * (a0 + a2);
+  r[0] = a0;
+  r[1] = h + 0.5f * a1;
+  r[2] = h - 0.5f * a1;
+  r[3] = a2;
+}
+
+__global__ __launch_bounds__(256) void wino2d_weight_kernel(const float* __restrict__ w, float* __restrict__ uf,
+                                                            float* __restrict__ ub, const int Cout, const int Cin) {
+  const bool bwd = blockIdx.y == 1;
+  float* dst = bwd ? ub : uf;
+  if (!dst) return;
+  const long n = (long)Cout * Cin;
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= n) return;
+  int co, ci;
+  if (!bwd) { ci = (int)(i % Cin); co = (int)(i / Cin); }
+  else { co = (int)(i % Cout); ci = (int)(i / Cout); }
+  const float* src = w + ((long)co * Cin + ci) * 27;
+  float gw[3][3][3];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) (&gw[0][0][0])[t] = src[bwd ? 26 - t : t];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float p[3][4], u[4][4];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) g4_2d(gw[a][ky][0], gw[a][ky][1], gw[a][ky][2], p[ky]);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      float col[4];
+      g4_2d(p[0][x], p[1][x], p[2][x], col);
+#pragma unroll
+      for (int y = 0; y < 4; ++y) u[y][x] = col[y];
+    }
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) dst[((long)xi * 3 + a) * n + i] = u[xi >> 2][xi & 3];
+  }
+}
+
+bool w2d_ok(const DramConvDesc* d, int K, int N) {
+  if (!d) return false;
+  if (d->B < 1 || d->D < 1 || d->H < 1 || d->W < 1) return false;
+  if (d->k != 3 || d->stride != 1 || d->dil != 1 || d->pad != 1) return false;
+  if (d->Do != d->D || d->Ho != d->H || d->Wo != d->W) return false;
+  if (K < 16 || K % 16 != 0 || N < 32 || N % 32 != 0) return false;
+  const long long cmax = K > N ? K : N;
+  return (long long)d->B * d->D * d->H * d->W * cmax < (1LL << 31);
+}
+
+W2dGeom make_w2d(const DramConvDesc* d, int K, int N, int BN) {
+  W2dGeom g{};
+  g.B = d->B; g.D = d->D; g.H = d->H; g.W = d->W; g.Ci = K; g.No = N;
+  g.nz = (g.D + W2_TZ - 1) / W2_TZ;
+  g.ny = (g.H + 7) / 8;
+  g.nx = (g.W + 7) / 8;
+  g.tiles_per_b = g.nz * g.ny * g.nx;
+  g.n_tiles = N / BN;
+  g.nblk = g.B * g.tiles_per_b * g.n_tiles;
+  return g;
+}
+
+int run_w2d(const float* in, const float* u2, const float* bias, const float* add, const float* gate, float* out,
+            float* stats, const DramConvDesc* d, int K, int N, hipStream_t s) {
+  const int BN = N % 64 == 0 ? 64 : 32;
+  const W2dGeom g = make_w2d(d, K, N, BN);
+  if (BN == 64)
+    hipLaunchKernelGGL((conv_wino2d_kernel<2>), dim3(g.nblk), dim3(512), 0, s, in, u2, bias, out, stats, add, gate, g);
+  else
+    hipLaunchKernelGGL((conv_wino2d_kernel<1>), dim3(g.nblk), dim3(512), 0, s, in, u2, bias, out, stats, add, gate, g);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+}  // namespace
+
+extern "C" int dram_wino2d_applicable(const DramConvDesc* d) {
+  return (d && w2d_ok(d, d->Cin, d->Cout) && w2d_ok(d, d->Cout, d->Cin)) ? 1 : 0;
+}
+
+extern "C" int dram_wino2d_num_stat_rows(const DramConvDesc* d) {
+  if (!dram_wino2d_applicable(d)) return DRAM_ERR_UNSUPPORTED;
+  const W2dGeom g = make_w2d(d, d->Cin, d->Cout, 64);
+  return g.B * g.tiles_per_b;
+}
+
+extern "C" int dram_wino2d_pack_weight(const float* w, float* uf, float* ub, int Cout, int Cin, dram_stream_t stream) {
+  if (!w || (!uf && !ub) || Cout < 1 || Cin < 1) return DRAM_ERR_BAD_ARG;
+  const long n = (long)Cout * Cin;
+  hipLaunchKernelGGL(wino2d_weight_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream, w,
+                     uf, ub, Cout, Cin);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_wino2d_conv3d_fwd(const float* x, const float* uf, const float* bias, float* y, float* stats_partial,
+                                      const DramConvDesc* d, dram_stream_t stream) {
+  if (!x || !uf || !y) return DRAM_ERR_BAD_ARG;
+  if (!dram_wino2d_applicable(d)) return DRAM_ERR_UNSUPPORTED;
+  return run_w2d(x, uf, bias, nullptr, nullptr, y, stats_partial, d, d->Cin, d->Cout, (hipStream_t)stream);
+}
+
+extern "C" int dram_wino2d_conv3d_bwd_data(const float* dy, const float* ub, float* dx, const float* add,
+                                           const float* gate, const DramConvDesc* d, dram_stream_t stream) {
+  if (!dy || !ub || !dx || (gate && !add)) return DRAM_ERR_BAD_ARG;
+  if (!dram_wino2d_applicable(d)) return DRAM_ERR_UNSUPPORTED;
+  return run_w2d(dy, ub, nullptr, add, gate, dx, nullptr, d, d->Cout, d->Cin, (hipStream_t)stream);
+}

@@ -185,9 +185,22 @@ def _workspace(nbytes: int, device) -> Tensor:
     return ws
 
 
+def conv_algo(g: "ConvGeom") -> int:
+    """Library plan for this geometry (dram_conv_algo): 0 direct implicit GEMM, 1 Winograd
+    F(2x2x2,3x3x3) pipeline, 2 fused in-plane Winograd F(2x2,3x3) x direct-z."""
+    return int(_L().dram_conv_algo(ctypes.byref(g.desc())))
+
+
 def conv_use_wino(g: "ConvGeom") -> bool:
-    """Library plan: Winograd F(2x2x2,3x3x3) path for this geometry (dram_conv_use_wino)."""
-    return bool(_L().dram_conv_use_wino(ctypes.byref(g.desc())))
+    return conv_algo(g) == 1
+
+
+_PACKED_TAPS = {0: None, 1: 64, 2: 48}
+
+
+def packed_taps(g: "ConvGeom") -> int:
+    t = _PACKED_TAPS[conv_algo(g)]
+    return g.taps if t is None else t
 
 
 def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True, g: Optional["ConvGeom"] = None
@@ -197,12 +210,14 @@ def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True, g: Optional["ConvG
     _req(w, "w")
     Cout, Cin = w.shape[0], w.shape[1]
     taps = w.shape[2] * w.shape[3] * w.shape[4]
-    wino = g is not None and conv_use_wino(g)
-    pt = 64 if wino else taps
+    algo = conv_algo(g) if g is not None else 0
+    pt = {0: taps, 1: 64, 2: 48}[algo]
     wf = torch.empty((pt, Cout, Cin), device=w.device, dtype=torch.float32) if want_fwd else None
     wb = torch.empty((pt, Cin, Cout), device=w.device, dtype=torch.float32) if want_bwd else None
-    if wino:
+    if algo == 1:
         _chk(_L().dram_wino_pack_weight(_p(w), _p(wf), _p(wb), Cout, Cin, _stream()), "dram_wino_pack_weight")
+    elif algo == 2:
+        _chk(_L().dram_wino2d_pack_weight(_p(w), _p(wf), _p(wb), Cout, Cin, _stream()), "dram_wino2d_pack_weight")
     else:
         _chk(_L().dram_pack_conv_weight(_p(w), _p(wf), _p(wb), Cout, Cin, taps, _stream()), "dram_pack_conv_weight")
     return wf, wb
@@ -217,15 +232,17 @@ def conv3d_fwd_keep(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, 
     """Forward conv; with keep=True on the Winograd path also returns the transformed input V
     (reused by conv3d_bwd_weight instead of transforming x again), else None."""
     _req(x, "x", shape=g.in_shape)
-    wino = conv_use_wino(g)
-    _req(wf, "wf", shape=(64 if wino else g.taps, g.Cout, g.Cin))
+    algo = conv_algo(g)
+    wino = algo == 1
+    _req(wf, "wf", shape=(packed_taps(g), g.Cout, g.Cin))
     if bias is not None:
         _req(bias, "bias", shape=(g.Cout,))
     d = g.desc()
     y = torch.empty(g.out_shape, device=x.device, dtype=torch.float32)
     stats = None
     if want_stats:
-        nt = (_L().dram_wino_num_stat_rows if wino else _L().dram_conv_num_mtiles)(ctypes.byref(d))
+        nt = {0: _L().dram_conv_num_mtiles, 1: _L().dram_wino_num_stat_rows,
+              2: _L().dram_wino2d_num_stat_rows}[algo](ctypes.byref(d))
         if nt <= 0:
             raise RuntimeError(f"dram_conv_num_mtiles rejected {g}")
         stats = torch.empty((nt, 2, g.Cout), device=x.device, dtype=torch.float32)
@@ -239,6 +256,11 @@ def conv3d_fwd_keep(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, 
             _chk(_L().dram_wino_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), _p(v), ctypes.byref(d), _p(ws),
                                            nbytes, _stream()), f"dram_wino_conv3d_fwd{g}")
         return y, stats, v
+    if algo == 2:
+        with _span("conv_wino2d_kernel", g.flops, f"fwd {g}"):
+            _chk(_L().dram_wino2d_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), ctypes.byref(d), _stream()),
+                 f"dram_wino2d_conv3d_fwd{g}")
+        return y, stats, None
     with _span("conv_igemm_kernel", g.flops, f"fwd {g}"):
         _chk(_L().dram_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), ctypes.byref(d), _stream()),
              f"dram_conv3d_fwd{g}")
@@ -248,8 +270,9 @@ def conv3d_fwd_keep(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, 
 def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] = None,
                     gate: Optional[Tensor] = None) -> Tensor:
     _req(dy, "dy", shape=g.out_shape)
-    wino = conv_use_wino(g)
-    _req(wb, "wb", shape=(64 if wino else g.taps, g.Cin, g.Cout))
+    algo = conv_algo(g)
+    wino = algo == 1
+    _req(wb, "wb", shape=(packed_taps(g), g.Cin, g.Cout))
     if add is not None:
         _req(add, "add", shape=g.in_shape)
     if gate is not None:
@@ -262,6 +285,11 @@ def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] =
         with _span("conv_wino_kernels", g.flops, f"dgrad {g}"):
             _chk(_L().dram_wino_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d), _p(ws),
                                                 nbytes, _stream()), f"dram_wino_conv3d_bwd_data{g}")
+        return dx
+    if algo == 2:
+        with _span("conv_wino2d_kernel", g.flops, f"dgrad {g}"):
+            _chk(_L().dram_wino2d_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d),
+                                                  _stream()), f"dram_wino2d_conv3d_bwd_data{g}")
         return dx
     with _span("conv_igemm_kernel", g.flops, f"dgrad {g}"):
         _chk(_L().dram_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d), _stream()),

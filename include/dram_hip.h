@@ -117,6 +117,28 @@ int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache, const floa
                                 dram_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
+/* Fused in-plane Winograd F(2x2, 3x3) x direct-z kernel for narrow (<= 128-channel) stride-1
+ * 3x3x3 convolutions with pad == dil == 1, Cin and Cout multiples of 32 (layer1 and decoder
+ * conv sites, med3d.py:91-100, :67/:76): forward and data gradient in one kernel each, 2.25x
+ * fewer MFMA products than the direct implicit GEMM, nothing extra in HBM.  Weight gradient
+ * stays on dram_conv3d_bwd_weight.
+ *   dram_wino2d_pack_weight: w [Cout][Cin][27] -> uf [16][3][Cout][Cin], ub [16][3][Cin][Cout]
+ *                         (taps flipped); either may be NULL.
+ *   stats_partial rows: dram_wino2d_num_stat_rows(desc). */
+int dram_wino2d_applicable(const DramConvDesc* desc);
+int dram_wino2d_num_stat_rows(const DramConvDesc* desc);
+int dram_wino2d_pack_weight(const float* w, float* uf, float* ub, int Cout, int Cin, dram_stream_t stream);
+int dram_wino2d_conv3d_fwd(const float* x, const float* uf, const float* bias, float* y,
+                           float* stats_partial, const DramConvDesc* desc, dram_stream_t stream);
+int dram_wino2d_conv3d_bwd_data(const float* dy, const float* ub, float* dx, const float* add,
+                                const float* gate, const DramConvDesc* desc, dram_stream_t stream);
+
+/* The library's plan for one convolution: 0 direct implicit GEMM (dram_conv3d_*), 1 Winograd
+ * F(2x2x2,3x3x3) pipeline (dram_wino_*), 2 fused in-plane Winograd (dram_wino2d_*).
+ * env DRAM_CONV_ALGO: 1 = always direct, 2 / 3 = path 1 / 2 wherever applicable (tests). */
+int dram_conv_algo(const DramConvDesc* desc);
+
+/* ------------------------------------------------------------------------- */
 /* Stem: Conv3d(1,64,k=7,s=2,p=3,bias=False)  (med3d.py:196-202 / :296-302).
  *   x [B,D,H,W] (C=1), w [64][1][7][7][7], y [B,Do,Ho,Wo,64], Do=(D+6-7)/2+1 ...
  *   stats_partial [dram_stem_num_tiles][2][64] or NULL. */

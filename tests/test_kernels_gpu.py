@@ -195,6 +195,54 @@ def test_conv3d_winograd_path(ops, monkeypatch, case):
     assert rel_l2(y.cpu(), y1.cpu()) < 1e-5
 
 
+W2D_CASES = [
+    # B, D, H, W, Cin, Cout      (DRAM_CONV_ALGO=3: fused in-plane Winograd wherever applicable)
+    (1, 16, 8, 8, 64, 64),
+    (2, 9, 11, 13, 32, 64),             # ragged in every axis, one 16-channel pair of chunks
+    (1, 20, 16, 24, 128, 64),           # two z tiles, 8 chunks
+    (1, 16, 16, 16, 64, 128),           # two N tiles forward, 128 gathered channels backward
+    (1, 18, 10, 9, 64, 32),             # 32-column variant
+    (1, 33, 8, 8, 96, 96),              # N = 96: 32-column tiles, 3 z tiles
+]
+
+
+@pytest.mark.parametrize("case", W2D_CASES, ids=[str(c) for c in W2D_CASES])
+def test_conv3d_fused_inplane_winograd(ops, monkeypatch, case):
+    """conv_wino2d_kernel (halo in LDS, A fragments B^T v B formed on the fly, output transform
+    folded into the accumulation) against F.conv3d and its autograd: forward with bias + fused BN
+    sums, data gradient with the fused shortcut-gradient epilogue."""
+    monkeypatch.setenv("DRAM_CONV_ALGO", "3")
+    B, D, H, W, Cin, Cout = case
+    x = rnd(B, Cin, D, H, W, seed=1).requires_grad_(True)
+    w = (rnd(Cout, Cin, 3, 3, 3, seed=2) * 0.1).requires_grad_(True)
+    bias = rnd(Cout, seed=3)
+    y_ref = F.conv3d(x, w, bias, 1, 1, 1)
+    gy = rnd(*y_ref.shape, seed=4)
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, [x, w], gy)
+    g = ops.ConvGeom(B, D, H, W, Cin, Cout, 3, 1, 1, 1)
+    assert ops.conv_algo(g) == 2
+    wf, wb = ops.pack_conv_weight(w.detach().to(DEV), True, True, g)
+    assert wf.shape == (48, Cout, Cin) and wb.shape == (48, Cin, Cout)
+    xd, gyd = to_ndhwc(x.detach()), to_ndhwc(gy)
+    y, stats = ops.conv3d_fwd(xd, wf, bias.to(DEV), g, True)
+    assert rel_l2(to_ncdhw(y), y_ref.detach()) < 1e-5
+    s = ops.reduce_partials(stats).cpu()
+    yr = y_ref.detach().double()
+    assert torch.allclose(s[0], yr.sum((0, 2, 3, 4)), rtol=2e-5, atol=2e-3)
+    assert torch.allclose(s[1], (yr * yr).sum((0, 2, 3, 4)), rtol=2e-5, atol=2e-3)
+    y2, st2 = ops.conv3d_fwd(xd, wf, None, g, False)
+    assert st2 is None and rel_l2(to_ncdhw(y2), F.conv3d(x, w, None, 1, 1, 1).detach()) < 1e-5
+    add = rnd(B, Cin, D, H, W, seed=5)
+    gate = rnd(B, Cin, D, H, W, seed=6)
+    dx = ops.conv3d_bwd_data(gyd, wb, g)
+    assert rel_l2(to_ncdhw(dx), gx_ref) < 1e-5
+    dx2 = ops.conv3d_bwd_data(gyd, wb, g, to_ndhwc(add), to_ndhwc(gate))
+    assert rel_l2(to_ncdhw(dx2), gx_ref + add * (gate > 0).float()) < 1e-5
+    if Cin % 64 == 0:
+        dw = ops.conv3d_bwd_weight(xd, gyd, g)           # weight gradient: direct kernels
+        assert rel_l2(dw.cpu(), gw_ref) < 5e-6
+
+
 def test_winograd_linearity_at_scale(ops):
     """BASELINE-sized layer4 conv (512->512, dilation 4 @ 2x16x32x32) on the library's own plan
     (Winograd): linearity, a probe of one residue sub-lattice against the CPU op, and bitwise
