@@ -19,8 +19,11 @@
 //   * transformed weights U2[xi][a][n][k] = (G w_a G^T)[xi] are streamed per xi, double-buffered.
 // MFMA work: 16 x 3 = 48 instead of 4 x 27 = 108 products per 2x2 tile -> 2.25x fewer.
 // LDS images are raw 64-B rows; bank conflicts are removed by placing voxel row r at
-// r ^ ((y_halo >> 1) & 1) and XOR-ing the 16-B slot with (x_halo >> 1) & 3 (weights:
-// (n >> 1) & 3), applied on the DMA source side and on the reads.
+// r ^ ((y_halo >> 1) & 1) and XOR-ing the 16-B slot with ((x_halo >> 2) & 1) | 2 * ((y_halo >> 2) & 1)
+// (so the 4 x 4 in-plane tiles of a 16-lane read group land on 16 different 16-B columns; weights:
+// bswz(n)), applied on the DMA source side and on the reads (SQ_LDS_BANK_CONFLICT = 0, measured).
+// Issuing the next group's LDS reads ahead of the current group's MFMAs (software pipelining inside
+// a wave) measured 2-4 % SLOWER; the sibling wave on the SIMD covers the latency.
 // The data gradient is the same kernel on dy with the tap-flipped, transposed weights.
 #include <stdlib.h>
 #include "common.h"
@@ -47,6 +50,15 @@ __device__ constexpr int kBP[4][2] = {{0, 2}, {1, 2}, {1, 2}, {1, 3}};
 __device__ constexpr float kBS[4][2] = {{1.f, -1.f}, {1.f, 1.f}, {-1.f, 1.f}, {1.f, -1.f}};
 // A^T = [1 1 1 0; 0 1 -1 -1]
 __device__ constexpr float kAT[2][4] = {{1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, -1.f}};
+
+// 16-B slot swizzle of weight row n.  A ds_read_b128 is served in four groups of 16 lanes
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32), one 256-B LDS cycle each when the 16 lanes hit 16
+// different 16-B columns; with 64-B rows the column is (row & 3) * 4 + slot, so the four 4-lane runs
+// of a group (rows >> 2 = {0,3,5,6} or {1,2,4,7}) need four different slot swizzles.
+__device__ __forceinline__ int bswz(int n) {
+  const int v = (n >> 2) & 7;
+  return (v & 3) ^ ((v >> 2) * 3);
+}
 
 // address of the second k-group: slot ^ 2, i.e. float index ^ 8 -- as an opaque VALU op at the use
 // site, so that the compiler does not keep a second copy of every address in registers
@@ -89,7 +101,7 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
 
   // ---- halo DMA: piece p = wave + 8q, this lane feeds LDS row 16p + (lane >> 2), slot lane & 3.
   // The (row -> source voxel) map is built once per workgroup into a small LDS table: element
-  // offset of the voxel at channel 0 with the slot swizzle (x_halo >> 1) & 3 in its two low bits
+  // offset of the voxel at channel 0 with the slot swizzle in its two low bits
   // (offsets are multiples of Ci >= 16), or -1 for rows outside the volume.
   const int pslot = lane & 3;
   for (int rp = tid; rp < W2_NPIECE * 16; rp += 512) {
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
     const int zh = rl / 100, xh = rl % 10;
     const int zi = z0 + zh - 1, yi = y0 + yh - 1, xi = x0 + xh - 1;
     const bool v = (rp < W2_HROWS) & (zi >= 0) & (zi < g.D) & (yi >= 0) & (yi < g.H) & (xi >= 0) & (xi < g.W);
-    htab[rp] = v ? ((((b * g.D + zi) * g.H + yi) * g.W + xi) * g.Ci) | ((xh >> 1) & 3) : -1;
+    htab[rp] = v ? ((((b * g.D + zi) * g.H + yi) * g.W + xi) * g.Ci) | ((xh >> 2) & 1) | (((yh >> 2) & 1) << 1) : -1;
   }
   // weight pieces: piece pb = wave + 8j covers rows 16*pb .. +15 of the (3 x BN)-row tile
   int boff[PB];
@@ -107,7 +119,7 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
     int row = 16 * (wave + 8 * j) + (lane >> 2);
     if (row >= BROWS) row = 0;
     const int a = row / BN, n = row - a * BN;
-    boff[j] = (a * g.No + n0 + n) * g.Ci + (pslot ^ ((n >> 1) & 3)) * 4;
+    boff[j] = (a * g.No + n0 + n) * g.Ci + (pslot ^ bswz(n)) * 4;
   }
   const long xi_stride = 3L * g.No * g.Ci;
 
@@ -155,9 +167,9 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
     for (int q = 0; q < 4; ++q) {
       const int yh = 2 * ty + p, xh = 2 * tx + q;
       const int rl = ((2 * wave + zl) * 10 + yh) * 10 + xh;
-      abase[p][q] = (rl ^ ((yh >> 1) & 1)) * 16 + ((lh ^ ((xh >> 1) & 3)) * 4);
+      abase[p][q] = (rl ^ ((yh >> 1) & 1)) * 16 + ((lh ^ (((xh >> 2) & 1) | (((yh >> 2) & 1) << 1))) * 4);
     }
-  const int bbase = li * 16 + ((lh ^ ((li >> 1) & 3)) * 4);
+  const int bbase = li * 16 + ((lh ^ bswz(li)) * 4);
   const int nchunk = g.Ci / W2_BK;
 
   for (int c = 0; c < nchunk; ++c) {
