@@ -60,6 +60,25 @@ __device__ __forceinline__ int bswz(int n) {
   return (v & 3) ^ ((v >> 2) * 3);
 }
 
+// y += t / y -= t on 16 floats as 8 v_pk_add_f32 (the compiler emits 16 scalar v_sub_f32 for the
+// subtraction).  Inline asm is invisible to the MFMA hazard recognizer: the caller places the
+// wait states (mfma_result_wait) between the last MFMA writing t and the first of these.
+template <bool NEG>
+__device__ __forceinline__ void pk_acc(f32x16& y, const f32x16& t) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f32x2 yy = {y[2 * i], y[2 * i + 1]};
+    const f32x2 tt = {t[2 * i], t[2 * i + 1]};
+    if (NEG) asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(yy) : "v"(tt));
+    else asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(yy) : "v"(tt));
+    y[2 * i] = yy[0];
+    y[2 * i + 1] = yy[1];
+  }
+}
+// v_mfma_f32_32x32x2_f32 (16 passes) result -> VALU read: 18 wait states
+__device__ __forceinline__ void mfma_result_wait() { asm volatile("s_nop 15\n\ts_nop 3"); }
+
 // address of the second k-group: slot ^ 2, i.e. float index ^ 8 -- as an opaque VALU op at the use
 // site, so that the compiler does not keep a second copy of every address in registers
 __device__ __forceinline__ int kx(int off, int gk) {
@@ -124,7 +143,7 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
   const long xi_stride = 3L * g.No * g.Ci;
 
   auto issue_halo = [&](int c) __attribute__((always_inline)) {
-#pragma unroll
+#pragma unroll 1   // a rolled loop: the unrolled address math of 15 pieces spilled accumulators to scratch
     for (int q = 0; q < W2_HQ; ++q) {
       if (wave + 8 * q < W2_NPIECE) {   // wave-uniform
         const int ho = htab[16 * (wave + 8 * q) + (lane >> 2)];
@@ -217,6 +236,7 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
         }
       }
       // output transform on the fly: y[oy][ox] += A^T[oy][xi_y] * A^T[ox][xi_x] * t
+      mfma_result_wait();
 #pragma unroll
       for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
@@ -225,9 +245,8 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
           if (cf != 0.f) {
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj) {
-              if (cf > 0.f) yacc[oy][ox][nj] += t[nj];
-              else yacc[oy][ox][nj] -= t[nj];
-              asm volatile("" : "+v"(yacc[oy][ox][nj]));   // pin the add here (else it is sunk past 15 more xi, t spilled)
+              if (cf > 0.f) pk_acc<false>(yacc[oy][ox][nj], t[nj]);   // volatile asm: stays here, in this xi
+              else pk_acc<true>(yacc[oy][ox][nj], t[nj]);
             }
           }
         }
