@@ -684,7 +684,25 @@ extern "C" int dram_conv_algo(const DramConvDesc* d) {
   return pick;
 }
 
-extern "C" int dram_conv_use_wino(const DramConvDesc* d) { return dram_conv_algo(d) == 1 ? 1 : 0; }
+// Weight-gradient plan (independent of the forward plan: the fused in-plane kernel has no weight
+// gradient of its own): 1 = Winograd TN pipeline (dram_wino_conv3d_bwd_weight), 0 = direct.
+// Cost per voxel: both tile transforms (36 B x (Cin + Cout) at ~4.9 TB/s) + the 64 TN GEMMs
+// (16 Cin Cout flops at ~125 TFLOP/s or their 32 (Cin + Cout) B of operands at ~4.7 TB/s).
+extern "C" int dram_conv_wgrad_algo(const DramConvDesc* d) {
+  const char* v = getenv("DRAM_CONV_ALGO");
+  const int algo = v ? atoi(v) : 0;
+  if (algo == 1 || algo == 3) return 0;
+  if (!dram_wino_applicable(d)) return 0;
+  if (algo == 2) return 1;
+  const WinoGeom g = make_geom(d);
+  if (g.T < 1024) return 0;
+  const double vox = (double)d->B * d->D * d->H * d->W, vpad = 8.0 * g.Tpad;
+  const double K = d->Cin, N = d->Cout;
+  const double gemm = 16.0 * K * N / 125e12, traffic = 32.0 * (K + N) / 4.7e12;
+  const double wino = vpad * (36.0 * (K + N) / 4.9e12 + (gemm > traffic ? gemm : traffic));
+  const double direct = vox * 54.0 * K * N / 125e12;
+  return wino < 0.85 * direct ? 1 : 0;
+}
 
 extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, int Cout, int Cin, dram_stream_t stream) {
   if (!w || (!uf && !ub) || Cout < 1 || Cin < 1) return DRAM_ERR_BAD_ARG;

@@ -305,7 +305,7 @@ def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] 
     shape = (g.Cout, g.Cin, g.k, g.k, g.k)
     dw = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
     _req(dw, "dw", shape=shape)
-    if conv_use_wino(g):
+    if _L().dram_conv_wgrad_algo(ctypes.byref(d)) == 1:
         nbytes = _L().dram_wino_workspace(ctypes.byref(d), 2)
         if nbytes:                                   # 0: this geometry's weight gradient stays on the direct path
             ws = _workspace(nbytes, x.device)

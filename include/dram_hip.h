@@ -89,8 +89,8 @@ int dram_conv_num_mtiles(const DramConvDesc* desc);
  * channel pair.  Same tensors and layouts as dram_conv3d_*; the packed weights are the
  * transformed ones and every pass needs a caller-owned workspace.
  *   dram_wino_applicable: 1 when the geometry is supported.
- *   dram_conv_use_wino:   1 when the library's plan prefers this path for desc (wide layers;
- *                         env DRAM_CONV_ALGO: 1 = never, 2 = wherever applicable).
+ *   dram_conv_wgrad_algo: 1 when the library's plan computes the WEIGHT gradient of desc on this
+ *                         path (decided separately from dram_conv_algo: forward / data gradient).
  *   dram_wino_pack_weight: w [Cout][Cin][27] -> uf [64][Cout][Cin], ub [64][Cin][Cout]
  *                         (taps flipped, data-gradient operand); either may be NULL.
  *   dram_wino_workspace(desc, pass): bytes for pass 0 forward, 1 data gradient, 2 weight
@@ -101,7 +101,7 @@ int dram_conv_num_mtiles(const DramConvDesc* desc);
  *                         transforming x again (x may then be NULL).
  * Deterministic (no atomics; the weight gradient sums its slabs in a fixed order). */
 int dram_wino_applicable(const DramConvDesc* desc);
-int dram_conv_use_wino(const DramConvDesc* desc);
+int dram_conv_wgrad_algo(const DramConvDesc* desc);
 int dram_wino_pack_weight(const float* w, float* uf, float* ub, int Cout, int Cin, dram_stream_t stream);
 size_t dram_wino_workspace(const DramConvDesc* desc, int pass);
 int dram_wino_num_stat_rows(const DramConvDesc* desc);

@@ -17,7 +17,7 @@ x = torch.randn(g.in_shape, device=dev)
 w = torch.randn(Cout, Cin, k, k, k, device=dev) * 0.05
 dy = torch.randn(g.out_shape, device=dev)
 wf, wb = ops.pack_conv_weight(w, True, True, g)
-print("winograd plan:", ops.conv_use_wino(g))
+print("plan: algo", ops.conv_algo(g))
 
 
 def run(mode):
