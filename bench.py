@@ -9,8 +9,10 @@ fused Adam update on one batch of synthetic volumes already resident in HBM
 conf/med3d18.yaml (resnet18segcls), batch 2 per GPU, 1x128x256x256, fp32.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  roofline     -- dominant kernel family (fp32-MFMA implicit-GEMM conv, fwd + dgrad),
-                  algorithmic FLOPs / HIP-event time measured inside the timed region
+  roofline     -- dominant single kernel of the step (the one with the largest HIP-event time
+                  among the conv kernels; on config 1 the fused in-plane Winograd conv),
+                  ALGORITHMIC (direct-convolution) FLOPs / HIP-event time measured inside the
+                  timed region; `executed_*` prices the MFMA products the kernel really issues
   cpu_baseline -- the CPU oracle (oracle/med3d_oracle.py, torch CPU ops) on a bounded
                   sample of the same workload, host cores stated  (N=1, rank 0 only)
 """
@@ -37,14 +39,25 @@ CONFIGS = {
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant family from rocprofv3 PMC passes (FETCH_SIZE x2
-    gfx950 correction + WRITE_SIZE), recorded offline for this exact command (config 1) in
-    profiles/r01_pmc_hbm_traffic.json -- PMC counters cannot be read from inside bench.py."""
+# profiler span -> (kernel description, key in profiles/r01_pmc_hbm_traffic.json,
+#                   algorithmic MACs / executed MFMA MACs)
+ROOFLINE_KERNELS = {
+    "conv_wino2d_kernel": ("conv_wino2d_kernel<NJ> (fused in-plane Winograd F(2x2,3x3) x direct-z conv, fwd + dgrad, "
+                           "fp32 MFMA 32x32x2)", "conv_wino2d", 54.0 / 24.0),
+    "conv_igemm_kernel": ("conv_igemm*_kernel family (direct implicit-GEMM conv fwd + dgrad, fp32 MFMA 32x32x2)",
+                          "conv_igemm", 1.0),
+}
+
+
+def measured_traffic(key):
+    """HBM bytes per launch of the roofline kernel from rocprofv3 PMC passes (FETCH_SIZE x2
+    gfx950 correction + WRITE_SIZE, separate passes), recorded offline for this exact command
+    (config 1) in profiles/r01_pmc_hbm_traffic.json (tools/profile_round.sh) -- PMC counters
+    cannot be read from inside bench.py."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
     try:
         with open(path) as f:
-            return float(json.load(f)["conv_igemm"]["total"])
+            return float(json.load(f)[key]["total"])
     except Exception:  # noqa: BLE001
         return None
 
@@ -199,7 +212,8 @@ def main():
                 f.write(f"{v['ms'] / args.steps:9.3f} ms/step  {v['launches'] // args.steps:3d}x  {tf:7.1f} TF  {fam}  {det}\n")
     if rank == 0:
         vols = args.steps * B * world
-        fam = "conv_igemm_kernel"
+        fam = max(ROOFLINE_KERNELS, key=lambda k: summ.get(k, {}).get("ms", 0.0))
+        kdesc, tkey, ratio = ROOFLINE_KERNELS[fam]
         s = summ.get(fam, dict(launches=0, ms=0.0, flops=0.0))
         achieved = (s["flops"] / 1e12) / (s["ms"] / 1e3) if s["ms"] > 0 else 0.0
         out = {
@@ -221,10 +235,14 @@ def main():
                        "train_gflop_per_volume": gflop_per_vol},
             "loss": float(loss),
             "roofline": {
-                "kernel": "conv_igemm*_kernel family (conv fwd + dgrad, fp32 MFMA 32x32x2)",
+                "kernel": kdesc,
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": measured_traffic() if args.config == 1 else None,
+                "note": "achieved = algorithmic (direct-convolution) FLOPs / time; a Winograd kernel executes "
+                        "fewer MFMA products than that, so frac may exceed 1 -- executed_* is the matrix-pipe view",
+                "algorithmic_over_executed_flops": ratio,
+                "executed_tflops": achieved / ratio, "executed_frac": achieved / ratio / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": measured_traffic(tkey) if args.config == 1 else None,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.json)",
                 "launches_per_step": s["launches"] / max(args.steps, 1),
                 "avg_launch_ms": s["ms"] / max(s["launches"], 1),
