@@ -44,6 +44,9 @@ SIGNATURES = {
     "dram_conv3d_bwd_weight": (I, [P, P, P, DP, P, SZ, P]),
     "dram_conv_num_mtiles": (I, [DP]),
     "dram_conv_algo": (I, [DP]),
+    "dram_wgrad_w2d_applicable": (I, [DP]),
+    "dram_wgrad_w2d_workspace": (SZ, [DP]),
+    "dram_wgrad_w2d": (I, [P, P, P, DP, P, SZ, P]),
     "dram_wino2d_applicable": (I, [DP]),
     "dram_wino2d_num_stat_rows": (I, [DP]),
     "dram_wino2d_pack_weight": (I, [P, P, P, I, I, P]),

@@ -684,6 +684,8 @@ extern "C" int dram_conv_algo(const DramConvDesc* d) {
   return pick;
 }
 
+constexpr double W2D_WGRAD_RATE = 215e12;   // measured 197-248 TFLOP/s direct-equivalent (round 1)
+
 // Weight-gradient plan (independent of the forward plan: the fused in-plane kernel has no weight
 // gradient of its own): 1 = Winograd TN pipeline (dram_wino_conv3d_bwd_weight), 0 = direct.
 // Cost per voxel: both tile transforms (36 B x (Cin + Cout) at ~4.9 TB/s) + the 64 TN GEMMs
@@ -691,17 +693,30 @@ extern "C" int dram_conv_algo(const DramConvDesc* d) {
 extern "C" int dram_conv_wgrad_algo(const DramConvDesc* d) {
   const char* v = getenv("DRAM_CONV_ALGO");
   const int algo = v ? atoi(v) : 0;
-  if (algo == 1 || algo == 3) return 0;
-  if (!dram_wino_applicable(d)) return 0;
-  if (algo == 2) return 1;
-  const WinoGeom g = make_geom(d);
-  if (g.T < 1024) return 0;
-  const double vox = (double)d->B * d->D * d->H * d->W, vpad = 8.0 * g.Tpad;
+  if (algo == 1) return 0;
+  const bool w3 = dram_wino_applicable(d) != 0, w2 = dram_wgrad_w2d_applicable(d) != 0;
+  if (algo == 2) return w3 ? 1 : 0;
+  if (algo == 3) return w2 ? 2 : 0;
+  if (!d) return 0;
+  const double vox = (double)d->B * d->D * d->H * d->W;
   const double K = d->Cin, N = d->Cout;
-  const double gemm = 16.0 * K * N / 125e12, traffic = 32.0 * (K + N) / 4.7e12;
-  const double wino = vpad * (36.0 * (K + N) / 4.9e12 + (gemm > traffic ? gemm : traffic));
   const double direct = vox * 54.0 * K * N / 125e12;
-  return wino < 0.85 * direct ? 1 : 0;
+  double best = 1e30;
+  int pick = 0;
+  if (w3) {
+    const WinoGeom g = make_geom(d);
+    if (g.T >= 1024) {
+      const double vpad = 8.0 * g.Tpad;
+      const double gemm = 16.0 * K * N / 125e12, traffic = 32.0 * (K + N) / 4.7e12;
+      const double wino = vpad * (36.0 * (K + N) / 4.9e12 + (gemm > traffic ? gemm : traffic));
+      if (wino < 0.85 * direct) { best = wino; pick = 1; }
+    }
+  }
+  if (w2 && d->D >= 8 && vox >= 65536.0) {
+    const double w2d = vox * 54.0 * K * N / W2D_WGRAD_RATE;     // direct-equivalent rate, measured
+    if (w2d < 0.92 * direct && w2d < best) { best = w2d; pick = 2; }
+  }
+  return pick;
 }
 
 extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, int Cout, int Cin, dram_stream_t stream) {

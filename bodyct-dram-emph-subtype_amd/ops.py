@@ -305,7 +305,15 @@ def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] 
     shape = (g.Cout, g.Cin, g.k, g.k, g.k)
     dw = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
     _req(dw, "dw", shape=shape)
-    if _L().dram_conv_wgrad_algo(ctypes.byref(d)) == 1:
+    walgo = _L().dram_conv_wgrad_algo(ctypes.byref(d))
+    if walgo == 2:
+        nbytes = _L().dram_wgrad_w2d_workspace(ctypes.byref(d))
+        ws = _workspace(nbytes, x.device)
+        with _span("conv_wgrad_w2d_kernel+reduce", g.flops, f"wgrad {g}"):
+            _chk(_L().dram_wgrad_w2d(_p(x), _p(dy), _p(dw), ctypes.byref(d), _p(ws), nbytes, _stream()),
+                 f"dram_wgrad_w2d{g}")
+        return dw
+    if walgo == 1:
         nbytes = _L().dram_wino_workspace(ctypes.byref(d), 2)
         if nbytes:                                   # 0: this geometry's weight gradient stays on the direct path
             ws = _workspace(nbytes, x.device)

@@ -89,8 +89,9 @@ int dram_conv_num_mtiles(const DramConvDesc* desc);
  * channel pair.  Same tensors and layouts as dram_conv3d_*; the packed weights are the
  * transformed ones and every pass needs a caller-owned workspace.
  *   dram_wino_applicable: 1 when the geometry is supported.
- *   dram_conv_wgrad_algo: 1 when the library's plan computes the WEIGHT gradient of desc on this
- *                         path (decided separately from dram_conv_algo: forward / data gradient).
+ *   dram_conv_wgrad_algo: plan for the WEIGHT gradient of desc, decided separately from
+ *                         dram_conv_algo: 0 direct (dram_conv3d_bwd_weight), 1 this pipeline,
+ *                         2 in-plane Winograd z-walking kernel (dram_wgrad_w2d).
  *   dram_wino_pack_weight: w [Cout][Cin][27] -> uf [64][Cout][Cin], ub [64][Cin][Cout]
  *                         (taps flipped, data-gradient operand); either may be NULL.
  *   dram_wino_workspace(desc, pass): bytes for pass 0 forward, 1 data gradient, 2 weight
@@ -132,6 +133,14 @@ int dram_wino2d_conv3d_fwd(const float* x, const float* uf, const float* bias, f
                            float* stats_partial, const DramConvDesc* desc, dram_stream_t stream);
 int dram_wino2d_conv3d_bwd_data(const float* dy, const float* ub, float* dx, const float* add,
                                 const float* gate, const DramConvDesc* desc, dram_stream_t stream);
+
+/* Weight gradient of the same narrow layers through the in-plane Winograd domain (z-walking,
+ * 48 instead of 108 MFMA products per 2x2 tile); dw in the reference layout [Cout][Cin][27];
+ * workspace = column slabs, summed in a fixed order (deterministic). */
+int dram_wgrad_w2d_applicable(const DramConvDesc* desc);
+size_t dram_wgrad_w2d_workspace(const DramConvDesc* desc);
+int dram_wgrad_w2d(const float* x, const float* dy, float* dw, const DramConvDesc* desc, void* workspace,
+                   size_t workspace_bytes, dram_stream_t stream);
 
 /* The library's plan for one convolution: 0 direct implicit GEMM (dram_conv3d_*), 1 Winograd
  * F(2x2x2,3x3x3) pipeline (dram_wino_*), 2 fused in-plane Winograd (dram_wino2d_*).

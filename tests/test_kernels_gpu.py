@@ -238,9 +238,9 @@ def test_conv3d_fused_inplane_winograd(ops, monkeypatch, case):
     assert rel_l2(to_ncdhw(dx), gx_ref) < 1e-5
     dx2 = ops.conv3d_bwd_data(gyd, wb, g, to_ndhwc(add), to_ndhwc(gate))
     assert rel_l2(to_ncdhw(dx2), gx_ref + add * (gate > 0).float()) < 1e-5
-    if Cin % 64 == 0:
-        dw = ops.conv3d_bwd_weight(xd, gyd, g)           # weight gradient: direct kernels
-        assert rel_l2(dw.cpu(), gw_ref) < 5e-6
+    dw = ops.conv3d_bwd_weight(xd, gyd, g)               # in-plane Winograd z-walking weight gradient
+    assert rel_l2(dw.cpu(), gw_ref) < 1e-5
+    assert torch.equal(dw, ops.conv3d_bwd_weight(xd, gyd, g))      # slabs summed in a fixed order
 
 
 def test_winograd_linearity_at_scale(ops):
