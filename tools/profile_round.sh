@@ -2,6 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun): the bench lines, the rocprofv3 kernel trace and the two PMC
 # passes (FETCH_SIZE / WRITE_SIZE in separate runs) behind profiles/rNN_*.  Output: gpurun_out/prof/.
 #   gpurun --timeout 1200 -- 'bash tools/profile_round.sh'
+# (delete the local gpurun_out/prof first: gpurun merges, it does not mirror)
 # then locally:  python tools/summarize_profile.py gpurun_out/prof profiles r01
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}

@@ -35,7 +35,7 @@ for f in glob.glob(os.path.join(src, "bench_config*")):
     shutil.copy(f, os.path.join(dst, f"{tag}_" + os.path.basename(f)))
 
 # ---- kernel trace summary -----------------------------------------------------------------
-stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")), key=os.path.getmtime)   # newest run
 shutil.copy(stats, os.path.join(dst, f"{tag}_rocprofv3_kernel_stats_bench_config1.csv"))
 rows = list(csv.DictReader(open(stats)))
 steps = 7.0   # 2 warm-up + 5 timed
@@ -71,7 +71,7 @@ with open(os.path.join(dst, f"{tag}_rocprofv3_summary.txt"), "w") as out:
 def pmc(dirname):
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.defaultdict(lambda: collections.defaultdict(set))
-    for f in glob.glob(os.path.join(src, dirname, "*", "*counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(src, dirname, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             fm = family(r["Kernel_Name"])
             acc[fm][r["Counter_Name"]] += float(r["Counter_Value"])
