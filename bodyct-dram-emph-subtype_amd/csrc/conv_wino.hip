@@ -310,18 +310,27 @@ __device__ __forceinline__ void gt3(const float a0, const float a1, const float 
   r2 = 0.5f * (a1 + a2) + a3;
 }
 
-__global__ __launch_bounds__(64) void wino_wgrad_out_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                             const int Cout, const int Cin, const int nsplit) {
+// One workgroup = 64 (co, ci) elements x 16 point groups (1024 threads): every thread sums 4 of the
+// 64 points over the splits (coalesced over elements), then 64 threads apply G^T . G (3-D).
+__global__ __launch_bounds__(1024) void wino_wgrad_out_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                               const int Cout, const int Cin, const int nsplit) {
+  __shared__ float us[64][64];
   const long n = (long)Cout * Cin;
-  const long i = blockIdx.x * 64L + threadIdx.x;   // (co, ci), ci fastest
-  if (i >= n) return;
+  const int e = threadIdx.x & 63, gq = threadIdx.x >> 6;
+  const long i = blockIdx.x * 64L + e;   // (co, ci), ci fastest
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int a = gq * 4 + j;
+    float acc = 0.f;
+    if (i < n)
+      for (int sp = 0; sp < nsplit; ++sp) acc += slab[((long)sp * 64 + a) * n + i];
+    us[a][e] = acc;
+  }
+  __syncthreads();
+  if (gq != 0 || i >= n) return;
   float s[4][4][4];
 #pragma unroll
-  for (int a = 0; a < 64; ++a) {
-    float acc = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) acc += slab[((long)sp * 64 + a) * n + i];
-    (&s[0][0][0])[a] = acc;
-  }
+  for (int a = 0; a < 64; ++a) (&s[0][0][0])[a] = us[a][e];
   float p[4][4][3], q[4][3][3], r[3][3][3];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -808,7 +817,7 @@ extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache,
 #undef WTN
   DRAM_LAUNCH_CHECK();
   const long n = (long)d->Cout * d->Cin;
-  hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, slab, dw, d->Cout,
+  hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, s, slab, dw, d->Cout,
                      d->Cin, p.nsplit);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
