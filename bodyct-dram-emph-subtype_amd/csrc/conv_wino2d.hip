@@ -76,8 +76,13 @@ __device__ __forceinline__ void pk_acc(f32x16& y, const f32x16& t) {
     y[2 * i + 1] = yy[1];
   }
 }
-// v_mfma_f32_32x32x2_f32 (16 passes) result -> VALU read: 18 wait states
-__device__ __forceinline__ void mfma_result_wait() { asm volatile("s_nop 15\n\ts_nop 3"); }
+// v_mfma_f32_32x32x2_f32 (16 passes) result -> VALU read: 18 wait states.  The scratch accumulators are
+// operands of the asm, so it stays between the MFMAs that write them and the adds that read them.
+template <int NJ>
+__device__ __forceinline__ void mfma_result_wait(f32x16 (&t)[NJ]) {
+  if (NJ == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(t[0]), "+v"(t[NJ - 1]));
+  else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(t[0]));
+}
 
 // address of the second k-group: slot ^ 2, i.e. float index ^ 8 -- as an opaque VALU op at the use
 // site, so that the compiler does not keep a second copy of every address in registers
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
         }
       }
       // output transform on the fly: y[oy][ox] += A^T[oy][xi_y] * A^T[ox][xi_x] * t
-      mfma_result_wait();
+      mfma_result_wait<NJ>(t);
 #pragma unroll
       for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
@@ -313,6 +318,257 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
   }
 }
 
+// ==========================================================================================
+// v2 of the fused kernel on v_mfma_f32_16x16x4_f32.  Same algorithm and LDS conventions, different
+// shape: output tile 8(z) x 8 x 8, a wave owns ONE z-plane = 16 in-plane tiles (16 MFMA rows) x BN
+// columns as NB 16x16 blocks.  Per 16x16 block an accumulator is 4 registers, so a wave keeps
+// 4 x NB output + NB scratch accumulators = 80 registers for 64 columns (160 in the 32x32 variant):
+// the compiler has room to overlap the next operand reads with the MFMAs without spilling, and
+//   * one ds_read_b128 per raw position covers all 16 channels of the chunk (lane = (row, k-quad)),
+//   * the 10x10x10 halo (64 KB) is double-buffered: the next chunk's halo arrives one DMA piece per
+//     wave every other Winograd point, spread over the whole chunk -- no drain at chunk boundaries.
+constexpr int V2_TZ = 8;
+constexpr int V2_HROWS = 10 * 10 * 10;
+constexpr int V2_NPIECE = (V2_HROWS + 15) / 16;          // 63 DMA pieces of 16 rows x 64 B
+constexpr int V2_HALO = V2_NPIECE * 256;                 // floats per halo buffer
+
+template <bool NEG>
+__device__ __forceinline__ void pk_acc4(f32x4& y, const f32x4& t) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    f32x2 yy = {y[2 * i], y[2 * i + 1]};
+    const f32x2 tt = {t[2 * i], t[2 * i + 1]};
+    if (NEG) asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(yy) : "v"(tt));
+    else asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(yy) : "v"(tt));
+    y[2 * i] = yy[0];
+    y[2 * i + 1] = yy[1];
+  }
+}
+// v_mfma_f32_16x16x4_f32 (8 passes) result -> VALU read: 11 wait states (operands: see mfma_result_wait)
+template <int NB>
+__device__ __forceinline__ void mfma16_result_wait(f32x4 (&t)[NB]) {
+  if (NB == 4) asm volatile("s_nop 12" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[NB - 1]));
+  else asm volatile("s_nop 12" : "+v"(t[0]), "+v"(t[NB - 1]));
+}
+
+// weight-row slot swizzle for the (row, k-quad) lane mapping: the four 4-row runs of a 16-lane read
+// group carry k-quads {0,0,1,1}, so f(row >> 2) = {0,2,3,1} keeps their 16-B columns distinct
+__device__ __forceinline__ int bswz16(int n) { return (0x78 >> (2 * ((n >> 2) & 3))) & 3; }
+
+template <int NB>
+__global__ __launch_bounds__(512) void conv_wino2d16_kernel(const float* __restrict__ in, const float* __restrict__ u2,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            float* __restrict__ stats, const float* __restrict__ add,
+                                                            const float* __restrict__ gate, const W2dGeom g) {
+  constexpr int BN = 16 * NB;
+  constexpr int BROWS = 3 * BN;
+  constexpr int BST = BROWS * 16;
+  constexpr int BPIECE = BROWS / 16;
+  constexpr int PB = (BPIECE + 7) / 8;
+  __shared__ __attribute__((aligned(1024))) float lds[2 * V2_HALO + 2 * BST];
+  __shared__ int htab[V2_NPIECE * 16];
+  float* bst = lds + 2 * V2_HALO;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int L = xcd_remap(blockIdx.x, g.nblk);
+  const int n_tile = L % g.n_tiles;
+  const int mt = L / g.n_tiles;
+  const int b = mt / g.tiles_per_b;
+  int r = mt - b * g.tiles_per_b;
+  const int txi = r % g.nx; r /= g.nx;
+  const int tyi = r % g.ny;
+  const int tzi = r / g.ny;
+  const int n0 = n_tile * BN;
+  const int z0 = tzi * V2_TZ, y0 = tyi * 8, x0 = txi * 8;
+
+  const int pslot = lane & 3;
+  for (int rp = tid; rp < V2_NPIECE * 16; rp += 512) {
+    const int yh = (rp / 10) % 10;
+    const int rl = rp ^ ((yh >> 1) & 1);
+    const int zh = rl / 100, xh = rl % 10;
+    const int zi = z0 + zh - 1, yi = y0 + yh - 1, xi = x0 + xh - 1;
+    const bool v = (rp < V2_HROWS) & (zi >= 0) & (zi < g.D) & (yi >= 0) & (yi < g.H) & (xi >= 0) & (xi < g.W);
+    htab[rp] = v ? ((((b * g.D + zi) * g.H + yi) * g.W + xi) * g.Ci) | ((xh >> 2) & 1) | (((yh >> 2) & 1) << 1) : -1;
+  }
+  int boff[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    int row = 16 * (wave + 8 * j) + (lane >> 2);
+    if (row >= BROWS) row = 0;
+    const int a = row / BN, n = row - a * BN;
+    boff[j] = (a * g.No + n0 + n) * g.Ci + (pslot ^ bswz16(n)) * 4;
+  }
+  const long xi_stride = 3L * g.No * g.Ci;
+
+  auto issue_halo_piece = [&](int c, int p, int buf) __attribute__((always_inline)) {
+    const int ho = htab[16 * p + (lane >> 2)];
+    const float* src = ho >= 0 ? in + (long)((ho & ~3) + ((pslot ^ (ho & 3)) << 2) + c * W2_BK) : g_w2d_zero;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + buf * V2_HALO + p * 256), 16, 0, 0);
+  };
+  auto issue_b = [&](int c, int xi, int stage) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      if (wave + 8 * j < BPIECE) {      // wave-uniform
+        const float* src = u2 + xi * xi_stride + c * W2_BK + boff[j];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(bst + stage * BST + (wave + 8 * j) * 256),
+                                         16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 yacc[2][2][NB];
+#pragma unroll
+  for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+    for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yacc[oy][ox][cb][e] = 0.f;
+
+  // lane = (row r = lane & 15 -> in-plane tile (ty, tx), k-quad kq = lane >> 4)
+  const int lr = lane & 15, kq = lane >> 4;
+  const int ty = lr >> 2, tx = lr & 3;
+  int abase[4][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int yh = 2 * ty + p, xh = 2 * tx + q;
+      const int rl = (wave * 10 + yh) * 10 + xh;
+      abase[p][q] = (rl ^ ((yh >> 1) & 1)) * 16 + ((kq ^ (((xh >> 2) & 1) | (((yh >> 2) & 1) << 1))) * 4);
+    }
+  const int bbase = lr * 16 + ((kq ^ bswz16(lr)) * 4);
+  const int nchunk = g.Ci / W2_BK;
+
+  __syncthreads();                      // htab complete
+#pragma unroll 1
+  for (int q = 0; q < 8; ++q)
+    if (wave + 8 * q < V2_NPIECE) issue_halo_piece(0, wave + 8 * q, 0);
+  issue_b(0, 0, 0);
+
+  for (int c = 0; c < nchunk; ++c) {
+    const float* hb = lds + (c & 1) * V2_HALO;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+      __syncthreads();                  // weights of (c, xi) have landed (at xi = 0 also the rest of halo c)
+      if (xi + 1 < 16) issue_b(c, xi + 1, (xi + 1) & 1);
+      else if (c + 1 < nchunk) issue_b(c + 1, 0, 0);
+      if (c + 1 < nchunk) {             // next chunk's halo: 4 pieces per point, waves 0-3 / 4-7 alternate
+        const int w4 = wave - 4 * (xi & 1);
+        const int p = xi * 4 + w4;
+        if (w4 >= 0 && w4 < 4 && p < V2_NPIECE) issue_halo_piece(c + 1, p, (c + 1) & 1);
+      }
+      const int xy = xi >> 2, xx = xi & 3;
+      const int p0 = kBP[xy][0], p1 = kBP[xy][1], q0 = kBP[xx][0], q1 = kBP[xx][1];
+      const float s00 = kBS[xy][0] * kBS[xx][0], s01 = kBS[xy][0] * kBS[xx][1];
+      const float s10 = kBS[xy][1] * kBS[xx][0], s11 = kBS[xy][1] * kBS[xx][1];
+      const float* bs = bst + (xi & 1) * BST;
+      f32x4 t[NB];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const f32x4 r00 = *reinterpret_cast<const f32x4*>(hb + abase[p0][q0] + a * 1600);
+        const f32x4 r01 = *reinterpret_cast<const f32x4*>(hb + abase[p0][q1] + a * 1600);
+        const f32x4 r10 = *reinterpret_cast<const f32x4*>(hb + abase[p1][q0] + a * 1600);
+        const f32x4 r11 = *reinterpret_cast<const f32x4*>(hb + abase[p1][q1] + a * 1600);
+        f32x4 bf[NB];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb)
+          bf[cb] = *reinterpret_cast<const f32x4*>(bs + (a * BN + cb * 16) * 16 + bbase);
+        const f32x4 av = (s00 * r00 + s01 * r01) + (s10 * r10 + s11 * r11);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int cb = 0; cb < NB; ++cb) {
+            if (a == 0 && e == 0) {
+              const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+              t[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bf[cb][e], zero, 0, 0, 0);
+            } else {
+              t[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bf[cb][e], t[cb], 0, 0, 0);
+            }
+          }
+        }
+      }
+      mfma16_result_wait<NB>(t);
+#pragma unroll
+      for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox) {
+          const float cf = kAT[oy][xy] * kAT[ox][xx];
+          if (cf != 0.f) {
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+              if (cf > 0.f) pk_acc4<false>(yacc[oy][ox][cb], t[cb]);
+              else pk_acc4<true>(yacc[oy][ox][cb], t[cb]);
+            }
+          }
+        }
+    }
+  }
+
+  // ---- epilogue: D register i of a 16x16 block <-> row 4*kq + i = tile (ty = kq, tx = i), column lr ---
+  float s1[NB], s2[NB], bv[NB];
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) {
+    s1[cb] = 0.f;
+    s2[cb] = 0.f;
+    bv[cb] = bias ? bias[n0 + cb * 16 + lr] : 0.f;
+  }
+  const int zo = z0 + wave;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+      for (int ox = 0; ox < 2; ++ox) {
+        const int yo = y0 + 2 * kq + oy, xo = x0 + 2 * i + ox;
+        if ((zo < g.D) & (yo < g.H) & (xo < g.W)) {
+          const long o = ((((long)b * g.D + zo) * g.H + yo) * g.W + xo) * g.No + n0 + lr;
+#pragma unroll
+          for (int cb = 0; cb < NB; ++cb) {
+            float v = yacc[oy][ox][cb][i] + bv[cb];
+            if (add) {
+              const float av = add[o + cb * 16];
+              v += gate ? (gate[o + cb * 16] > 0.f ? av : 0.f) : av;
+            }
+            out[o + cb * 16] = v;
+            s1[cb] += v;
+            s2[cb] += v * v;
+          }
+        }
+      }
+  }
+  if (stats) {
+    __syncthreads();
+    float* red = lds;  // [8 waves][2][BN]
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      float t1 = s1[cb] + __shfl_xor(s1[cb], 16, 64);
+      float t2 = s2[cb] + __shfl_xor(s2[cb], 16, 64);
+      t1 += __shfl_xor(t1, 32, 64);
+      t2 += __shfl_xor(t2, 32, 64);
+      if (kq == 0) {
+        red[(wave * 2 + 0) * BN + cb * 16 + lr] = t1;
+        red[(wave * 2 + 1) * BN + cb * 16 + lr] = t2;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, cc = tid - which * BN;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += red[(w * 2 + which) * BN + cc];
+      stats[((long)mt * 2 + which) * g.No + n0 + cc] = v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // U2[xi][a][n][k] = (G w_a G^T)[xi], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
 //   blockIdx.y == 0: forward operand   n = co, k = ci
@@ -367,10 +623,24 @@ bool w2d_ok(const DramConvDesc* d, int K, int N) {
   return (long long)d->B * d->D * d->H * d->W * cmax < (1LL << 31);
 }
 
+// Kernel variant: 1 = 32x32x2 kernel (16-deep tiles), 2 = 16x16x4 kernel (8-deep tiles).  The two
+// measure within 0-4 % of each other on full tiles (variant 1 ahead on the largest layers), so the
+// choice is made on tile waste: variant 2 whenever 16-deep tiles would pad the depth more than 8-deep
+// ones.  DRAM_W2D_V forces one (tests).
+int w2d_variant(const DramConvDesc* d) {
+  if (const char* e = getenv("DRAM_W2D_V")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2) return v;
+  }
+  const int z16 = (d->D + 15) / 16 * 16, z8 = (d->D + 7) / 8 * 8;
+  return z16 == z8 ? 1 : 2;
+}
+
 W2dGeom make_w2d(const DramConvDesc* d, int K, int N, int BN) {
   W2dGeom g{};
   g.B = d->B; g.D = d->D; g.H = d->H; g.W = d->W; g.Ci = K; g.No = N;
-  g.nz = (g.D + W2_TZ - 1) / W2_TZ;
+  const int tz = w2d_variant(d) == 1 ? W2_TZ : V2_TZ;
+  g.nz = (g.D + tz - 1) / tz;
   g.ny = (g.H + 7) / 8;
   g.nx = (g.W + 7) / 8;
   g.tiles_per_b = g.nz * g.ny * g.nx;
@@ -383,10 +653,17 @@ int run_w2d(const float* in, const float* u2, const float* bias, const float* ad
             float* stats, const DramConvDesc* d, int K, int N, hipStream_t s) {
   const int BN = N % 64 == 0 ? 64 : 32;
   const W2dGeom g = make_w2d(d, K, N, BN);
-  if (BN == 64)
-    hipLaunchKernelGGL((conv_wino2d_kernel<2>), dim3(g.nblk), dim3(512), 0, s, in, u2, bias, out, stats, add, gate, g);
-  else
-    hipLaunchKernelGGL((conv_wino2d_kernel<1>), dim3(g.nblk), dim3(512), 0, s, in, u2, bias, out, stats, add, gate, g);
+  if (w2d_variant(d) == 1) {
+    if (BN == 64)
+      hipLaunchKernelGGL((conv_wino2d_kernel<2>), dim3(g.nblk), dim3(512), 0, s, in, u2, bias, out, stats, add, gate, g);
+    else
+      hipLaunchKernelGGL((conv_wino2d_kernel<1>), dim3(g.nblk), dim3(512), 0, s, in, u2, bias, out, stats, add, gate, g);
+  } else {
+    if (BN == 64)
+      hipLaunchKernelGGL((conv_wino2d16_kernel<4>), dim3(g.nblk), dim3(512), 0, s, in, u2, bias, out, stats, add, gate, g);
+    else
+      hipLaunchKernelGGL((conv_wino2d16_kernel<2>), dim3(g.nblk), dim3(512), 0, s, in, u2, bias, out, stats, add, gate, g);
+  }
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

@@ -206,12 +206,14 @@ W2D_CASES = [
 ]
 
 
+@pytest.mark.parametrize("variant", ["1", "2"], ids=["mfma32x32x2", "mfma16x16x4"])
 @pytest.mark.parametrize("case", W2D_CASES, ids=[str(c) for c in W2D_CASES])
-def test_conv3d_fused_inplane_winograd(ops, monkeypatch, case):
+def test_conv3d_fused_inplane_winograd(ops, monkeypatch, case, variant):
     """conv_wino2d_kernel (halo in LDS, A fragments B^T v B formed on the fly, output transform
     folded into the accumulation) against F.conv3d and its autograd: forward with bias + fused BN
     sums, data gradient with the fused shortcut-gradient epilogue."""
     monkeypatch.setenv("DRAM_CONV_ALGO", "3")
+    monkeypatch.setenv("DRAM_W2D_V", variant)          # both kernel variants (16-deep / 8-deep tiles)
     B, D, H, W, Cin, Cout = case
     x = rnd(B, Cin, D, H, W, seed=1).requires_grad_(True)
     w = (rnd(Cout, Cin, 3, 3, 3, seed=2) * 0.1).requires_grad_(True)

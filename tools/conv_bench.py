@@ -14,8 +14,12 @@ pad = dil * (k - 1) // 2
 g = ops.ConvGeom(B, D, H, W, Cin, Cout, k, stride, pad, dil)
 dev = "cuda:0"
 x = torch.randn(g.in_shape, device=dev)
+if os.environ.get("BENCH_ZERO"):      # power / clock probe: all-zero activations toggle far fewer bits
+    x.zero_()
 w = torch.randn(Cout, Cin, k, k, k, device=dev) * 0.05
 dy = torch.randn(g.out_shape, device=dev)
+if os.environ.get("BENCH_ZERO"):
+    dy.zero_()
 wf, wb = ops.pack_conv_weight(w, True, True, g)
 print("plan: algo", ops.conv_algo(g))
 
