@@ -657,9 +657,27 @@ extern "C" int dram_wino_applicable(const DramConvDesc* d) {
 // (36 B x N at ~3.4 TB/s).  Forward and data gradient (K and N swapped) are averaged; Winograd is
 // planned when it is at least 8 % cheaper.  DRAM_CONV_ALGO: 0/unset auto, 1 always direct,
 // 2 Winograd wherever applicable (tests).
-static double wino_cost_per_voxel(double K, double N) {
-  const double gemm = 16.0 * K * N / 118e12, traffic = 32.0 * (K + N) / 4.7e12;
+// Small volumes underfill the chip: a launch of `wgs` workgroups on `slots` resident slots runs at
+// wgs / (rounds * slots) of the steady-state rate.
+static double fill(double wgs, double slots) {
+  if (wgs < 1.0) wgs = 1.0;
+  const double rounds = (double)(long)((wgs + slots - 1.0) / slots);
+  return wgs / (rounds * slots);
+}
+static double wino_cost_per_voxel(double K, double N, double tpad) {
+  const double nt = (double)(long)((N + 255.0) / 256.0);           // 256-column GEMM tiles (fewer columns: one tile)
+  const double gemm = 16.0 * K * N / (118e12 * fill(64.0 * (tpad / 256.0) * nt, 256.0));
+  const double traffic = 32.0 * (K + N) / 4.7e12;
   return 36.0 * K / 4.9e12 + (gemm > traffic ? gemm : traffic) + 36.0 * N / 3.4e12;
+}
+// direct implicit GEMM: 8x8x8 / 4x8x8 output tiles x 64..256 columns, two workgroups per CU
+static double direct_rate(const DramConvDesc* d, double N) {
+  const double lat = d->dil;
+  const double sz = (double)(long)((d->D + lat - 1) / lat), sy = (double)(long)((d->H + lat - 1) / lat),
+               sx = (double)(long)((d->W + lat - 1) / lat);
+  const double mt = d->B * lat * lat * lat * (double)(long)((sz + 3) / 4) * (double)(long)((sy + 7) / 8) *
+                    (double)(long)((sx + 7) / 8);
+  return 135e12 * fill(mt * (double)(long)((N + 127.0) / 128.0), 512.0);
 }
 
 extern "C" int dram_conv_algo(const DramConvDesc* d) {
@@ -674,10 +692,12 @@ extern "C" int dram_conv_algo(const DramConvDesc* d) {
   int pick = 0;
   if (w3) {
     const WinoGeom g = make_geom(d);
-    if (g.T >= 1024) {
+    if (g.T >= 128) {
       const double vpad = 8.0 * g.Tpad;
-      const double direct = vox * 54.0 * d->Cin * d->Cout / 135e12;
-      const double wino = vpad * 0.5 * (wino_cost_per_voxel(d->Cin, d->Cout) + wino_cost_per_voxel(d->Cout, d->Cin));
+      const double direct = vox * 54.0 * d->Cin * d->Cout * 0.5 *
+                            (1.0 / direct_rate(d, d->Cout) + 1.0 / direct_rate(d, d->Cin));
+      const double wino = vpad * 0.5 * (wino_cost_per_voxel(d->Cin, d->Cout, g.Tpad) +
+                                        wino_cost_per_voxel(d->Cout, d->Cin, g.Tpad));
       if (wino < 0.92 * direct) { best = wino; pick = 1; }
     }
   }
@@ -714,11 +734,16 @@ extern "C" int dram_conv_wgrad_algo(const DramConvDesc* d) {
   int pick = 0;
   if (w3) {
     const WinoGeom g = make_geom(d);
-    if (g.T >= 1024) {
+    if (g.T >= 128) {
       const double vpad = 8.0 * g.Tpad;
-      const double gemm = 16.0 * K * N / 125e12, traffic = 32.0 * (K + N) / 4.7e12;
+      TnPlan tp;
+      plan_tn(d, g, tp);
+      const double wgs = 64.0 * tp.m_tiles * tp.n_tiles * tp.nsplit;
+      const double gemm = 16.0 * K * N / (125e12 * fill(wgs, 256.0)), traffic = 32.0 * (K + N) / 4.7e12;
       const double wino = vpad * (36.0 * (K + N) / 4.9e12 + (gemm > traffic ? gemm : traffic));
-      if (wino < 0.85 * direct) { best = wino; pick = 1; }
+      // the direct weight gradient splits over voxel chunks, so it keeps the chip full down to ~16k voxels
+      const double dfill = vox >= 16384.0 ? 1.0 : vox / 16384.0;
+      if (wino < 0.85 * direct / dfill) { best = wino; pick = 1; }
     }
   }
   if (w2 && d->D >= 8 && vox >= 65536.0) {
