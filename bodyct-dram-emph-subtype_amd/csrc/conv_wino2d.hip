@@ -625,26 +625,32 @@ bool w2d_ok(const DramConvDesc* d, int K, int N) {
 
 // Kernel variant: 1 = 32x32x2 kernel (16-deep tiles), 2 = 16x16x4 kernel (8-deep tiles).  The two
 // measure within 0-4 % of each other on full tiles (variant 1 ahead on the largest layers), so the
-// choice is made on tile waste: variant 2 whenever 16-deep tiles would pad the depth more than 8-deep
-// ones.  DRAM_W2D_V forces one (tests).
-int w2d_variant(const DramConvDesc* d) {
+// choice is made on waste: variant 2 when 16-deep tiles would pad the depth more than 8-deep ones, or
+// when they would leave the chip under-filled (one workgroup per CU: 128 tiles on 256 CUs run at half
+// rate, 256 half-size tiles do not).  DRAM_W2D_V forces one (tests).
+int w2d_variant(const DramConvDesc* d, int n_tiles) {
   if (const char* e = getenv("DRAM_W2D_V")) {
     const int v = atoi(e);
     if (v == 1 || v == 2) return v;
   }
-  const int z16 = (d->D + 15) / 16 * 16, z8 = (d->D + 7) / 8 * 8;
-  return z16 == z8 ? 1 : 2;
+  const int z16 = (d->D + 15) / 16, z8 = (d->D + 7) / 8;
+  if (z16 * 16 != z8 * 8) return 2;
+  const long cols = (long)d->B * ((d->H + 7) / 8) * ((d->W + 7) / 8) * n_tiles;
+  auto fill = [](long wgs) { return (double)wgs / (double)(((wgs + 255) / 256) * 256); };
+  return fill(cols * z16) + 0.05 < fill(cols * z8) ? 2 : 1;
 }
 
-W2dGeom make_w2d(const DramConvDesc* d, int K, int N, int BN) {
+W2dGeom make_w2d(const DramConvDesc* d, int K, int N, int BN, int* variant = nullptr) {
   W2dGeom g{};
   g.B = d->B; g.D = d->D; g.H = d->H; g.W = d->W; g.Ci = K; g.No = N;
-  const int tz = w2d_variant(d) == 1 ? W2_TZ : V2_TZ;
+  g.n_tiles = N / BN;
+  const int v = w2d_variant(d, g.n_tiles);
+  if (variant) *variant = v;
+  const int tz = v == 1 ? W2_TZ : V2_TZ;
   g.nz = (g.D + tz - 1) / tz;
   g.ny = (g.H + 7) / 8;
   g.nx = (g.W + 7) / 8;
   g.tiles_per_b = g.nz * g.ny * g.nx;
-  g.n_tiles = N / BN;
   g.nblk = g.B * g.tiles_per_b * g.n_tiles;
   return g;
 }
@@ -652,8 +658,9 @@ W2dGeom make_w2d(const DramConvDesc* d, int K, int N, int BN) {
 int run_w2d(const float* in, const float* u2, const float* bias, const float* add, const float* gate, float* out,
             float* stats, const DramConvDesc* d, int K, int N, hipStream_t s) {
   const int BN = N % 64 == 0 ? 64 : 32;
-  const W2dGeom g = make_w2d(d, K, N, BN);
-  if (w2d_variant(d) == 1) {
+  int variant = 1;
+  const W2dGeom g = make_w2d(d, K, N, BN, &variant);
+  if (variant == 1) {
     if (BN == 64)
       hipLaunchKernelGGL((conv_wino2d_kernel<2>), dim3(g.nblk), dim3(512), 0, s, in, u2, bias, out, stats, add, gate, g);
     else
@@ -676,7 +683,7 @@ extern "C" int dram_wino2d_applicable(const DramConvDesc* d) {
 
 extern "C" int dram_wino2d_num_stat_rows(const DramConvDesc* d) {
   if (!dram_wino2d_applicable(d)) return DRAM_ERR_UNSUPPORTED;
-  const W2dGeom g = make_w2d(d, d->Cin, d->Cout, 64);
+  const W2dGeom g = make_w2d(d, d->Cin, d->Cout, d->Cout % 64 == 0 ? 64 : 32);   // same tiling as the forward launch
   return g.B * g.tiles_per_b;
 }
 
