@@ -54,7 +54,8 @@ SIGNATURES = {
     "dram_wino2d_conv3d_bwd_data": (I, [P, P, P, P, P, DP, P]),
     "dram_wino_applicable": (I, [DP]),
     "dram_conv_wgrad_algo": (I, [DP]),
-    "dram_wino_pack_weight": (I, [P, P, P, I, I, P]),
+    "dram_wino_num_points": (I, [DP]),
+    "dram_wino_pack_weight": (I, [P, P, P, DP, P]),
     "dram_wino_workspace": (SZ, [DP, I]),
     "dram_wino_num_stat_rows": (I, [DP]),
     "dram_wino_v_elems": (SZ, [DP]),

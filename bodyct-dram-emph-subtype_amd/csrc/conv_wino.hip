@@ -29,10 +29,15 @@
 
 namespace {
 
+// Tile: NZ x 2 x 2 outputs, (NZ + 2) x 4 x 4 inputs / Winograd points, NZ = 2 (F(2,3) along z) or
+// 4 (F(4,3) along z: 6 instead of 8 products per 4 output planes -> 25 % fewer GEMM flops and
+// Winograd-domain bytes; used when the sub-lattice depth is a multiple of 4).
 struct WinoGeom {
   int B, D, H, W;  // voxel grid (input and output grids coincide: stride 1, pad == dil)
   int d;           // dilation
-  int Tz, Ty, Tx;  // 2x2x2 tiles per residue sub-lattice axis
+  int nz;          // outputs per tile along z (2 or 4); points = (nz + 2) * 16
+  int npts;
+  int Tz, Ty, Tx;  // tiles per residue sub-lattice axis
   int T;           // B * d^3 * Tz * Ty * Tx
   int Tpad;        // T rounded up to the GEMM M tile (256)
 };
@@ -47,20 +52,88 @@ __device__ __forceinline__ void tile_origin(const WinoGeom& g, int t, int& b, in
   const int ry = r % g.d; r /= g.d;
   const int rz = r % g.d;
   b = r / g.d;
-  z0 = 2 * tz * g.d + rz;
+  z0 = g.nz * tz * g.d + rz;
   y0 = 2 * ty * g.d + ry;
   x0 = 2 * tx * g.d + rx;
 }
 
+// ---- 1-D transforms (Lavin & Gray): F(2,3) with points {0, 1, -1, inf}, F(4,3) with {0, +-1, +-2, inf} --
+// B^T d   (n + 2 -> n + 2)
+__device__ __forceinline__ void bt2(float* a) {
+  const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+  a[0] = a0 - a2; a[1] = a1 + a2; a[2] = a2 - a1; a[3] = a1 - a3;
+}
+__device__ __forceinline__ void bt4(float* a) {
+  const float d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3], d4 = a[4], d5 = a[5];
+  a[0] = 4.f * d0 - 5.f * d2 + d4;
+  a[1] = -4.f * (d1 + d2) + d3 + d4;
+  a[2] = 4.f * (d1 - d2) - d3 + d4;
+  a[3] = -2.f * d1 - d2 + 2.f * d3 + d4;
+  a[4] = 2.f * d1 - d2 - 2.f * d3 + d4;
+  a[5] = 4.f * d1 - 5.f * d3 + d5;
+}
+// A^T m   (n + 2 -> n)
+__device__ __forceinline__ void at2(const float* m, float* r) {
+  r[0] = m[0] + m[1] + m[2];
+  r[1] = m[1] - m[2] - m[3];
+}
+__device__ __forceinline__ void at4(const float* m, float* r) {
+  const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  r[0] = m[0] + s12 + s34;
+  r[1] = d12 + 2.f * d34;
+  r[2] = s12 + 4.f * s34;
+  r[3] = d12 + 8.f * d34 + m[5];
+}
+// A y   (n -> n + 2), the transpose of A^T (weight gradient)
+__device__ __forceinline__ void a2(const float* y, float* r) {
+  r[0] = y[0]; r[1] = y[0] + y[1]; r[2] = y[0] - y[1]; r[3] = -y[1];
+}
+__device__ __forceinline__ void a4(const float* y, float* r) {
+  const float e = y[0] + y[2], o = y[1] + y[3], e4 = y[0] + 4.f * y[2], o4 = 2.f * y[1] + 8.f * y[3];
+  r[0] = y[0]; r[1] = e + o; r[2] = e - o; r[3] = e4 + o4; r[4] = e4 - o4; r[5] = y[3];
+}
+// G g   (3 -> n + 2)
+__device__ __forceinline__ void g2(const float* g, float* r) {
+  const float h = 0.5f * (g[0] + g[2]);
+  r[0] = g[0]; r[1] = h + 0.5f * g[1]; r[2] = h - 0.5f * g[1]; r[3] = g[2];
+}
+__device__ __forceinline__ void g4z(const float* g, float* r) {
+  const float s = (g[0] + g[2]) * (1.f / 6.f), t = g[0] * (1.f / 24.f) + g[2] * (1.f / 6.f);
+  r[0] = 0.25f * g[0];
+  r[1] = -s - g[1] * (1.f / 6.f);
+  r[2] = -s + g[1] * (1.f / 6.f);
+  r[3] = t + g[1] * (1.f / 12.f);
+  r[4] = t - g[1] * (1.f / 12.f);
+  r[5] = g[2];
+}
+// G^T s   (n + 2 -> 3)
+__device__ __forceinline__ void gt2(const float* s, float* r) {
+  r[0] = s[0] + 0.5f * (s[1] + s[2]);
+  r[1] = 0.5f * (s[1] - s[2]);
+  r[2] = 0.5f * (s[1] + s[2]) + s[3];
+}
+__device__ __forceinline__ void gt4(const float* s, float* r) {
+  const float s12 = s[1] + s[2], s34 = s[3] + s[4];
+  r[0] = 0.25f * s[0] - s12 * (1.f / 6.f) + s34 * (1.f / 24.f);
+  r[1] = (s[2] - s[1]) * (1.f / 6.f) + (s[3] - s[4]) * (1.f / 12.f);
+  r[2] = -s12 * (1.f / 6.f) + s34 * (1.f / 6.f) + s[5];
+}
+template <int NZ> __device__ __forceinline__ void btz(float* a) { if (NZ == 2) bt2(a); else bt4(a); }
+template <int NZ> __device__ __forceinline__ void atz(const float* m, float* r) { if (NZ == 2) at2(m, r); else at4(m, r); }
+template <int NZ> __device__ __forceinline__ void az(const float* y, float* r) { if (NZ == 2) a2(y, r); else a4(y, r); }
+template <int NZ> __device__ __forceinline__ void gz(const float* g, float* r) { if (NZ == 2) g2(g, r); else g4z(g, r); }
+template <int NZ> __device__ __forceinline__ void gtz(const float* s, float* r) { if (NZ == 2) gt2(s, r); else gt4(s, r); }
+
 // ------------------------------------------------------------------------------------------
 // Tile transforms into the Winograd domain.  One wave per (tile, 64-channel block); lanes are
-// consecutive channels (256-B coalesced rows).  out[xi][t][c], xi = (i*4 + j)*4 + k.
-//   MODE 0:  V = B^T v B over the 4x4x4 input tile (zero outside the volume)
-//   MODE 1:  A dy A^T over the 2x2x2 output-gradient tile (weight gradient)
+// consecutive channels (256-B coalesced rows).  out[xi][t][c], xi = (i*4 + j)*4 + k, i < NZ + 2.
+//   MODE 0:  V = B^T v B over the (NZ+2)x4x4 input tile (zero outside the volume)
+//   MODE 1:  A dy A^T over the NZ x2x2 output-gradient tile (weight gradient)
 // Rows t in [T, Tpad) are written as zeros (the TN GEMM contracts over t).
-template <int MODE>
+template <int MODE, int NZ>
 __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                       const WinoGeom g, const int C) {
+  constexpr int NI = NZ + 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cblks = C >> 6;
   const long plane = (long)g.Tpad * C;
@@ -68,17 +141,17 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
   for (long w = blockIdx.x * 4L + wave; w < total; w += gridDim.x * 4L) {
     const int t = (int)(w / cblks);
     const int c = (int)(w - (long)t * cblks) * 64 + lane;
-    float v[4][4][4];
+    float v[NI][4][4];
     if (t >= g.T) {
 #pragma unroll
-      for (int i = 0; i < 64; ++i) out[i * plane + (long)t * C + c] = 0.f;
+      for (int i = 0; i < NI * 16; ++i) out[i * plane + (long)t * C + c] = 0.f;
       continue;
     }
     int b, z0, y0, x0;
     tile_origin(g, t, b, z0, y0, x0);
     if (MODE == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NI; ++i) {
         const int z = z0 + (i - 1) * g.d;
         const bool zo = (z >= 0) & (z < g.D);
 #pragma unroll
@@ -94,32 +167,33 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
           }
         }
       }
-      // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1] along x, y, z
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float a0 = v[i][j][0], a1 = v[i][j][1], a2 = v[i][j][2], a3 = v[i][j][3];
-          v[i][j][0] = a0 - a2; v[i][j][1] = a1 + a2; v[i][j][2] = a2 - a1; v[i][j][3] = a1 - a3;
-        }
+        for (int j = 0; j < 4; ++j) bt2(v[i][j]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float a0 = v[i][0][k], a1 = v[i][1][k], a2 = v[i][2][k], a3 = v[i][3][k];
-          v[i][0][k] = a0 - a2; v[i][1][k] = a1 + a2; v[i][2][k] = a2 - a1; v[i][3][k] = a1 - a3;
+          float col[4] = {v[i][0][k], v[i][1][k], v[i][2][k], v[i][3][k]};
+          bt2(col);
+          v[i][0][k] = col[0]; v[i][1][k] = col[1]; v[i][2][k] = col[2]; v[i][3][k] = col[3];
         }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float a0 = v[0][j][k], a1 = v[1][j][k], a2 = v[2][j][k], a3 = v[3][j][k];
-          v[0][j][k] = a0 - a2; v[1][j][k] = a1 + a2; v[2][j][k] = a2 - a1; v[3][j][k] = a1 - a3;
+          float col[NI];
+#pragma unroll
+          for (int i = 0; i < NI; ++i) col[i] = v[i][j][k];
+          btz<NZ>(col);
+#pragma unroll
+          for (int i = 0; i < NI; ++i) v[i][j][k] = col[i];
         }
     } else {
-      float u[2][2][2];
+      float u[NZ][2][2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NZ; ++i) {
         const int z = z0 + i * g.d;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -133,33 +207,35 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
           }
         }
       }
-      // A = [1 0; 1 1; 1 -1; 0 -1] along x, y, z
-      float p[2][2][4], q[2][4][4];
+      float p[NZ][2][4], q[NZ][4][4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NZ; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const float a0 = u[i][j][0], a1 = u[i][j][1];
-          p[i][j][0] = a0; p[i][j][1] = a0 + a1; p[i][j][2] = a0 - a1; p[i][j][3] = -a1;
-        }
+        for (int j = 0; j < 2; ++j) a2(u[i][j], p[i][j]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NZ; ++i)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float a0 = p[i][0][k], a1 = p[i][1][k];
-          q[i][0][k] = a0; q[i][1][k] = a0 + a1; q[i][2][k] = a0 - a1; q[i][3][k] = -a1;
+          const float yy[2] = {p[i][0][k], p[i][1][k]};
+          float col[4];
+          a2(yy, col);
+          q[i][0][k] = col[0]; q[i][1][k] = col[1]; q[i][2][k] = col[2]; q[i][3][k] = col[3];
         }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float a0 = q[0][j][k], a1 = q[1][j][k];
-          v[0][j][k] = a0; v[1][j][k] = a0 + a1; v[2][j][k] = a0 - a1; v[3][j][k] = -a1;
+          float yy[NZ], col[NI];
+#pragma unroll
+          for (int i = 0; i < NZ; ++i) yy[i] = q[i][j][k];
+          az<NZ>(yy, col);
+#pragma unroll
+          for (int i = 0; i < NI; ++i) v[i][j][k] = col[i];
         }
     }
     float* o = out + (long)t * C + c;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -173,10 +249,12 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 // TPB consecutive tiles x 64 channels; stats row = tile block.
 constexpr int WINO_TPB = 16;
 
+template <int NZ>
 __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ mh, const float* __restrict__ bias,
                                                        const float* __restrict__ add, const float* __restrict__ gate,
                                                        float* __restrict__ out, float* __restrict__ stats,
                                                        const WinoGeom g, const int N) {
+  constexpr int NI = NZ + 2;
   __shared__ float red[4][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cblks = N >> 6;
@@ -188,41 +266,43 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
   for (int q = wave; q < WINO_TPB; q += 4) {
     const int t = tb * WINO_TPB + q;
     if (t >= g.T) break;
-    float m[4][4][4];
+    float m[NI][4][4];
     const float* src = mh + (long)t * N + c;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) m[i][j][k] = src[((i * 4 + j) * 4 + k) * plane];
-    // A^T = [1 1 1 0; 0 1 -1 -1] along x, y, z
-    float p[4][4][2], q2[4][2][2], o[2][2][2];
+    float p[NI][4][2], q2[NI][2][2], o[NZ][2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        p[i][j][0] = m[i][j][0] + m[i][j][1] + m[i][j][2];
-        p[i][j][1] = m[i][j][1] - m[i][j][2] - m[i][j][3];
-      }
+      for (int j = 0; j < 4; ++j) at2(m[i][j], p[i][j]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        q2[i][0][k] = p[i][0][k] + p[i][1][k] + p[i][2][k];
-        q2[i][1][k] = p[i][1][k] - p[i][2][k] - p[i][3][k];
+        const float col[4] = {p[i][0][k], p[i][1][k], p[i][2][k], p[i][3][k]};
+        float r[2];
+        at2(col, r);
+        q2[i][0][k] = r[0]; q2[i][1][k] = r[1];
       }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        o[0][j][k] = q2[0][j][k] + q2[1][j][k] + q2[2][j][k];
-        o[1][j][k] = q2[1][j][k] - q2[2][j][k] - q2[3][j][k];
+        float col[NI], r[NZ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) col[i] = q2[i][j][k];
+        atz<NZ>(col, r);
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) o[i][j][k] = r[i];
       }
     int b, z0, y0, x0;
     tile_origin(g, t, b, z0, y0, x0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NZ; ++i) {
       const int z = z0 + i * g.d;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -258,20 +338,13 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// Weight transform  U = G w G^T (3-D), G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].
+// Weight transform  U = G w G^T (3-D).
 //   blockIdx.y == 0: uf[xi][co][ci]               (forward B operand, K = ci contiguous)
 //   blockIdx.y == 1: ub[xi][ci][co], taps flipped  (data-gradient B operand, K = co contiguous)
-__device__ __forceinline__ void g4(const float a0, const float a1, const float a2, float& r0, float& r1, float& r2,
-                                   float& r3) {
-  const float h = 0.5f * (a0 + a2);
-  r0 = a0;
-  r1 = h + 0.5f * a1;
-  r2 = h - 0.5f * a1;
-  r3 = a2;
-}
-
+template <int NZ>
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ uf,
                                                           float* __restrict__ ub, const int Cout, const int Cin) {
+  constexpr int NI = NZ + 2;
   const bool bwd = blockIdx.y == 1;
   float* dst = bwd ? ub : uf;
   if (!dst) return;
@@ -285,65 +358,82 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
   float gw[3][3][3];
 #pragma unroll
   for (int a = 0; a < 27; ++a) (&gw[0][0][0])[a] = src[bwd ? 26 - a : a];
-  float p[3][3][4], q[3][4][4], u[4][4][4];
+  float p[3][3][4], q[3][4][4], u[NI][4][4];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) g4(gw[a][b][0], gw[a][b][1], gw[a][b][2], p[a][b][0], p[a][b][1], p[a][b][2], p[a][b][3]);
+    for (int b = 0; b < 3; ++b) g2(gw[a][b], p[a][b]);
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) g4(p[a][0][k], p[a][1][k], p[a][2][k], q[a][0][k], q[a][1][k], q[a][2][k], q[a][3][k]);
+    for (int k = 0; k < 4; ++k) {
+      const float col[3] = {p[a][0][k], p[a][1][k], p[a][2][k]};
+      float r[4];
+      g2(col, r);
+      q[a][0][k] = r[0]; q[a][1][k] = r[1]; q[a][2][k] = r[2]; q[a][3][k] = r[3];
+    }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) g4(q[0][j][k], q[1][j][k], q[2][j][k], u[0][j][k], u[1][j][k], u[2][j][k], u[3][j][k]);
+    for (int k = 0; k < 4; ++k) {
+      const float col[3] = {q[0][j][k], q[1][j][k], q[2][j][k]};
+      float r[NI];
+      gz<NZ>(col, r);
 #pragma unroll
-  for (int a = 0; a < 64; ++a) dst[a * n + i] = (&u[0][0][0])[a];
+      for (int a = 0; a < NI; ++a) u[a][j][k] = r[a];
+    }
+#pragma unroll
+  for (int a = 0; a < NI * 16; ++a) dst[a * n + i] = (&u[0][0][0])[a];
 }
 
-// dw[co][ci][27] = G^T (sum over splits of slab[split][xi][co][ci]) G   (3-D), fixed order
-__device__ __forceinline__ void gt3(const float a0, const float a1, const float a2, const float a3, float& r0,
-                                    float& r1, float& r2) {
-  r0 = a0 + 0.5f * (a1 + a2);
-  r1 = 0.5f * (a1 - a2);
-  r2 = 0.5f * (a1 + a2) + a3;
-}
-
-// One workgroup = 64 (co, ci) elements x 16 point groups (1024 threads): every thread sums 4 of the
-// 64 points over the splits (coalesced over elements), then 64 threads apply G^T . G (3-D).
+// dw[co][ci][27] = G^T (sum over splits of slab[split][xi][co][ci]) G   (3-D), fixed order.
+// One workgroup = 64 (co, ci) elements x 16 point groups (1024 threads): every thread sums NI of the
+// NI*16 points over the splits (coalesced over elements), then 64 threads apply G^T . G (3-D).
+template <int NZ>
 __global__ __launch_bounds__(1024) void wino_wgrad_out_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                                const int Cout, const int Cin, const int nsplit) {
-  __shared__ float us[64][64];
+  constexpr int NI = NZ + 2, NP = NI * 16;
+  __shared__ float us[NP][64];
   const long n = (long)Cout * Cin;
   const int e = threadIdx.x & 63, gq = threadIdx.x >> 6;
   const long i = blockIdx.x * 64L + e;   // (co, ci), ci fastest
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int a = gq * 4 + j;
+  for (int j = 0; j < NI; ++j) {
+    const int a = gq * NI + j;
     float acc = 0.f;
     if (i < n)
-      for (int sp = 0; sp < nsplit; ++sp) acc += slab[((long)sp * 64 + a) * n + i];
+      for (int sp = 0; sp < nsplit; ++sp) acc += slab[((long)sp * NP + a) * n + i];
     us[a][e] = acc;
   }
   __syncthreads();
   if (gq != 0 || i >= n) return;
-  float s[4][4][4];
+  float s[NI][4][4];
 #pragma unroll
-  for (int a = 0; a < 64; ++a) (&s[0][0][0])[a] = us[a][e];
-  float p[4][4][3], q[4][3][3], r[3][3][3];
+  for (int a = 0; a < NP; ++a) (&s[0][0][0])[a] = us[a][e];
+  float p[NI][4][3], q[NI][3][3], r[3][3][3];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NI; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) gt3(s[a][b][0], s[a][b][1], s[a][b][2], s[a][b][3], p[a][b][0], p[a][b][1], p[a][b][2]);
+    for (int b = 0; b < 4; ++b) gt2(s[a][b], p[a][b]);
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NI; ++a)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) gt3(p[a][0][k], p[a][1][k], p[a][2][k], p[a][3][k], q[a][0][k], q[a][1][k], q[a][2][k]);
+    for (int k = 0; k < 3; ++k) {
+      const float col[4] = {p[a][0][k], p[a][1][k], p[a][2][k], p[a][3][k]};
+      float rr[3];
+      gt2(col, rr);
+      q[a][0][k] = rr[0]; q[a][1][k] = rr[1]; q[a][2][k] = rr[2];
+    }
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) gt3(q[0][j][k], q[1][j][k], q[2][j][k], q[3][j][k], r[0][j][k], r[1][j][k], r[2][j][k]);
+    for (int k = 0; k < 3; ++k) {
+      float col[NI], rr[3];
+#pragma unroll
+      for (int a = 0; a < NI; ++a) col[a] = q[a][j][k];
+      gtz<NZ>(col, rr);
+      r[0][j][k] = rr[0]; r[1][j][k] = rr[1]; r[2][j][k] = rr[2];
+    }
   float* dst = dw + i * 27;
 #pragma unroll
   for (int a = 0; a < 27; ++a) dst[a] = (&r[0][0][0])[a];
@@ -458,7 +548,8 @@ template <int WMW, int MI, int NJ>
 __global__ __launch_bounds__(512) void wino_gemm_tn_kernel(const float* __restrict__ Ah, const float* __restrict__ Bh,
                                                            float* __restrict__ slab, const int Tpad, const int M,
                                                            const int N, const int m_tiles, const int n_tiles,
-                                                           const int nsplit, const int kper, const int nblk) {
+                                                           const int nsplit, const int kper, const int nblk,
+                                                           const int npts) {
   constexpr int WNW = 8 / WMW;
   constexpr int BM = WMW * 32 * MI, BN = WNW * 32 * NJ;
   static_assert(BM % 64 == 0 && BM <= 256 && BN % 64 == 0 && BN <= 256, "one DMA piece = 256 floats");
@@ -535,7 +626,7 @@ __global__ __launch_bounds__(512) void wino_gemm_tn_kernel(const float* __restri
     }
   }
 
-  float* sb = slab + (((long)split * 64 + xi) * M + mt * BM) * N + nt * BN;
+  float* sb = slab + (((long)split * npts + xi) * M + mt * BM) * N + nt * BN;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -559,11 +650,24 @@ bool wino_geom_ok(const DramConvDesc* d) {
   return true;
 }
 
+// F(4,3) along z when the residue sub-lattice depth is a multiple of 4 (no extra padding) --
+// DRAM_WINO_NZ = 2 | 4 forces one (tests).
+int pick_nz(const DramConvDesc* d) {
+  if (const char* e = getenv("DRAM_WINO_NZ")) {
+    const int v = atoi(e);
+    if (v == 2 || v == 4) return v;
+  }
+  const int sz = (d->D + d->dil - 1) / d->dil;
+  return (sz % 4 == 0) ? 4 : 2;
+}
+
 WinoGeom make_geom(const DramConvDesc* d) {
   WinoGeom g{};
   g.B = d->B; g.D = d->D; g.H = d->H; g.W = d->W; g.d = d->dil;
-  auto tiles = [&](int n) { return ((n + g.d - 1) / g.d + 1) / 2; };
-  g.Tz = tiles(g.D); g.Ty = tiles(g.H); g.Tx = tiles(g.W);
+  g.nz = pick_nz(d);
+  g.npts = (g.nz + 2) * 16;
+  auto tiles = [&](int n, int per) { return ((n + g.d - 1) / g.d + per - 1) / per; };
+  g.Tz = tiles(g.D, g.nz); g.Ty = tiles(g.H, 2); g.Tx = tiles(g.W, 2);
   const long long T = (long long)g.B * g.d * g.d * g.d * g.Tz * g.Ty * g.Tx;
   g.T = (int)T;
   g.Tpad = (int)((T + 255) / 256 * 256);
@@ -596,7 +700,7 @@ bool plan_tn(const DramConvDesc* d, const WinoGeom& g, TnPlan& p) {
   }
   p.m_tiles = M / p.bm;
   p.n_tiles = (N + p.bn - 1) / p.bn;
-  const int base = 64 * p.m_tiles * p.n_tiles;
+  const int base = g.npts * p.m_tiles * p.n_tiles;
   const int k32 = g.Tpad / 32;
   int ns = 1;
   while (base * ns < 512 && ns * 2 <= k32 / 4 && ns < 16) ns *= 2;
@@ -613,7 +717,7 @@ int grid_for(long waves) {
 int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, int K, hipStream_t s) {
   const int nj = nj_for(N);
   const int m_tiles = g.Tpad / 256, n_tiles = N / (64 * nj);
-  const int nblk = 64 * m_tiles * n_tiles;
+  const int nblk = g.npts * m_tiles * n_tiles;
 #define WNN(NJ_) \
   hipLaunchKernelGGL((wino_gemm_nn_kernel<NJ_>), dim3(nblk), dim3(512), 0, s, A, U, Y, g.Tpad, N, K, m_tiles, n_tiles, nblk)
   if (nj == 4) WNN(4);
@@ -629,16 +733,22 @@ int run_conv(const float* in, const float* U, const float* bias, const float* ad
              float* stats, float* v_keep, const DramConvDesc* d, int K, int N, void* ws, size_t ws_bytes,
              hipStream_t s) {
   const WinoGeom g = make_geom(d);
-  const size_t need = (size_t)64 * g.Tpad * ((size_t)K + N) * sizeof(float);
+  const size_t need = (size_t)g.npts * g.Tpad * ((size_t)K + N) * sizeof(float);
   if (!ws || ws_bytes < need) return DRAM_ERR_WORKSPACE;
   float* V = v_keep ? v_keep : (float*)ws;          // kept for the weight gradient when the caller asks
-  float* Mh = (float*)ws + (size_t)64 * g.Tpad * K;
-  hipLaunchKernelGGL((wino_in_kernel<0>), dim3(grid_for((long)g.Tpad * (K / 64))), dim3(256), 0, s, in, V, g, K);
+  float* Mh = (float*)ws + (size_t)g.npts * g.Tpad * K;
+  if (g.nz == 4)
+    hipLaunchKernelGGL((wino_in_kernel<0, 4>), dim3(grid_for((long)g.Tpad * (K / 64))), dim3(256), 0, s, in, V, g, K);
+  else
+    hipLaunchKernelGGL((wino_in_kernel<0, 2>), dim3(grid_for((long)g.Tpad * (K / 64))), dim3(256), 0, s, in, V, g, K);
   DRAM_LAUNCH_CHECK();
   const int rc = run_nn(V, U, Mh, g, N, K, s);
   if (rc != DRAM_OK) return rc;
   const int ntb = (g.T + WINO_TPB - 1) / WINO_TPB;
-  hipLaunchKernelGGL(wino_out_kernel, dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add, gate, out, stats, g, N);
+  if (g.nz == 4)
+    hipLaunchKernelGGL(wino_out_kernel<4>, dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add, gate, out, stats, g, N);
+  else
+    hipLaunchKernelGGL(wino_out_kernel<2>, dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add, gate, out, stats, g, N);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
@@ -664,11 +774,12 @@ static double fill(double wgs, double slots) {
   const double rounds = (double)(long)((wgs + slots - 1.0) / slots);
   return wgs / (rounds * slots);
 }
-static double wino_cost_per_voxel(double K, double N, double tpad) {
+// per voxel of the padded tile grid; pv = Winograd points per output voxel (8 for F(2,3)^3, 6 with F(4,3) along z)
+static double wino_cost_per_voxel(double K, double N, double tpad, double npts, double pv) {
   const double nt = (double)(long)((N + 255.0) / 256.0);           // 256-column GEMM tiles (fewer columns: one tile)
-  const double gemm = 16.0 * K * N / (118e12 * fill(64.0 * (tpad / 256.0) * nt, 256.0));
-  const double traffic = 32.0 * (K + N) / 4.7e12;
-  return 36.0 * K / 4.9e12 + (gemm > traffic ? gemm : traffic) + 36.0 * N / 3.4e12;
+  const double gemm = 2.0 * pv * K * N / (118e12 * fill(npts * (tpad / 256.0) * nt, 256.0));
+  const double traffic = 4.0 * pv * (K + N) / 4.7e12;
+  return (4.0 + 4.0 * pv) * K / 4.9e12 + (gemm > traffic ? gemm : traffic) + (4.0 + 4.0 * pv) * N / 3.4e12;
 }
 // direct implicit GEMM: 8x8x8 / 4x8x8 output tiles x 64..256 columns, two workgroups per CU
 static double direct_rate(const DramConvDesc* d, double N) {
@@ -693,11 +804,11 @@ extern "C" int dram_conv_algo(const DramConvDesc* d) {
   if (w3) {
     const WinoGeom g = make_geom(d);
     if (g.T >= 128) {
-      const double vpad = 8.0 * g.Tpad;
+      const double vpad = 4.0 * g.nz * g.Tpad, pv = g.npts / (4.0 * g.nz);
       const double direct = vox * 54.0 * d->Cin * d->Cout * 0.5 *
                             (1.0 / direct_rate(d, d->Cout) + 1.0 / direct_rate(d, d->Cin));
-      const double wino = vpad * 0.5 * (wino_cost_per_voxel(d->Cin, d->Cout, g.Tpad) +
-                                        wino_cost_per_voxel(d->Cout, d->Cin, g.Tpad));
+      const double wino = vpad * 0.5 * (wino_cost_per_voxel(d->Cin, d->Cout, g.Tpad, g.npts, pv) +
+                                        wino_cost_per_voxel(d->Cout, d->Cin, g.Tpad, g.npts, pv));
       if (wino < 0.92 * direct) { best = wino; pick = 1; }
     }
   }
@@ -735,12 +846,12 @@ extern "C" int dram_conv_wgrad_algo(const DramConvDesc* d) {
   if (w3) {
     const WinoGeom g = make_geom(d);
     if (g.T >= 128) {
-      const double vpad = 8.0 * g.Tpad;
+      const double vpad = 4.0 * g.nz * g.Tpad, pv = g.npts / (4.0 * g.nz);
       TnPlan tp;
       plan_tn(d, g, tp);
-      const double wgs = 64.0 * tp.m_tiles * tp.n_tiles * tp.nsplit;
-      const double gemm = 16.0 * K * N / (125e12 * fill(wgs, 256.0)), traffic = 32.0 * (K + N) / 4.7e12;
-      const double wino = vpad * (36.0 * (K + N) / 4.9e12 + (gemm > traffic ? gemm : traffic));
+      const double wgs = (double)g.npts * tp.m_tiles * tp.n_tiles * tp.nsplit;
+      const double gemm = 2.0 * pv * K * N / (125e12 * fill(wgs, 256.0)), traffic = 4.0 * pv * (K + N) / 4.7e12;
+      const double wino = vpad * ((4.0 + 4.0 * pv) * (K + N) / 4.9e12 + (gemm > traffic ? gemm : traffic));
       // the direct weight gradient splits over voxel chunks, so it keeps the chip full down to ~16k voxels
       const double dfill = vox >= 16384.0 ? 1.0 : vox / 16384.0;
       if (wino < 0.85 * direct / dfill) { best = wino; pick = 1; }
@@ -753,11 +864,21 @@ extern "C" int dram_conv_wgrad_algo(const DramConvDesc* d) {
   return pick;
 }
 
-extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, int Cout, int Cin, dram_stream_t stream) {
-  if (!w || (!uf && !ub) || Cout < 1 || Cin < 1) return DRAM_ERR_BAD_ARG;
-  const long n = (long)Cout * Cin;
-  hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream, w, uf,
-                     ub, Cout, Cin);
+extern "C" int dram_wino_num_points(const DramConvDesc* d) {
+  if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
+  return make_geom(d).npts;
+}
+
+extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, const DramConvDesc* d,
+                                     dram_stream_t stream) {
+  if (!w || (!uf && !ub)) return DRAM_ERR_BAD_ARG;
+  if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
+  const long n = (long)d->Cout * d->Cin;
+  const dim3 grid((unsigned)((n + 255) / 256), 2);
+  if (pick_nz(d) == 4)
+    hipLaunchKernelGGL(wino_weight_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, w, uf, ub, d->Cout, d->Cin);
+  else
+    hipLaunchKernelGGL(wino_weight_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, w, uf, ub, d->Cout, d->Cin);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
@@ -772,11 +893,11 @@ extern "C" int dram_wino_num_stat_rows(const DramConvDesc* d) {
 extern "C" size_t dram_wino_workspace(const DramConvDesc* d, int pass) {
   if (!dram_wino_applicable(d) || pass < 0 || pass > 2) return 0;
   const WinoGeom g = make_geom(d);
-  size_t n = (size_t)64 * g.Tpad * ((size_t)d->Cin + d->Cout);
+  size_t n = (size_t)g.npts * g.Tpad * ((size_t)d->Cin + d->Cout);
   if (pass == 2) {
     TnPlan p;
     if (!plan_tn(d, g, p)) return 0;
-    n += (size_t)p.nsplit * 64 * d->Cout * d->Cin;
+    n += (size_t)p.nsplit * g.npts * d->Cout * d->Cin;
   }
   return n * sizeof(float);
 }
@@ -792,7 +913,8 @@ extern "C" int dram_wino_conv3d_fwd(const float* x, const float* uf, const float
 
 extern "C" size_t dram_wino_v_elems(const DramConvDesc* d) {
   if (!dram_wino_applicable(d)) return 0;
-  return (size_t)64 * make_geom(d).Tpad * (size_t)d->Cin;
+  const WinoGeom g = make_geom(d);
+  return (size_t)g.npts * g.Tpad * (size_t)d->Cin;
 }
 
 extern "C" int dram_wino_conv3d_bwd_data(const float* dy, const float* ub, float* dx, const float* add,
@@ -816,21 +938,29 @@ extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache,
   if (!workspace || workspace_bytes < need) return DRAM_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   float* V = (float*)workspace;                               // [64][Tpad][Cin]
-  float* Dh = V + (size_t)64 * g.Tpad * d->Cin;               // [64][Tpad][Cout]
-  float* slab = Dh + (size_t)64 * g.Tpad * d->Cout;           // [nsplit][64][Cout][Cin]
+  float* Dh = V + (size_t)g.npts * g.Tpad * d->Cin;           // [npts][Tpad][Cout]
+  float* slab = Dh + (size_t)g.npts * g.Tpad * d->Cout;       // [nsplit][npts][Cout][Cin]
   if (v_cache) V = const_cast<float*>(v_cache);
   else {
-    hipLaunchKernelGGL((wino_in_kernel<0>), dim3(grid_for((long)g.Tpad * (d->Cin / 64))), dim3(256), 0, s, x, V, g,
-                       d->Cin);
+    if (g.nz == 4)
+      hipLaunchKernelGGL((wino_in_kernel<0, 4>), dim3(grid_for((long)g.Tpad * (d->Cin / 64))), dim3(256), 0, s, x, V, g,
+                         d->Cin);
+    else
+      hipLaunchKernelGGL((wino_in_kernel<0, 2>), dim3(grid_for((long)g.Tpad * (d->Cin / 64))), dim3(256), 0, s, x, V, g,
+                         d->Cin);
     DRAM_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL((wino_in_kernel<1>), dim3(grid_for((long)g.Tpad * (d->Cout / 64))), dim3(256), 0, s, dy, Dh, g,
-                     d->Cout);
+  if (g.nz == 4)
+    hipLaunchKernelGGL((wino_in_kernel<1, 4>), dim3(grid_for((long)g.Tpad * (d->Cout / 64))), dim3(256), 0, s, dy, Dh, g,
+                       d->Cout);
+  else
+    hipLaunchKernelGGL((wino_in_kernel<1, 2>), dim3(grid_for((long)g.Tpad * (d->Cout / 64))), dim3(256), 0, s, dy, Dh, g,
+                       d->Cout);
   DRAM_LAUNCH_CHECK();
-  const int nblk = 64 * p.nsplit * p.m_tiles * p.n_tiles;
+  const int nblk = g.npts * p.nsplit * p.m_tiles * p.n_tiles;
 #define WTN(WM_, MI_, NJ_)                                                                                       \
   hipLaunchKernelGGL((wino_gemm_tn_kernel<WM_, MI_, NJ_>), dim3(nblk), dim3(512), 0, s, Dh, V, slab, g.Tpad, d->Cout, \
-                     d->Cin, p.m_tiles, p.n_tiles, p.nsplit, p.kper, nblk)
+                     d->Cin, p.m_tiles, p.n_tiles, p.nsplit, p.kper, nblk, g.npts)
   if (p.bm == 256 && p.bn == 256) WTN(4, 2, 4);
   else if (p.bm == 256 && p.bn == 128) WTN(4, 2, 2);
   else if (p.bm == 256 && p.bn == 64) WTN(4, 2, 1);
@@ -842,8 +972,12 @@ extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache,
 #undef WTN
   DRAM_LAUNCH_CHECK();
   const long n = (long)d->Cout * d->Cin;
-  hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, s, slab, dw, d->Cout,
-                     d->Cin, p.nsplit);
+  if (g.nz == 4)
+    hipLaunchKernelGGL(wino_wgrad_out_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, s, slab, dw, d->Cout,
+                       d->Cin, p.nsplit);
+  else
+    hipLaunchKernelGGL(wino_wgrad_out_kernel<2>, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, s, slab, dw, d->Cout,
+                       d->Cin, p.nsplit);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

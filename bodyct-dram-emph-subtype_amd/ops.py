@@ -195,12 +195,12 @@ def conv_use_wino(g: "ConvGeom") -> bool:
     return conv_algo(g) == 1
 
 
-_PACKED_TAPS = {0: None, 1: 64, 2: 48}
-
-
 def packed_taps(g: "ConvGeom") -> int:
-    t = _PACKED_TAPS[conv_algo(g)]
-    return g.taps if t is None else t
+    """Leading dimension of the packed weights the library's plan expects for g."""
+    algo = conv_algo(g)
+    if algo == 1:
+        return int(_L().dram_wino_num_points(ctypes.byref(g.desc())))
+    return 48 if algo == 2 else g.taps
 
 
 def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True, g: Optional["ConvGeom"] = None
@@ -211,11 +211,12 @@ def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True, g: Optional["ConvG
     Cout, Cin = w.shape[0], w.shape[1]
     taps = w.shape[2] * w.shape[3] * w.shape[4]
     algo = conv_algo(g) if g is not None else 0
-    pt = {0: taps, 1: 64, 2: 48}[algo]
+    pt = packed_taps(g) if g is not None else taps
     wf = torch.empty((pt, Cout, Cin), device=w.device, dtype=torch.float32) if want_fwd else None
     wb = torch.empty((pt, Cin, Cout), device=w.device, dtype=torch.float32) if want_bwd else None
     if algo == 1:
-        _chk(_L().dram_wino_pack_weight(_p(w), _p(wf), _p(wb), Cout, Cin, _stream()), "dram_wino_pack_weight")
+        _chk(_L().dram_wino_pack_weight(_p(w), _p(wf), _p(wb), ctypes.byref(g.desc()), _stream()),
+             "dram_wino_pack_weight")
     elif algo == 2:
         _chk(_L().dram_wino2d_pack_weight(_p(w), _p(wf), _p(wb), Cout, Cin, _stream()), "dram_wino2d_pack_weight")
     else:

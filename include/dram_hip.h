@@ -92,7 +92,9 @@ int dram_conv_num_mtiles(const DramConvDesc* desc);
  *   dram_conv_wgrad_algo: plan for the WEIGHT gradient of desc, decided separately from
  *                         dram_conv_algo: 0 direct (dram_conv3d_bwd_weight), 1 this pipeline,
  *                         2 in-plane Winograd z-walking kernel (dram_wgrad_w2d).
- *   dram_wino_pack_weight: w [Cout][Cin][27] -> uf [64][Cout][Cin], ub [64][Cin][Cout]
+ *   dram_wino_num_points: P = Winograd points of desc's tiling: 64 (F(2,3) on every axis) or 96
+ *                         (F(4,3) along z when the sub-lattice depth is a multiple of 4).
+ *   dram_wino_pack_weight: w [Cout][Cin][27] -> uf [P][Cout][Cin], ub [P][Cin][Cout]
  *                         (taps flipped, data-gradient operand); either may be NULL.
  *   dram_wino_workspace(desc, pass): bytes for pass 0 forward, 1 data gradient, 2 weight
  *                         gradient (0 when unsupported).
@@ -103,7 +105,8 @@ int dram_conv_num_mtiles(const DramConvDesc* desc);
  * Deterministic (no atomics; the weight gradient sums its slabs in a fixed order). */
 int dram_wino_applicable(const DramConvDesc* desc);
 int dram_conv_wgrad_algo(const DramConvDesc* desc);
-int dram_wino_pack_weight(const float* w, float* uf, float* ub, int Cout, int Cin, dram_stream_t stream);
+int dram_wino_num_points(const DramConvDesc* desc);
+int dram_wino_pack_weight(const float* w, float* uf, float* ub, const DramConvDesc* desc, dram_stream_t stream);
 size_t dram_wino_workspace(const DramConvDesc* desc, int pass);
 int dram_wino_num_stat_rows(const DramConvDesc* desc);
 size_t dram_wino_v_elems(const DramConvDesc* desc);

@@ -152,12 +152,14 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize("nz", ["2", "4"], ids=["F(2,3)z", "F(4,3)z"])
 @pytest.mark.parametrize("case", WINO_CASES, ids=[str(c) for c in WINO_CASES])
-def test_conv3d_winograd_path(ops, monkeypatch, case):
+def test_conv3d_winograd_path(ops, monkeypatch, case, nz):
     """Winograd F(2x2x2,3x3x3) pipeline (tile transforms + batched NN / TN GEMMs) against
     F.conv3d and its autograd: forward with bias + fused BN sums, data gradient with the fused
     shortcut-gradient epilogue, weight gradient."""
     monkeypatch.setenv("DRAM_CONV_ALGO", "2")
+    monkeypatch.setenv("DRAM_WINO_NZ", nz)            # tile depth 2 (F(2,3) along z) or 4 (F(4,3) along z)
     B, D, H, W, Cin, Cout, dil = case
     x = rnd(B, Cin, D, H, W, seed=1).requires_grad_(True)
     w = (rnd(Cout, Cin, 3, 3, 3, seed=2) * 0.1).requires_grad_(True)
@@ -168,7 +170,8 @@ def test_conv3d_winograd_path(ops, monkeypatch, case):
     g = ops.ConvGeom(B, D, H, W, Cin, Cout, 3, 1, dil, dil)
     assert ops.conv_use_wino(g)
     wf, wb = ops.pack_conv_weight(w.detach().to(DEV), True, True, g)
-    assert wf.shape == (64, Cout, Cin) and wb.shape == (64, Cin, Cout)
+    npts = 16 * (int(nz) + 2)
+    assert wf.shape == (npts, Cout, Cin) and wb.shape == (npts, Cin, Cout)
     xd, gyd = to_ndhwc(x.detach()), to_ndhwc(gy)
     y, stats = ops.conv3d_fwd(xd, wf, bias.to(DEV), g, True)
     assert rel_l2(to_ncdhw(y), y_ref.detach()) < 1e-5
