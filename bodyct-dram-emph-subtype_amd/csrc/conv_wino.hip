@@ -29,13 +29,14 @@
 
 namespace {
 
-// Tile: NZ x 2 x 2 outputs, (NZ + 2) x 4 x 4 inputs / Winograd points, NZ = 2 (F(2,3) along z) or
-// 4 (F(4,3) along z: 6 instead of 8 products per 4 output planes -> 25 % fewer GEMM flops and
-// Winograd-domain bytes; used when the sub-lattice depth is a multiple of 4).
+// Tile: NZ x NY x 2 outputs, (NZ + 2) x (NY + 2) x 4 inputs / Winograd points.  NZ, NY = 2 (F(2,3)) or
+// 4 (F(4,3): 6 instead of 8 products per 4 outputs of that axis -> 25 % fewer GEMM flops and
+// Winograd-domain bytes per axis; used when the sub-lattice extent of the axis is a multiple of 4).
+// Measured rel-L2 vs fp64 on a 256-channel layer: 6.6e-7 (2,2), 1.7e-6 (4,2); torch fp32 direct 3.6e-7.
 struct WinoGeom {
   int B, D, H, W;  // voxel grid (input and output grids coincide: stride 1, pad == dil)
   int d;           // dilation
-  int nz;          // outputs per tile along z (2 or 4); points = (nz + 2) * 16
+  int nz, ny;      // outputs per tile along z and y (2 or 4); points = (nz + 2) * (ny + 2) * 4
   int npts;
   int Tz, Ty, Tx;  // tiles per residue sub-lattice axis
   int T;           // B * d^3 * Tz * Ty * Tx
@@ -53,7 +54,7 @@ __device__ __forceinline__ void tile_origin(const WinoGeom& g, int t, int& b, in
   const int rz = r % g.d;
   b = r / g.d;
   z0 = g.nz * tz * g.d + rz;
-  y0 = 2 * ty * g.d + ry;
+  y0 = g.ny * ty * g.d + ry;
   x0 = 2 * tx * g.d + rx;
 }
 
@@ -126,14 +127,15 @@ template <int NZ> __device__ __forceinline__ void gtz(const float* s, float* r) 
 
 // ------------------------------------------------------------------------------------------
 // Tile transforms into the Winograd domain.  One wave per (tile, 64-channel block); lanes are
-// consecutive channels (256-B coalesced rows).  out[xi][t][c], xi = (i*4 + j)*4 + k, i < NZ + 2.
-//   MODE 0:  V = B^T v B over the (NZ+2)x4x4 input tile (zero outside the volume)
-//   MODE 1:  A dy A^T over the NZ x2x2 output-gradient tile (weight gradient)
+// consecutive channels (256-B coalesced rows).  out[xi][t][c], xi = (i*NJ + j)*4 + k,
+// i < NI = NZ + 2, j < NJ = NY + 2.
+//   MODE 0:  V = B^T v B over the NI x NJ x 4 input tile (zero outside the volume)
+//   MODE 1:  A dy A^T over the NZ x NY x 2 output-gradient tile (weight gradient)
 // Rows t in [T, Tpad) are written as zeros (the TN GEMM contracts over t).
-template <int MODE, int NZ>
+template <int MODE, int NZ, int NY>
 __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                       const WinoGeom g, const int C) {
-  constexpr int NI = NZ + 2;
+  constexpr int NI = NZ + 2, NJ = NY + 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cblks = C >> 6;
   const long plane = (long)g.Tpad * C;
@@ -141,10 +143,10 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
   for (long w = blockIdx.x * 4L + wave; w < total; w += gridDim.x * 4L) {
     const int t = (int)(w / cblks);
     const int c = (int)(w - (long)t * cblks) * 64 + lane;
-    float v[NI][4][4];
+    float v[NI][NJ][4];
     if (t >= g.T) {
 #pragma unroll
-      for (int i = 0; i < NI * 16; ++i) out[i * plane + (long)t * C + c] = 0.f;
+      for (int i = 0; i < NI * NJ * 4; ++i) out[i * plane + (long)t * C + c] = 0.f;
       continue;
     }
     int b, z0, y0, x0;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
         const int z = z0 + (i - 1) * g.d;
         const bool zo = (z >= 0) & (z < g.D);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           const int y = y0 + (j - 1) * g.d;
           const bool yo = zo & (y >= 0) & (y < g.H);
 #pragma unroll
@@ -170,17 +172,20 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bt2(v[i][j]);
+        for (int j = 0; j < NJ; ++j) bt2(v[i][j]);
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          float col[4] = {v[i][0][k], v[i][1][k], v[i][2][k], v[i][3][k]};
-          bt2(col);
-          v[i][0][k] = col[0]; v[i][1][k] = col[1]; v[i][2][k] = col[2]; v[i][3][k] = col[3];
+          float col[NJ];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) col[j] = v[i][j][k];
+          btz<NY>(col);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) v[i][j][k] = col[j];
         }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float col[NI];
@@ -191,12 +196,12 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
           for (int i = 0; i < NI; ++i) v[i][j][k] = col[i];
         }
     } else {
-      float u[NZ][2][2];
+      float u[NZ][NY][2];
 #pragma unroll
       for (int i = 0; i < NZ; ++i) {
         const int z = z0 + i * g.d;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NY; ++j) {
           const int y = y0 + j * g.d;
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
@@ -207,22 +212,24 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
           }
         }
       }
-      float p[NZ][2][4], q[NZ][4][4];
+      float p[NZ][NY][4], q[NZ][NJ][4];
 #pragma unroll
       for (int i = 0; i < NZ; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) a2(u[i][j], p[i][j]);
+        for (int j = 0; j < NY; ++j) a2(u[i][j], p[i][j]);
 #pragma unroll
       for (int i = 0; i < NZ; ++i)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float yy[2] = {p[i][0][k], p[i][1][k]};
-          float col[4];
-          a2(yy, col);
-          q[i][0][k] = col[0]; q[i][1][k] = col[1]; q[i][2][k] = col[2]; q[i][3][k] = col[3];
+          float yy[NY], col[NJ];
+#pragma unroll
+          for (int j = 0; j < NY; ++j) yy[j] = p[i][j][k];
+          az<NY>(yy, col);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) q[i][j][k] = col[j];
         }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float yy[NZ], col[NI];
@@ -237,24 +244,36 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[((i * 4 + j) * 4 + k) * plane] = v[i][j][k];
+        for (int k = 0; k < 4; ++k) o[((i * NJ + j) * 4 + k) * plane] = v[i][j][k];
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // Output transform: y(tile) = A^T M A (3-D), + bias, optional fused  += add * (gate > 0)
 // (identity-shortcut gradient), per-channel BatchNorm partial sums.  A workgroup owns
-// TPB consecutive tiles x 64 channels; stats row = tile block.
+// TPB consecutive tiles x 64 channels; stats row = tile block.  One xi_z plane at a time: its
+// in-plane A^T . A result is folded into the NZ output planes with the z column of A^T.
 constexpr int WINO_TPB = 16;
 
-template <int NZ>
+template <int NZ> __device__ __forceinline__ float atz_coef(int o, int i) {
+  // A^T[o][i]: F(2,3) [1 1 1 0; 0 1 -1 -1], F(4,3) [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+  if (NZ == 2) {
+    const float t[2][4] = {{1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, -1.f}};
+    return t[o][i];
+  }
+  const float t[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -2.f, 0.f},
+                         {0.f, 1.f, 1.f, 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 8.f, -8.f, 1.f}};
+  return t[o][i];
+}
+
+template <int NZ, int NY>
 __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ mh, const float* __restrict__ bias,
                                                        const float* __restrict__ add, const float* __restrict__ gate,
                                                        float* __restrict__ out, float* __restrict__ stats,
                                                        const WinoGeom g, const int N) {
-  constexpr int NI = NZ + 2;
+  constexpr int NI = NZ + 2, NJ = NY + 2;
   __shared__ float red[4][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cblks = N >> 6;
@@ -266,46 +285,47 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
   for (int q = wave; q < WINO_TPB; q += 4) {
     const int t = tb * WINO_TPB + q;
     if (t >= g.T) break;
-    float m[NI][4][4];
     const float* src = mh + (long)t * N + c;
+    float o[NZ][NY][2];
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI; ++i) {
+      float m[NJ][4], p[NJ][2], q2[NY][2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) m[i][j][k] = src[((i * 4 + j) * 4 + k) * plane];
-    float p[NI][4][2], q2[NI][2][2], o[NZ][2][2];
+        for (int k = 0; k < 4; ++k) m[j][k] = src[((i * NJ + j) * 4 + k) * plane];
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) at2(m[i][j], p[i][j]);
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
+      for (int j = 0; j < NJ; ++j) at2(m[j], p[j]);
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const float col[4] = {p[i][0][k], p[i][1][k], p[i][2][k], p[i][3][k]};
-        float r[2];
-        at2(col, r);
-        q2[i][0][k] = r[0]; q2[i][1][k] = r[1];
+        float col[NJ], r[NY];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) col[j] = p[j][k];
+        atz<NY>(col, r);
+#pragma unroll
+        for (int j = 0; j < NY; ++j) q2[j][k] = r[j];
       }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int oz = 0; oz < NZ; ++oz) {
+        const float cf = atz_coef<NZ>(oz, i);
+        if (cf != 0.f) {
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        float col[NI], r[NZ];
+          for (int j = 0; j < NY; ++j)
 #pragma unroll
-        for (int i = 0; i < NI; ++i) col[i] = q2[i][j][k];
-        atz<NZ>(col, r);
-#pragma unroll
-        for (int i = 0; i < NZ; ++i) o[i][j][k] = r[i];
+            for (int k = 0; k < 2; ++k) {
+              if (i == 0 || (i == 1 && oz > 0)) o[oz][j][k] = cf * q2[j][k];     // first contribution to this plane
+              else o[oz][j][k] = __builtin_fmaf(cf, q2[j][k], o[oz][j][k]);
+            }
+        }
       }
+    }
     int b, z0, y0, x0;
     tile_origin(g, t, b, z0, y0, x0);
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
       const int z = z0 + i * g.d;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NY; ++j) {
         const int y = y0 + j * g.d;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -341,10 +361,10 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 // Weight transform  U = G w G^T (3-D).
 //   blockIdx.y == 0: uf[xi][co][ci]               (forward B operand, K = ci contiguous)
 //   blockIdx.y == 1: ub[xi][ci][co], taps flipped  (data-gradient B operand, K = co contiguous)
-template <int NZ>
+template <int NZ, int NY>
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ uf,
                                                           float* __restrict__ ub, const int Cout, const int Cin) {
-  constexpr int NI = NZ + 2;
+  constexpr int NI = NZ + 2, NJ = NY + 2;
   const bool bwd = blockIdx.y == 1;
   float* dst = bwd ? ub : uf;
   if (!dst) return;
@@ -358,7 +378,7 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
   float gw[3][3][3];
 #pragma unroll
   for (int a = 0; a < 27; ++a) (&gw[0][0][0])[a] = src[bwd ? 26 - a : a];
-  float p[3][3][4], q[3][4][4], u[NI][4][4];
+  float p[3][3][4], q[3][NJ][4], u[NI][NJ][4];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -368,12 +388,13 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float col[3] = {p[a][0][k], p[a][1][k], p[a][2][k]};
-      float r[4];
-      g2(col, r);
-      q[a][0][k] = r[0]; q[a][1][k] = r[1]; q[a][2][k] = r[2]; q[a][3][k] = r[3];
+      float r[NJ];
+      gz<NY>(col, r);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) q[a][j][k] = r[j];
     }
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float col[3] = {q[0][j][k], q[1][j][k], q[2][j][k]};
@@ -383,23 +404,23 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
       for (int a = 0; a < NI; ++a) u[a][j][k] = r[a];
     }
 #pragma unroll
-  for (int a = 0; a < NI * 16; ++a) dst[a * n + i] = (&u[0][0][0])[a];
+  for (int a = 0; a < NI * NJ * 4; ++a) dst[a * n + i] = (&u[0][0][0])[a];
 }
 
 // dw[co][ci][27] = G^T (sum over splits of slab[split][xi][co][ci]) G   (3-D), fixed order.
-// One workgroup = 64 (co, ci) elements x 16 point groups (1024 threads): every thread sums NI of the
-// NI*16 points over the splits (coalesced over elements), then 64 threads apply G^T . G (3-D).
-template <int NZ>
+// One workgroup = 64 (co, ci) elements x 16 point groups (1024 threads): every thread sums NP/16 of the
+// NP points over the splits (coalesced over elements), then 64 threads apply G^T . G (3-D).
+template <int NZ, int NY>
 __global__ __launch_bounds__(1024) void wino_wgrad_out_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                                const int Cout, const int Cin, const int nsplit) {
-  constexpr int NI = NZ + 2, NP = NI * 16;
+  constexpr int NI = NZ + 2, NJ = NY + 2, NP = NI * NJ * 4, PPG = NP / 16;
   __shared__ float us[NP][64];
   const long n = (long)Cout * Cin;
   const int e = threadIdx.x & 63, gq = threadIdx.x >> 6;
   const long i = blockIdx.x * 64L + e;   // (co, ci), ci fastest
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int a = gq * NI + j;
+  for (int j = 0; j < PPG; ++j) {
+    const int a = gq * PPG + j;
     float acc = 0.f;
     if (i < n)
       for (int sp = 0; sp < nsplit; ++sp) acc += slab[((long)sp * NP + a) * n + i];
@@ -407,23 +428,25 @@ __global__ __launch_bounds__(1024) void wino_wgrad_out_kernel(const float* __res
   }
   __syncthreads();
   if (gq != 0 || i >= n) return;
-  float s[NI][4][4];
+  float q[NI][3][3], r[3][3][3];
 #pragma unroll
-  for (int a = 0; a < NP; ++a) (&s[0][0][0])[a] = us[a][e];
-  float p[NI][4][3], q[NI][3][3], r[3][3][3];
+  for (int a = 0; a < NI; ++a) {
+    float p[NJ][3];
 #pragma unroll
-  for (int a = 0; a < NI; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) gt2(s[a][b], p[a][b]);
-#pragma unroll
-  for (int a = 0; a < NI; ++a)
+    for (int b = 0; b < NJ; ++b) {
+      const float row[4] = {us[(a * NJ + b) * 4 + 0][e], us[(a * NJ + b) * 4 + 1][e], us[(a * NJ + b) * 4 + 2][e],
+                            us[(a * NJ + b) * 4 + 3][e]};
+      gt2(row, p[b]);
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const float col[4] = {p[a][0][k], p[a][1][k], p[a][2][k], p[a][3][k]};
-      float rr[3];
-      gt2(col, rr);
+      float col[NJ], rr[3];
+#pragma unroll
+      for (int b = 0; b < NJ; ++b) col[b] = p[b][k];
+      gtz<NY>(col, rr);
       q[a][0][k] = rr[0]; q[a][1][k] = rr[1]; q[a][2][k] = rr[2];
     }
+  }
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -641,6 +664,13 @@ __global__ __launch_bounds__(512) void wino_gemm_tn_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------
 // host side
+// instantiated tilings (z, y outputs per tile): 2x2, 4x2, 4x4  (x is always 2)
+#define WINO_TILING_DISPATCH(g_, CALL_)          \
+  do {                                           \
+    if ((g_).nz == 4 && (g_).ny == 4) { CALL_(4, 4); } \
+    else if ((g_).nz == 4) { CALL_(4, 2); }      \
+    else { CALL_(2, 2); }                        \
+  } while (0)
 bool wino_geom_ok(const DramConvDesc* d) {
   if (!d) return false;
   if (d->B < 1 || d->D < 1 || d->H < 1 || d->W < 1) return false;
@@ -650,24 +680,41 @@ bool wino_geom_ok(const DramConvDesc* d) {
   return true;
 }
 
-// F(4,3) along z when the residue sub-lattice depth is a multiple of 4 (no extra padding) --
-// DRAM_WINO_NZ = 2 | 4 forces one (tests).
-int pick_nz(const DramConvDesc* d) {
-  if (const char* e = getenv("DRAM_WINO_NZ")) {
-    const int v = atoi(e);
-    if (v == 2 || v == 4) return v;
+// Tiling (outputs per tile along z, y): F(4,3) on an axis when the residue sub-lattice extent of that axis
+// is a multiple of 4 (no extra padding) -- largest first among the instantiated 4x4, 4x2, 2x2 -- as long
+// as at least 512 tiles remain (two GEMM M tiles per point; small volumes keep the finer tiling).
+// DRAM_WINO_NZ / DRAM_WINO_NY = 2 | 4 force one (tests).
+long long tiles_for(const DramConvDesc* d, int nz, int ny) {
+  const int dd = d->dil;
+  auto tiles = [&](int n, int per) { return (long long)(((n + dd - 1) / dd + per - 1) / per); };
+  return (long long)d->B * dd * dd * dd * tiles(d->D, nz) * tiles(d->H, ny) * tiles(d->W, 2);
+}
+
+void pick_tiling(const DramConvDesc* d, int& nz, int& ny) {
+  const char* ez = getenv("DRAM_WINO_NZ");
+  const char* ey = getenv("DRAM_WINO_NY");
+  if (ez && (atoi(ez) == 2 || atoi(ez) == 4)) {
+    nz = atoi(ez);
+    ny = (nz == 4 && ey && atoi(ey) == 4) ? 4 : 2;
+    return;
   }
-  const int sz = (d->D + d->dil - 1) / d->dil;
-  return (sz % 4 == 0) ? 4 : 2;
+  const int sz = (d->D + d->dil - 1) / d->dil, sy = (d->H + d->dil - 1) / d->dil;
+  const int cand[3][2] = {{4, 4}, {4, 2}, {2, 2}};
+  for (int i = 0; i < 3; ++i) {
+    nz = cand[i][0]; ny = cand[i][1];
+    if (nz == 4 && sz % 4 != 0) continue;
+    if (ny == 4 && sy % 4 != 0) continue;
+    if (i == 2 || tiles_for(d, nz, ny) >= 512) return;
+  }
 }
 
 WinoGeom make_geom(const DramConvDesc* d) {
   WinoGeom g{};
   g.B = d->B; g.D = d->D; g.H = d->H; g.W = d->W; g.d = d->dil;
-  g.nz = pick_nz(d);
-  g.npts = (g.nz + 2) * 16;
+  pick_tiling(d, g.nz, g.ny);
+  g.npts = (g.nz + 2) * (g.ny + 2) * 4;
   auto tiles = [&](int n, int per) { return ((n + g.d - 1) / g.d + per - 1) / per; };
-  g.Tz = tiles(g.D, g.nz); g.Ty = tiles(g.H, 2); g.Tx = tiles(g.W, 2);
+  g.Tz = tiles(g.D, g.nz); g.Ty = tiles(g.H, g.ny); g.Tx = tiles(g.W, 2);
   const long long T = (long long)g.B * g.d * g.d * g.d * g.Tz * g.Ty * g.Tx;
   g.T = (int)T;
   g.Tpad = (int)((T + 255) / 256 * 256);
@@ -737,18 +784,19 @@ int run_conv(const float* in, const float* U, const float* bias, const float* ad
   if (!ws || ws_bytes < need) return DRAM_ERR_WORKSPACE;
   float* V = v_keep ? v_keep : (float*)ws;          // kept for the weight gradient when the caller asks
   float* Mh = (float*)ws + (size_t)g.npts * g.Tpad * K;
-  if (g.nz == 4)
-    hipLaunchKernelGGL((wino_in_kernel<0, 4>), dim3(grid_for((long)g.Tpad * (K / 64))), dim3(256), 0, s, in, V, g, K);
-  else
-    hipLaunchKernelGGL((wino_in_kernel<0, 2>), dim3(grid_for((long)g.Tpad * (K / 64))), dim3(256), 0, s, in, V, g, K);
+#define W_IN(NZ_, NY_) \
+  hipLaunchKernelGGL((wino_in_kernel<0, NZ_, NY_>), dim3(grid_for((long)g.Tpad * (K / 64))), dim3(256), 0, s, in, V, g, K)
+  WINO_TILING_DISPATCH(g, W_IN);
+#undef W_IN
   DRAM_LAUNCH_CHECK();
   const int rc = run_nn(V, U, Mh, g, N, K, s);
   if (rc != DRAM_OK) return rc;
   const int ntb = (g.T + WINO_TPB - 1) / WINO_TPB;
-  if (g.nz == 4)
-    hipLaunchKernelGGL(wino_out_kernel<4>, dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add, gate, out, stats, g, N);
-  else
-    hipLaunchKernelGGL(wino_out_kernel<2>, dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add, gate, out, stats, g, N);
+#define W_OUT(NZ_, NY_)                                                                                                \
+  hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add, gate, out, stats, \
+                     g, N)
+  WINO_TILING_DISPATCH(g, W_OUT);
+#undef W_OUT
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
@@ -804,7 +852,7 @@ extern "C" int dram_conv_algo(const DramConvDesc* d) {
   if (w3) {
     const WinoGeom g = make_geom(d);
     if (g.T >= 128) {
-      const double vpad = 4.0 * g.nz * g.Tpad, pv = g.npts / (4.0 * g.nz);
+      const double vpad = 2.0 * g.nz * g.ny * g.Tpad, pv = g.npts / (2.0 * g.nz * g.ny);
       const double direct = vox * 54.0 * d->Cin * d->Cout * 0.5 *
                             (1.0 / direct_rate(d, d->Cout) + 1.0 / direct_rate(d, d->Cin));
       const double wino = vpad * 0.5 * (wino_cost_per_voxel(d->Cin, d->Cout, g.Tpad, g.npts, pv) +
@@ -846,7 +894,7 @@ extern "C" int dram_conv_wgrad_algo(const DramConvDesc* d) {
   if (w3) {
     const WinoGeom g = make_geom(d);
     if (g.T >= 128) {
-      const double vpad = 4.0 * g.nz * g.Tpad, pv = g.npts / (4.0 * g.nz);
+      const double vpad = 2.0 * g.nz * g.ny * g.Tpad, pv = g.npts / (2.0 * g.nz * g.ny);
       TnPlan tp;
       plan_tn(d, g, tp);
       const double wgs = (double)g.npts * tp.m_tiles * tp.n_tiles * tp.nsplit;
@@ -875,10 +923,11 @@ extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, const
   if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
   const long n = (long)d->Cout * d->Cin;
   const dim3 grid((unsigned)((n + 255) / 256), 2);
-  if (pick_nz(d) == 4)
-    hipLaunchKernelGGL(wino_weight_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, w, uf, ub, d->Cout, d->Cin);
-  else
-    hipLaunchKernelGGL(wino_weight_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, w, uf, ub, d->Cout, d->Cin);
+  const WinoGeom g = make_geom(d);
+#define W_WT(NZ_, NY_) \
+  hipLaunchKernelGGL((wino_weight_kernel<NZ_, NY_>), grid, dim3(256), 0, (hipStream_t)stream, w, uf, ub, d->Cout, d->Cin)
+  WINO_TILING_DISPATCH(g, W_WT);
+#undef W_WT
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
@@ -942,20 +991,18 @@ extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache,
   float* slab = Dh + (size_t)g.npts * g.Tpad * d->Cout;       // [nsplit][npts][Cout][Cin]
   if (v_cache) V = const_cast<float*>(v_cache);
   else {
-    if (g.nz == 4)
-      hipLaunchKernelGGL((wino_in_kernel<0, 4>), dim3(grid_for((long)g.Tpad * (d->Cin / 64))), dim3(256), 0, s, x, V, g,
-                         d->Cin);
-    else
-      hipLaunchKernelGGL((wino_in_kernel<0, 2>), dim3(grid_for((long)g.Tpad * (d->Cin / 64))), dim3(256), 0, s, x, V, g,
-                         d->Cin);
+#define W_INX(NZ_, NY_)                                                                                             \
+  hipLaunchKernelGGL((wino_in_kernel<0, NZ_, NY_>), dim3(grid_for((long)g.Tpad * (d->Cin / 64))), dim3(256), 0, s, x, V, \
+                     g, d->Cin)
+    WINO_TILING_DISPATCH(g, W_INX);
+#undef W_INX
     DRAM_LAUNCH_CHECK();
   }
-  if (g.nz == 4)
-    hipLaunchKernelGGL((wino_in_kernel<1, 4>), dim3(grid_for((long)g.Tpad * (d->Cout / 64))), dim3(256), 0, s, dy, Dh, g,
-                       d->Cout);
-  else
-    hipLaunchKernelGGL((wino_in_kernel<1, 2>), dim3(grid_for((long)g.Tpad * (d->Cout / 64))), dim3(256), 0, s, dy, Dh, g,
-                       d->Cout);
+#define W_INDY(NZ_, NY_)                                                                                              \
+  hipLaunchKernelGGL((wino_in_kernel<1, NZ_, NY_>), dim3(grid_for((long)g.Tpad * (d->Cout / 64))), dim3(256), 0, s, dy, Dh, \
+                     g, d->Cout)
+  WINO_TILING_DISPATCH(g, W_INDY);
+#undef W_INDY
   DRAM_LAUNCH_CHECK();
   const int nblk = g.npts * p.nsplit * p.m_tiles * p.n_tiles;
 #define WTN(WM_, MI_, NJ_)                                                                                       \
@@ -972,12 +1019,11 @@ extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache,
 #undef WTN
   DRAM_LAUNCH_CHECK();
   const long n = (long)d->Cout * d->Cin;
-  if (g.nz == 4)
-    hipLaunchKernelGGL(wino_wgrad_out_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, s, slab, dw, d->Cout,
-                       d->Cin, p.nsplit);
-  else
-    hipLaunchKernelGGL(wino_wgrad_out_kernel<2>, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, s, slab, dw, d->Cout,
-                       d->Cin, p.nsplit);
+#define W_WGO(NZ_, NY_)                                                                                           \
+  hipLaunchKernelGGL((wino_wgrad_out_kernel<NZ_, NY_>), dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, s, slab, dw, \
+                     d->Cout, d->Cin, p.nsplit)
+  WINO_TILING_DISPATCH(g, W_WGO);
+#undef W_WGO
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

@@ -152,14 +152,16 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("nz", ["2", "4"], ids=["F(2,3)z", "F(4,3)z"])
+@pytest.mark.parametrize("tiling", ["2,2", "4,2", "4,4"], ids=["F222", "F422", "F442"])
 @pytest.mark.parametrize("case", WINO_CASES, ids=[str(c) for c in WINO_CASES])
-def test_conv3d_winograd_path(ops, monkeypatch, case, nz):
+def test_conv3d_winograd_path(ops, monkeypatch, case, tiling):
     """Winograd F(2x2x2,3x3x3) pipeline (tile transforms + batched NN / TN GEMMs) against
     F.conv3d and its autograd: forward with bias + fused BN sums, data gradient with the fused
     shortcut-gradient epilogue, weight gradient."""
     monkeypatch.setenv("DRAM_CONV_ALGO", "2")
-    monkeypatch.setenv("DRAM_WINO_NZ", nz)            # tile depth 2 (F(2,3) along z) or 4 (F(4,3) along z)
+    nz, ny = tiling.split(",")                        # outputs per tile along z, y: F(2,3) or F(4,3) per axis
+    monkeypatch.setenv("DRAM_WINO_NZ", nz)
+    monkeypatch.setenv("DRAM_WINO_NY", ny)
     B, D, H, W, Cin, Cout, dil = case
     x = rnd(B, Cin, D, H, W, seed=1).requires_grad_(True)
     w = (rnd(Cout, Cin, 3, 3, 3, seed=2) * 0.1).requires_grad_(True)
@@ -170,7 +172,7 @@ def test_conv3d_winograd_path(ops, monkeypatch, case, nz):
     g = ops.ConvGeom(B, D, H, W, Cin, Cout, 3, 1, dil, dil)
     assert ops.conv_use_wino(g)
     wf, wb = ops.pack_conv_weight(w.detach().to(DEV), True, True, g)
-    npts = 16 * (int(nz) + 2)
+    npts = 4 * (int(nz) + 2) * (int(ny) + 2)
     assert wf.shape == (npts, Cout, Cin) and wb.shape == (npts, Cin, Cout)
     xd, gyd = to_ndhwc(x.detach()), to_ndhwc(gy)
     y, stats = ops.conv3d_fwd(xd, wf, bias.to(DEV), g, True)

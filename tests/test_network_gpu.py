@@ -56,15 +56,21 @@ def assert_close_rel(a, b, tol, what):
 
 # every golden network on the library's own plan, and once more with the Winograd path forced
 # onto every 3x3x3 stride-1 convolution it supports (DRAM_CONV_ALGO=2)
-NET_RUNS = [(p, "") for p in NET_FILES] + [(p, "2") for p in NET_FILES]
+# ... and, on three of them, with the coarsest tiling (F(4,3) along z and y) forced as well
+NET_RUNS = [(p, "") for p in NET_FILES] + [(p, "2") for p in NET_FILES] + [(p, "2:4,4") for p in NET_FILES[:3]]
 
 
 @pytest.mark.parametrize("path,algo", NET_RUNS,
-                         ids=[os.path.basename(p)[:-4] + ("-winograd" if a else "") for p, a in NET_RUNS])
+                         ids=[os.path.basename(p)[:-4] + ("-winograd" + a[1:].replace(":", "-F").replace(",", "") if a else "")
+                              for p, a in NET_RUNS])
 def test_train_step_matches_reference_golden(path, algo, monkeypatch):
     from bodyct_dram_emph_subtype_amd.optim import FusedAdam
     if algo:
-        monkeypatch.setenv("DRAM_CONV_ALGO", algo)
+        monkeypatch.setenv("DRAM_CONV_ALGO", algo.split(":")[0])
+        if ":" in algo:
+            nz, ny = algo.split(":")[1].split(",")
+            monkeypatch.setenv("DRAM_WINO_NZ", nz)
+            monkeypatch.setenv("DRAM_WINO_NY", ny)
     g = np.load(path)
     factory = str(g["factory"])
     shape = tuple(int(v) for v in g["meta"][3:])
@@ -129,8 +135,9 @@ def test_train_step_matches_reference_golden(path, algo, monkeypatch):
     sd = m.state_dict()
     # Adam turns every near-zero gradient into a +-lr move (exact optimizer arithmetic is
     # checked in test_fused_adam_and_sgd_match_torch): only a loose bound is meaningful here
-    assert rel_l2(sd["conv1.weight"].cpu(), g["conv1_after"]) < 6e-2
-    assert rel_l2(sd["fcs.0.weight"].cpu(), g["fc0_after"]) < 6e-2
+    loose = 8e-2 if ":" in algo else 6e-2
+    assert rel_l2(sd["conv1.weight"].cpu(), g["conv1_after"]) < loose
+    assert rel_l2(sd["fcs.0.weight"].cpu(), g["fc0_after"]) < loose
     # (the golden eval-mode outputs after these two Adam steps are not compared: by then the
     #  parameters differ by the +-lr noise moves above; eval-mode parity is checked on the
     #  initial weights at the top of this test)
