@@ -24,6 +24,7 @@
 // LDS-DMA (global_load_lds_dwordx4), double-buffered, one barrier per K-step; NN form reads both
 // operands with the ds_read_b128 k-permutation trick of conv_igemm.hip, TN form reads [t][c] rows
 // with ds_read_b32 (lanes = consecutive channels).
+#include <stdio.h>
 #include <stdlib.h>
 #include "common.h"
 
@@ -36,7 +37,7 @@ namespace {
 struct WinoGeom {
   int B, D, H, W;  // voxel grid (input and output grids coincide: stride 1, pad == dil)
   int d;           // dilation
-  int nz, ny;      // outputs per tile along z and y (2 or 4); points = (nz + 2) * (ny + 2) * 4
+  int nz, ny, nx;  // outputs per tile along z, y, x (2 or 4); points = (nz + 2) * (ny + 2) * (nx + 2)
   int npts;
   int Tz, Ty, Tx;  // tiles per residue sub-lattice axis
   int T;           // B * d^3 * Tz * Ty * Tx
@@ -55,7 +56,7 @@ __device__ __forceinline__ void tile_origin(const WinoGeom& g, int t, int& b, in
   b = r / g.d;
   z0 = g.nz * tz * g.d + rz;
   y0 = g.ny * ty * g.d + ry;
-  x0 = 2 * tx * g.d + rx;
+  x0 = g.nx * tx * g.d + rx;
 }
 
 // ---- 1-D transforms (Lavin & Gray): F(2,3) with points {0, 1, -1, inf}, F(4,3) with {0, +-1, +-2, inf} --
@@ -125,17 +126,49 @@ template <int NZ> __device__ __forceinline__ void az(const float* y, float* r) {
 template <int NZ> __device__ __forceinline__ void gz(const float* g, float* r) { if (NZ == 2) g2(g, r); else g4z(g, r); }
 template <int NZ> __device__ __forceinline__ void gtz(const float* s, float* r) { if (NZ == 2) gt2(s, r); else gt4(s, r); }
 
+// Matrix entries as compile-time tables (indices are unrolled constants, zero entries vanish).
+template <int N> __device__ __forceinline__ constexpr float bt_coef(int r, int c) {   // B^T [N+2][N+2]
+  if (N == 2) {
+    constexpr float t[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
+    return t[r][c];
+  }
+  constexpr float t[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                             {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+  return t[r][c];
+}
+template <int N> __device__ __forceinline__ constexpr float at_coef(int o, int i) {   // A^T [N][N+2]
+  if (N == 2) {
+    constexpr float t[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+    return t[o][i];
+  }
+  constexpr float t[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+  return t[o][i];
+}
+template <int N> __device__ __forceinline__ constexpr float g_coef(int r, int k) {    // G [N+2][3]
+  if (N == 2) {
+    constexpr float t[4][3] = {{1, 0, 0}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0, 0, 1}};
+    return t[r][k];
+  }
+  constexpr float t[6][3] = {{.25f, 0, 0}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                             {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0, 0, 1}};
+  return t[r][k];
+}
+
 // ------------------------------------------------------------------------------------------
 // Tile transforms into the Winograd domain.  One wave per (tile, 64-channel block); lanes are
-// consecutive channels (256-B coalesced rows).  out[xi][t][c], xi = (i*NJ + j)*4 + k,
-// i < NI = NZ + 2, j < NJ = NY + 2.
-//   MODE 0:  V = B^T v B over the NI x NJ x 4 input tile (zero outside the volume)
-//   MODE 1:  A dy A^T over the NZ x NY x 2 output-gradient tile (weight gradient)
+// consecutive channels (256-B coalesced rows).  out[xi][t][c], xi = (i*NJ + j)*NK + k,
+// i < NI = NZ + 2, j < NJ = NY + 2, k < NK = NX + 2.
+//   MODE 0:  V = B^T v B over the NI x NJ x NK input tile (zero outside the volume)
+//   MODE 1:  A dy A^T over the NZ x NY x NX output-gradient tile (weight gradient)
+// All NI*NJ*NK values of a (tile, channel) live in registers (up to 216 at F(4,3)^3; with one wave per
+// SIMD the allocator may use the AGPR half of the file).  A form streamed over the z point with the z
+// row re-applied to the raw planes (36 live values, 3.7x the loads) measured 2x SLOWER: the kernel is
+// bound by vector-memory instructions, not registers.
 // Rows t in [T, Tpad) are written as zeros (the TN GEMM contracts over t).
-template <int MODE, int NZ, int NY>
+template <int MODE, int NZ, int NY, int NX>
 __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                       const WinoGeom g, const int C) {
-  constexpr int NI = NZ + 2, NJ = NY + 2;
+  constexpr int NI = NZ + 2, NJ = NY + 2, NK = NX + 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cblks = C >> 6;
   const long plane = (long)g.Tpad * C;
@@ -143,10 +176,10 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
   for (long w = blockIdx.x * 4L + wave; w < total; w += gridDim.x * 4L) {
     const int t = (int)(w / cblks);
     const int c = (int)(w - (long)t * cblks) * 64 + lane;
-    float v[NI][NJ][4];
+    float v[NI][NJ][NK];
     if (t >= g.T) {
 #pragma unroll
-      for (int i = 0; i < NI * NJ * 4; ++i) out[i * plane + (long)t * C + c] = 0.f;
+      for (int i = 0; i < NI * NJ * NK; ++i) out[i * plane + (long)t * C + c] = 0.f;
       continue;
     }
     int b, z0, y0, x0;
@@ -161,7 +194,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
           const int y = y0 + (j - 1) * g.d;
           const bool yo = zo & (y >= 0) & (y < g.H);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < NK; ++k) {
             const int x = x0 + (k - 1) * g.d;
             const bool ok = yo & (x >= 0) & (x < g.W);
             const long o = ((((long)b * g.D + z) * g.H + y) * g.W + x) * C + c;
@@ -172,11 +205,11 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bt2(v[i][j]);
+        for (int j = 0; j < NJ; ++j) btz<NX>(v[i][j]);
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NK; ++k) {
           float col[NJ];
 #pragma unroll
           for (int j = 0; j < NJ; ++j) col[j] = v[i][j][k];
@@ -187,7 +220,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NK; ++k) {
           float col[NI];
 #pragma unroll
           for (int i = 0; i < NI; ++i) col[i] = v[i][j][k];
@@ -196,7 +229,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
           for (int i = 0; i < NI; ++i) v[i][j][k] = col[i];
         }
     } else {
-      float u[NZ][NY][2];
+      float u[NZ][NY][NX];
 #pragma unroll
       for (int i = 0; i < NZ; ++i) {
         const int z = z0 + i * g.d;
@@ -204,7 +237,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
         for (int j = 0; j < NY; ++j) {
           const int y = y0 + j * g.d;
 #pragma unroll
-          for (int k = 0; k < 2; ++k) {
+          for (int k = 0; k < NX; ++k) {
             const int x = x0 + k * g.d;
             const bool ok = (z < g.D) & (y < g.H) & (x < g.W);
             const long o = ((((long)b * g.D + z) * g.H + y) * g.W + x) * C + c;
@@ -212,15 +245,15 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
           }
         }
       }
-      float p[NZ][NY][4], q[NZ][NJ][4];
+      float p[NZ][NY][NK], q[NZ][NJ][NK];
 #pragma unroll
       for (int i = 0; i < NZ; ++i)
 #pragma unroll
-        for (int j = 0; j < NY; ++j) a2(u[i][j], p[i][j]);
+        for (int j = 0; j < NY; ++j) az<NX>(u[i][j], p[i][j]);
 #pragma unroll
       for (int i = 0; i < NZ; ++i)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NK; ++k) {
           float yy[NY], col[NJ];
 #pragma unroll
           for (int j = 0; j < NY; ++j) yy[j] = p[i][j][k];
@@ -231,7 +264,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NK; ++k) {
           float yy[NZ], col[NI];
 #pragma unroll
           for (int i = 0; i < NZ; ++i) yy[i] = q[i][j][k];
@@ -246,7 +279,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[((i * NJ + j) * 4 + k) * plane] = v[i][j][k];
+        for (int k = 0; k < NK; ++k) o[((i * NJ + j) * NK + k) * plane] = v[i][j][k];
   }
 }
 
@@ -257,23 +290,12 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 // in-plane A^T . A result is folded into the NZ output planes with the z column of A^T.
 constexpr int WINO_TPB = 16;
 
-template <int NZ> __device__ __forceinline__ float atz_coef(int o, int i) {
-  // A^T[o][i]: F(2,3) [1 1 1 0; 0 1 -1 -1], F(4,3) [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-  if (NZ == 2) {
-    const float t[2][4] = {{1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, -1.f}};
-    return t[o][i];
-  }
-  const float t[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -2.f, 0.f},
-                         {0.f, 1.f, 1.f, 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 8.f, -8.f, 1.f}};
-  return t[o][i];
-}
-
-template <int NZ, int NY>
+template <int NZ, int NY, int NX>
 __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ mh, const float* __restrict__ bias,
                                                        const float* __restrict__ add, const float* __restrict__ gate,
                                                        float* __restrict__ out, float* __restrict__ stats,
                                                        const WinoGeom g, const int N) {
-  constexpr int NI = NZ + 2, NJ = NY + 2;
+  constexpr int NI = NZ + 2, NJ = NY + 2, NK = NX + 2;
   __shared__ float red[4][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cblks = N >> 6;
@@ -286,18 +308,18 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
     const int t = tb * WINO_TPB + q;
     if (t >= g.T) break;
     const float* src = mh + (long)t * N + c;
-    float o[NZ][NY][2];
+    float o[NZ][NY][NX];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      float m[NJ][4], p[NJ][2], q2[NY][2];
+      float m[NJ][NK], p[NJ][NX], q2[NY][NX];
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) m[j][k] = src[((i * NJ + j) * 4 + k) * plane];
+        for (int k = 0; k < NK; ++k) m[j][k] = src[((i * NJ + j) * NK + k) * plane];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) at2(m[j], p[j]);
+      for (int j = 0; j < NJ; ++j) atz<NX>(m[j], p[j]);
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < NX; ++k) {
         float col[NJ], r[NY];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) col[j] = p[j][k];
@@ -307,12 +329,12 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
       }
 #pragma unroll
       for (int oz = 0; oz < NZ; ++oz) {
-        const float cf = atz_coef<NZ>(oz, i);
+        const float cf = at_coef<NZ>(oz, i);
         if (cf != 0.f) {
 #pragma unroll
           for (int j = 0; j < NY; ++j)
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < NX; ++k) {
               if (i == 0 || (i == 1 && oz > 0)) o[oz][j][k] = cf * q2[j][k];     // first contribution to this plane
               else o[oz][j][k] = __builtin_fmaf(cf, q2[j][k], o[oz][j][k]);
             }
@@ -328,7 +350,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
       for (int j = 0; j < NY; ++j) {
         const int y = y0 + j * g.d;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < NX; ++k) {
           const int x = x0 + k * g.d;
           if ((z < g.D) & (y < g.H) & (x < g.W)) {
             const long oo = ((((long)b * g.D + z) * g.H + y) * g.W + x) * N + c;
@@ -358,13 +380,13 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// Weight transform  U = G w G^T (3-D).
+// Weight transform  U = G w G^T (3-D), streamed over the z point (9 + 36 live values).
 //   blockIdx.y == 0: uf[xi][co][ci]               (forward B operand, K = ci contiguous)
 //   blockIdx.y == 1: ub[xi][ci][co], taps flipped  (data-gradient B operand, K = co contiguous)
-template <int NZ, int NY>
+template <int NZ, int NY, int NX>
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ uf,
                                                           float* __restrict__ ub, const int Cout, const int Cin) {
-  constexpr int NI = NZ + 2, NJ = NY + 2;
+  constexpr int NI = NZ + 2, NJ = NY + 2, NK = NX + 2;
   const bool bwd = blockIdx.y == 1;
   float* dst = bwd ? ub : uf;
   if (!dst) return;
@@ -378,49 +400,43 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
   float gw[3][3][3];
 #pragma unroll
   for (int a = 0; a < 27; ++a) (&gw[0][0][0])[a] = src[bwd ? 26 - a : a];
-  float p[3][3][4], q[3][NJ][4], u[NI][NJ][4];
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
+  for (int a = 0; a < NI; ++a) {
+    float r[3][3], p[3][NK], u[NJ][NK];
 #pragma unroll
-    for (int b = 0; b < 3; ++b) g2(gw[a][b], p[a][b]);
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
+      for (int kx = 0; kx < 3; ++kx)
+        r[ky][kx] = g_coef<NZ>(a, 0) * gw[0][ky][kx] + g_coef<NZ>(a, 1) * gw[1][ky][kx] + g_coef<NZ>(a, 2) * gw[2][ky][kx];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float col[3] = {p[a][0][k], p[a][1][k], p[a][2][k]};
-      float r[NJ];
-      gz<NY>(col, r);
+    for (int ky = 0; ky < 3; ++ky) gz<NX>(r[ky], p[ky]);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) q[a][j][k] = r[j];
+    for (int k = 0; k < NK; ++k) {
+      const float col[3] = {p[0][k], p[1][k], p[2][k]};
+      float rr[NJ];
+      gz<NY>(col, rr);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) u[j][k] = rr[j];
     }
 #pragma unroll
-  for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float col[3] = {q[0][j][k], q[1][j][k], q[2][j][k]};
-      float r[NI];
-      gz<NZ>(col, r);
-#pragma unroll
-      for (int a = 0; a < NI; ++a) u[a][j][k] = r[a];
-    }
-#pragma unroll
-  for (int a = 0; a < NI * NJ * 4; ++a) dst[a * n + i] = (&u[0][0][0])[a];
+      for (int k = 0; k < NK; ++k) dst[((long)(a * NJ + j) * NK + k) * n + i] = u[j][k];
+  }
 }
 
 // dw[co][ci][27] = G^T (sum over splits of slab[split][xi][co][ci]) G   (3-D), fixed order.
-// One workgroup = 64 (co, ci) elements x 16 point groups (1024 threads): every thread sums NP/16 of the
-// NP points over the splits (coalesced over elements), then 64 threads apply G^T . G (3-D).
-template <int NZ, int NY>
-__global__ __launch_bounds__(1024) void wino_wgrad_out_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+// One workgroup = 64 (co, ci) elements x 8 point groups (512 threads): every thread sums every 8th of
+// the NP points over the splits (coalesced over elements), then 64 threads apply G^T . G (3-D).
+template <int NZ, int NY, int NX>
+__global__ __launch_bounds__(512) void wino_wgrad_out_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                                const int Cout, const int Cin, const int nsplit) {
-  constexpr int NI = NZ + 2, NJ = NY + 2, NP = NI * NJ * 4, PPG = NP / 16;
+  constexpr int NI = NZ + 2, NJ = NY + 2, NK = NX + 2, NP = NI * NJ * NK;
   __shared__ float us[NP][64];
   const long n = (long)Cout * Cin;
   const int e = threadIdx.x & 63, gq = threadIdx.x >> 6;
   const long i = blockIdx.x * 64L + e;   // (co, ci), ci fastest
-#pragma unroll
-  for (int j = 0; j < PPG; ++j) {
-    const int a = gq * PPG + j;
+  for (int a = gq; a < NP; a += 8) {
     float acc = 0.f;
     if (i < n)
       for (int sp = 0; sp < nsplit; ++sp) acc += slab[((long)sp * NP + a) * n + i];
@@ -434,9 +450,10 @@ __global__ __launch_bounds__(1024) void wino_wgrad_out_kernel(const float* __res
     float p[NJ][3];
 #pragma unroll
     for (int b = 0; b < NJ; ++b) {
-      const float row[4] = {us[(a * NJ + b) * 4 + 0][e], us[(a * NJ + b) * 4 + 1][e], us[(a * NJ + b) * 4 + 2][e],
-                            us[(a * NJ + b) * 4 + 3][e]};
-      gt2(row, p[b]);
+      float row[NK];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) row[k] = us[(a * NJ + b) * NK + k][e];
+      gtz<NX>(row, p[b]);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -664,12 +681,13 @@ __global__ __launch_bounds__(512) void wino_gemm_tn_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------
 // host side
-// instantiated tilings (z, y outputs per tile): 2x2, 4x2, 4x4  (x is always 2)
-#define WINO_TILING_DISPATCH(g_, CALL_)          \
-  do {                                           \
-    if ((g_).nz == 4 && (g_).ny == 4) { CALL_(4, 4); } \
-    else if ((g_).nz == 4) { CALL_(4, 2); }      \
-    else { CALL_(2, 2); }                        \
+// instantiated tilings (z, y, x outputs per tile): 2x2x2, 4x2x2, 4x4x2, 4x4x4
+#define WINO_TILING_DISPATCH(g_, CALL_)                                 \
+  do {                                                                  \
+    if ((g_).nz == 4 && (g_).ny == 4 && (g_).nx == 4) { CALL_(4, 4, 4); } \
+    else if ((g_).nz == 4 && (g_).ny == 4) { CALL_(4, 4, 2); }          \
+    else if ((g_).nz == 4) { CALL_(4, 2, 2); }                          \
+    else { CALL_(2, 2, 2); }                                            \
   } while (0)
 bool wino_geom_ok(const DramConvDesc* d) {
   if (!d) return false;
@@ -684,37 +702,42 @@ bool wino_geom_ok(const DramConvDesc* d) {
 // is a multiple of 4 (no extra padding) -- largest first among the instantiated 4x4, 4x2, 2x2 -- as long
 // as at least 512 tiles remain (two GEMM M tiles per point; small volumes keep the finer tiling).
 // DRAM_WINO_NZ / DRAM_WINO_NY = 2 | 4 force one (tests).
-long long tiles_for(const DramConvDesc* d, int nz, int ny) {
+long long tiles_for(const DramConvDesc* d, int nz, int ny, int nx) {
   const int dd = d->dil;
   auto tiles = [&](int n, int per) { return (long long)(((n + dd - 1) / dd + per - 1) / per); };
-  return (long long)d->B * dd * dd * dd * tiles(d->D, nz) * tiles(d->H, ny) * tiles(d->W, 2);
+  return (long long)d->B * dd * dd * dd * tiles(d->D, nz) * tiles(d->H, ny) * tiles(d->W, nx);
 }
 
-void pick_tiling(const DramConvDesc* d, int& nz, int& ny) {
-  const char* ez = getenv("DRAM_WINO_NZ");
-  const char* ey = getenv("DRAM_WINO_NY");
-  if (ez && (atoi(ez) == 2 || atoi(ez) == 4)) {
-    nz = atoi(ez);
-    ny = (nz == 4 && ey && atoi(ey) == 4) ? 4 : 2;
-    return;
+// instantiated tilings: 4x4x4, 4x4x2, 4x2x2, 2x2x2;  DRAM_WINO_TILING = "z,y,x" forces one (tests)
+void pick_tiling(const DramConvDesc* d, int& nz, int& ny, int& nx) {
+  static const int cand[4][3] = {{4, 4, 4}, {4, 4, 2}, {4, 2, 2}, {2, 2, 2}};
+  if (const char* e = getenv("DRAM_WINO_TILING")) {
+    int a = 0, b = 0, c = 0;
+    if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3)
+      for (int i = 0; i < 4; ++i)
+        if (cand[i][0] == a && cand[i][1] == b && cand[i][2] == c) { nz = a; ny = b; nx = c; return; }
   }
-  const int sz = (d->D + d->dil - 1) / d->dil, sy = (d->H + d->dil - 1) / d->dil;
-  const int cand[3][2] = {{4, 4}, {4, 2}, {2, 2}};
-  for (int i = 0; i < 3; ++i) {
-    nz = cand[i][0]; ny = cand[i][1];
+  const int sz = (d->D + d->dil - 1) / d->dil, sy = (d->H + d->dil - 1) / d->dil, sx = (d->W + d->dil - 1) / d->dil;
+  // F(4,3) on all three axes pays only on GEMM-dominated (>= 512 x 256 channel) layers: its 216-value
+  // input transform spills into the AGPR half of the register file (measured: -12 % on 512->512,
+  // +5 % on 128->64)
+  const bool wide = (long long)d->Cin * d->Cout >= 512LL * 256;
+  for (int i = wide ? 0 : 1; i < 4; ++i) {
+    nz = cand[i][0]; ny = cand[i][1]; nx = cand[i][2];
     if (nz == 4 && sz % 4 != 0) continue;
     if (ny == 4 && sy % 4 != 0) continue;
-    if (i == 2 || tiles_for(d, nz, ny) >= 512) return;
+    if (nx == 4 && sx % 4 != 0) continue;
+    if (i == 3 || tiles_for(d, nz, ny, nx) >= 512) return;
   }
 }
 
 WinoGeom make_geom(const DramConvDesc* d) {
   WinoGeom g{};
   g.B = d->B; g.D = d->D; g.H = d->H; g.W = d->W; g.d = d->dil;
-  pick_tiling(d, g.nz, g.ny);
-  g.npts = (g.nz + 2) * (g.ny + 2) * 4;
+  pick_tiling(d, g.nz, g.ny, g.nx);
+  g.npts = (g.nz + 2) * (g.ny + 2) * (g.nx + 2);
   auto tiles = [&](int n, int per) { return ((n + g.d - 1) / g.d + per - 1) / per; };
-  g.Tz = tiles(g.D, g.nz); g.Ty = tiles(g.H, g.ny); g.Tx = tiles(g.W, 2);
+  g.Tz = tiles(g.D, g.nz); g.Ty = tiles(g.H, g.ny); g.Tx = tiles(g.W, g.nx);
   const long long T = (long long)g.B * g.d * g.d * g.d * g.Tz * g.Ty * g.Tx;
   g.T = (int)T;
   g.Tpad = (int)((T + 255) / 256 * 256);
@@ -784,16 +807,16 @@ int run_conv(const float* in, const float* U, const float* bias, const float* ad
   if (!ws || ws_bytes < need) return DRAM_ERR_WORKSPACE;
   float* V = v_keep ? v_keep : (float*)ws;          // kept for the weight gradient when the caller asks
   float* Mh = (float*)ws + (size_t)g.npts * g.Tpad * K;
-#define W_IN(NZ_, NY_) \
-  hipLaunchKernelGGL((wino_in_kernel<0, NZ_, NY_>), dim3(grid_for((long)g.Tpad * (K / 64))), dim3(256), 0, s, in, V, g, K)
+#define W_IN(NZ_, NY_, NX_) \
+  hipLaunchKernelGGL((wino_in_kernel<0, NZ_, NY_, NX_>), dim3(grid_for((long)g.Tpad * (K / 64))), dim3(256), 0, s, in, V, g, K)
   WINO_TILING_DISPATCH(g, W_IN);
 #undef W_IN
   DRAM_LAUNCH_CHECK();
   const int rc = run_nn(V, U, Mh, g, N, K, s);
   if (rc != DRAM_OK) return rc;
   const int ntb = (g.T + WINO_TPB - 1) / WINO_TPB;
-#define W_OUT(NZ_, NY_)                                                                                                \
-  hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add, gate, out, stats, \
+#define W_OUT(NZ_, NY_, NX_)                                                                                              \
+  hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_, NX_>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add, gate, out, stats, \
                      g, N)
   WINO_TILING_DISPATCH(g, W_OUT);
 #undef W_OUT
@@ -852,7 +875,7 @@ extern "C" int dram_conv_algo(const DramConvDesc* d) {
   if (w3) {
     const WinoGeom g = make_geom(d);
     if (g.T >= 128) {
-      const double vpad = 2.0 * g.nz * g.ny * g.Tpad, pv = g.npts / (2.0 * g.nz * g.ny);
+      const double vpad = (double)g.nz * g.ny * g.nx * g.Tpad, pv = g.npts / ((double)g.nz * g.ny * g.nx);
       const double direct = vox * 54.0 * d->Cin * d->Cout * 0.5 *
                             (1.0 / direct_rate(d, d->Cout) + 1.0 / direct_rate(d, d->Cin));
       const double wino = vpad * 0.5 * (wino_cost_per_voxel(d->Cin, d->Cout, g.Tpad, g.npts, pv) +
@@ -894,7 +917,7 @@ extern "C" int dram_conv_wgrad_algo(const DramConvDesc* d) {
   if (w3) {
     const WinoGeom g = make_geom(d);
     if (g.T >= 128) {
-      const double vpad = 2.0 * g.nz * g.ny * g.Tpad, pv = g.npts / (2.0 * g.nz * g.ny);
+      const double vpad = (double)g.nz * g.ny * g.nx * g.Tpad, pv = g.npts / ((double)g.nz * g.ny * g.nx);
       TnPlan tp;
       plan_tn(d, g, tp);
       const double wgs = (double)g.npts * tp.m_tiles * tp.n_tiles * tp.nsplit;
@@ -924,8 +947,8 @@ extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, const
   const long n = (long)d->Cout * d->Cin;
   const dim3 grid((unsigned)((n + 255) / 256), 2);
   const WinoGeom g = make_geom(d);
-#define W_WT(NZ_, NY_) \
-  hipLaunchKernelGGL((wino_weight_kernel<NZ_, NY_>), grid, dim3(256), 0, (hipStream_t)stream, w, uf, ub, d->Cout, d->Cin)
+#define W_WT(NZ_, NY_, NX_) \
+  hipLaunchKernelGGL((wino_weight_kernel<NZ_, NY_, NX_>), grid, dim3(256), 0, (hipStream_t)stream, w, uf, ub, d->Cout, d->Cin)
   WINO_TILING_DISPATCH(g, W_WT);
 #undef W_WT
   DRAM_LAUNCH_CHECK();
@@ -991,15 +1014,15 @@ extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache,
   float* slab = Dh + (size_t)g.npts * g.Tpad * d->Cout;       // [nsplit][npts][Cout][Cin]
   if (v_cache) V = const_cast<float*>(v_cache);
   else {
-#define W_INX(NZ_, NY_)                                                                                             \
-  hipLaunchKernelGGL((wino_in_kernel<0, NZ_, NY_>), dim3(grid_for((long)g.Tpad * (d->Cin / 64))), dim3(256), 0, s, x, V, \
+#define W_INX(NZ_, NY_, NX_)                                                                                           \
+  hipLaunchKernelGGL((wino_in_kernel<0, NZ_, NY_, NX_>), dim3(grid_for((long)g.Tpad * (d->Cin / 64))), dim3(256), 0, s, x, V, \
                      g, d->Cin)
     WINO_TILING_DISPATCH(g, W_INX);
 #undef W_INX
     DRAM_LAUNCH_CHECK();
   }
-#define W_INDY(NZ_, NY_)                                                                                              \
-  hipLaunchKernelGGL((wino_in_kernel<1, NZ_, NY_>), dim3(grid_for((long)g.Tpad * (d->Cout / 64))), dim3(256), 0, s, dy, Dh, \
+#define W_INDY(NZ_, NY_, NX_)                                                                                            \
+  hipLaunchKernelGGL((wino_in_kernel<1, NZ_, NY_, NX_>), dim3(grid_for((long)g.Tpad * (d->Cout / 64))), dim3(256), 0, s, dy, Dh, \
                      g, d->Cout)
   WINO_TILING_DISPATCH(g, W_INDY);
 #undef W_INDY
@@ -1019,8 +1042,8 @@ extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache,
 #undef WTN
   DRAM_LAUNCH_CHECK();
   const long n = (long)d->Cout * d->Cin;
-#define W_WGO(NZ_, NY_)                                                                                           \
-  hipLaunchKernelGGL((wino_wgrad_out_kernel<NZ_, NY_>), dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, s, slab, dw, \
+#define W_WGO(NZ_, NY_, NX_)                                                                                         \
+  hipLaunchKernelGGL((wino_wgrad_out_kernel<NZ_, NY_, NX_>), dim3((unsigned)((n + 63) / 64)), dim3(512), 0, s, slab, dw, \
                      d->Cout, d->Cin, p.nsplit)
   WINO_TILING_DISPATCH(g, W_WGO);
 #undef W_WGO

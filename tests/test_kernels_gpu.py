@@ -152,16 +152,16 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tiling", ["2,2", "4,2", "4,4"], ids=["F222", "F422", "F442"])
+@pytest.mark.parametrize("tiling", ["2,2,2", "4,2,2", "4,4,2", "4,4,4"], ids=["F222", "F422", "F442", "F444"])
 @pytest.mark.parametrize("case", WINO_CASES, ids=[str(c) for c in WINO_CASES])
 def test_conv3d_winograd_path(ops, monkeypatch, case, tiling):
     """Winograd F(2x2x2,3x3x3) pipeline (tile transforms + batched NN / TN GEMMs) against
     F.conv3d and its autograd: forward with bias + fused BN sums, data gradient with the fused
     shortcut-gradient epilogue, weight gradient."""
     monkeypatch.setenv("DRAM_CONV_ALGO", "2")
-    nz, ny = tiling.split(",")                        # outputs per tile along z, y: F(2,3) or F(4,3) per axis
-    monkeypatch.setenv("DRAM_WINO_NZ", nz)
-    monkeypatch.setenv("DRAM_WINO_NY", ny)
+    nz, ny, nx = tiling.split(",")                    # outputs per tile along z, y, x: F(2,3) or F(4,3) per axis
+    monkeypatch.setenv("DRAM_WINO_TILING", tiling)
+    tol = 3e-5 if tiling == "4,4,4" else 1e-5         # F(4,3) on all three axes: ~1e-5 vs fp64 (F(2,3): 7e-7)
     B, D, H, W, Cin, Cout, dil = case
     x = rnd(B, Cin, D, H, W, seed=1).requires_grad_(True)
     w = (rnd(Cout, Cin, 3, 3, 3, seed=2) * 0.1).requires_grad_(True)
@@ -172,23 +172,24 @@ def test_conv3d_winograd_path(ops, monkeypatch, case, tiling):
     g = ops.ConvGeom(B, D, H, W, Cin, Cout, 3, 1, dil, dil)
     assert ops.conv_use_wino(g)
     wf, wb = ops.pack_conv_weight(w.detach().to(DEV), True, True, g)
-    npts = 4 * (int(nz) + 2) * (int(ny) + 2)
+    npts = (int(nz) + 2) * (int(ny) + 2) * (int(nx) + 2)
     assert wf.shape == (npts, Cout, Cin) and wb.shape == (npts, Cin, Cout)
     xd, gyd = to_ndhwc(x.detach()), to_ndhwc(gy)
     y, stats = ops.conv3d_fwd(xd, wf, bias.to(DEV), g, True)
-    assert rel_l2(to_ncdhw(y), y_ref.detach()) < 1e-5
+    assert rel_l2(to_ncdhw(y), y_ref.detach()) < tol
     s = ops.reduce_partials(stats).cpu()
     yr = y_ref.detach().double()
-    assert torch.allclose(s[0], yr.sum((0, 2, 3, 4)), rtol=2e-5, atol=2e-3)
-    assert torch.allclose(s[1], (yr * yr).sum((0, 2, 3, 4)), rtol=2e-5, atol=2e-3)
+    cnt, rms = B * D * H * W, float(yr.std())          # coherent-error bound on a sum of cnt values with rel. error tol
+    assert float((s[0] - yr.sum((0, 2, 3, 4))).abs().max()) <= 2 * tol * rms * cnt + 1e-3
+    assert float((s[1] - (yr * yr).sum((0, 2, 3, 4))).abs().max()) <= 4 * tol * rms * rms * cnt + 1e-3
     add = rnd(B, Cin, D, H, W, seed=5)
     gate = rnd(B, Cin, D, H, W, seed=6)
     dx = ops.conv3d_bwd_data(gyd, wb, g)
-    assert rel_l2(to_ncdhw(dx), gx_ref) < 1e-5
+    assert rel_l2(to_ncdhw(dx), gx_ref) < tol
     dx2 = ops.conv3d_bwd_data(gyd, wb, g, to_ndhwc(add), to_ndhwc(gate))
-    assert rel_l2(to_ncdhw(dx2), gx_ref + add * (gate > 0).float()) < 1e-5
+    assert rel_l2(to_ncdhw(dx2), gx_ref + add * (gate > 0).float()) < tol
     dw = ops.conv3d_bwd_weight(xd, gyd, g)
-    assert rel_l2(dw.cpu(), gw_ref) < 2e-5
+    assert rel_l2(dw.cpu(), gw_ref) < 2 * tol
     # the forward pass can hand its transformed input to the weight gradient (bitwise same result)
     y_k, _, v = ops.conv3d_fwd_keep(xd, wf, bias.to(DEV), g, False, True)
     assert v is not None and torch.equal(y_k, y)
@@ -197,7 +198,7 @@ def test_conv3d_winograd_path(ops, monkeypatch, case, tiling):
     monkeypatch.setenv("DRAM_CONV_ALGO", "1")
     wf1, _ = ops.pack_conv_weight(w.detach().to(DEV), True, False, g)
     y1, _ = ops.conv3d_fwd(xd, wf1, bias.to(DEV), g, False)
-    assert rel_l2(y.cpu(), y1.cpu()) < 1e-5
+    assert rel_l2(y.cpu(), y1.cpu()) < tol
 
 
 W2D_CASES = [
@@ -219,6 +220,7 @@ def test_conv3d_fused_inplane_winograd(ops, monkeypatch, case, variant):
     sums, data gradient with the fused shortcut-gradient epilogue."""
     monkeypatch.setenv("DRAM_CONV_ALGO", "3")
     monkeypatch.setenv("DRAM_W2D_V", variant)          # both kernel variants (16-deep / 8-deep tiles)
+    tol = 1e-5
     B, D, H, W, Cin, Cout = case
     x = rnd(B, Cin, D, H, W, seed=1).requires_grad_(True)
     w = (rnd(Cout, Cin, 3, 3, 3, seed=2) * 0.1).requires_grad_(True)
@@ -232,7 +234,7 @@ def test_conv3d_fused_inplane_winograd(ops, monkeypatch, case, variant):
     assert wf.shape == (48, Cout, Cin) and wb.shape == (48, Cin, Cout)
     xd, gyd = to_ndhwc(x.detach()), to_ndhwc(gy)
     y, stats = ops.conv3d_fwd(xd, wf, bias.to(DEV), g, True)
-    assert rel_l2(to_ncdhw(y), y_ref.detach()) < 1e-5
+    assert rel_l2(to_ncdhw(y), y_ref.detach()) < tol
     s = ops.reduce_partials(stats).cpu()
     yr = y_ref.detach().double()
     assert torch.allclose(s[0], yr.sum((0, 2, 3, 4)), rtol=2e-5, atol=2e-3)
@@ -242,9 +244,9 @@ def test_conv3d_fused_inplane_winograd(ops, monkeypatch, case, variant):
     add = rnd(B, Cin, D, H, W, seed=5)
     gate = rnd(B, Cin, D, H, W, seed=6)
     dx = ops.conv3d_bwd_data(gyd, wb, g)
-    assert rel_l2(to_ncdhw(dx), gx_ref) < 1e-5
+    assert rel_l2(to_ncdhw(dx), gx_ref) < tol
     dx2 = ops.conv3d_bwd_data(gyd, wb, g, to_ndhwc(add), to_ndhwc(gate))
-    assert rel_l2(to_ncdhw(dx2), gx_ref + add * (gate > 0).float()) < 1e-5
+    assert rel_l2(to_ncdhw(dx2), gx_ref + add * (gate > 0).float()) < tol
     dw = ops.conv3d_bwd_weight(xd, gyd, g)               # in-plane Winograd z-walking weight gradient
     assert rel_l2(dw.cpu(), gw_ref) < 1e-5
     assert torch.equal(dw, ops.conv3d_bwd_weight(xd, gyd, g))      # slabs summed in a fixed order
@@ -252,7 +254,7 @@ def test_conv3d_fused_inplane_winograd(ops, monkeypatch, case, variant):
 
 def test_winograd_linearity_at_scale(ops):
     """BASELINE-sized layer4 conv (512->512, dilation 4 @ 2x16x32x32) on the library's own plan
-    (Winograd): linearity, a probe of one residue sub-lattice against the CPU op, and bitwise
+    (Winograd, F(4,3) on all three axes: rounding error ~1e-5): linearity, a probe of one residue sub-lattice against the CPU op, and bitwise
     reproducibility of the weight gradient (fixed-order slab sum, no atomics)."""
     B, D, H, W, C = 2, 16, 32, 32, 512
     g = ops.ConvGeom(B, D, H, W, C, C, 3, 1, 4, 4)
@@ -265,11 +267,11 @@ def test_winograd_linearity_at_scale(ops):
     y1, _ = ops.conv3d_fwd(x1, wf, None, g, False)
     y2, _ = ops.conv3d_fwd(x2, wf, None, g, False)
     y3, _ = ops.conv3d_fwd(0.5 * x1 + x2, wf, None, g, False)
-    assert rel_l2((0.5 * y1 + y2).cpu(), y3.cpu()) < 1e-5
+    assert rel_l2((0.5 * y1 + y2).cpu(), y3.cpu()) < 5e-5
     # residue (1, 2, 3) of batch 0 is an ordinary dilation-1 convolution of a 4x8x8 volume
     sub = x1[0, 1::4, 2::4, 3::4].permute(3, 0, 1, 2)[None].cpu()
     ref = F.conv3d(sub, w.cpu(), None, 1, 1)
-    assert rel_l2(y1[0, 1::4, 2::4, 3::4].permute(3, 0, 1, 2)[None].cpu(), ref) < 1e-5
+    assert rel_l2(y1[0, 1::4, 2::4, 3::4].permute(3, 0, 1, 2)[None].cpu(), ref) < 5e-5
     dw1 = ops.conv3d_bwd_weight(x1, y2, g)
     dw2 = ops.conv3d_bwd_weight(x1, y2, g)
     assert torch.equal(dw1, dw2)

@@ -56,8 +56,8 @@ def assert_close_rel(a, b, tol, what):
 
 # every golden network on the library's own plan, and once more with the Winograd path forced
 # onto every 3x3x3 stride-1 convolution it supports (DRAM_CONV_ALGO=2)
-# ... and, on three of them, with the coarsest tiling (F(4,3) along z and y) forced as well
-NET_RUNS = [(p, "") for p in NET_FILES] + [(p, "2") for p in NET_FILES] + [(p, "2:4,4") for p in NET_FILES[:3]]
+# ... and, on three of them, with the coarsest tiling (F(4,3) on all three axes) forced as well
+NET_RUNS = [(p, "") for p in NET_FILES] + [(p, "2") for p in NET_FILES] + [(p, "2:4,4,4") for p in NET_FILES[:3]]
 
 
 @pytest.mark.parametrize("path,algo", NET_RUNS,
@@ -68,9 +68,7 @@ def test_train_step_matches_reference_golden(path, algo, monkeypatch):
     if algo:
         monkeypatch.setenv("DRAM_CONV_ALGO", algo.split(":")[0])
         if ":" in algo:
-            nz, ny = algo.split(":")[1].split(",")
-            monkeypatch.setenv("DRAM_WINO_NZ", nz)
-            monkeypatch.setenv("DRAM_WINO_NY", ny)
+            monkeypatch.setenv("DRAM_WINO_TILING", algo.split(":")[1])
     g = np.load(path)
     factory = str(g["factory"])
     shape = tuple(int(v) for v in g["meta"][3:])
