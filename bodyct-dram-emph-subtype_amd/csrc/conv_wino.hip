@@ -895,7 +895,7 @@ extern "C" int dram_conv_algo(const DramConvDesc* d) {
   return pick;
 }
 
-constexpr double W2D_WGRAD_RATE = 215e12;   // measured 197-248 TFLOP/s direct-equivalent (round 1)
+constexpr double W2D_WGRAD_RATE = 240e12;   // measured 197-257 TFLOP/s direct-equivalent (round 1)
 
 // Weight-gradient plan (independent of the forward plan: the fused in-plane kernel has no weight
 // gradient of its own): 1 = Winograd TN pipeline (dram_wino_conv3d_bwd_weight), 0 = direct.
