@@ -233,7 +233,8 @@ def main():
                                    f"batch {B}/GPU, 1x{dims[0]}x{dims[1]}x{dims[2]}, fp32, inputs resident in HBM",
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "train_gflop_per_volume": gflop_per_vol},
-            "loss": float(loss),
+            "loss": float(loss.detach()),
+            "peak_hbm_gb": torch.cuda.max_memory_allocated(device) / 1e9,
             "roofline": {
                 "kernel": kdesc,
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
