@@ -436,12 +436,18 @@ __global__ __launch_bounds__(512) void wino_wgrad_out_kernel(const float* __rest
   const long n = (long)Cout * Cin;
   const int e = threadIdx.x & 63, gq = threadIdx.x >> 6;
   const long i = blockIdx.x * 64L + e;   // (co, ci), ci fastest
-  for (int a = gq; a < NP; a += 8) {
-    float acc = 0.f;
-    if (i < n)
-      for (int sp = 0; sp < nsplit; ++sp) acc += slab[((long)sp * NP + a) * n + i];
-    us[a][e] = acc;
-  }
+  constexpr int PPT = NP / 8;            // points per thread (NP is a multiple of 8 for every tiling)
+  static_assert(NP % 8 == 0, "points per group");
+  float acc[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) acc[j] = 0.f;
+  if (i < n)
+    for (int sp = 0; sp < nsplit; ++sp) {   // splits in order (deterministic); the PPT loads of a split are independent
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) acc[j] += slab[((long)sp * NP + gq + 8 * j) * n + i];
+    }
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) us[gq + 8 * j][e] = acc[j];
   __syncthreads();
   if (gq != 0 || i >= n) return;
   float q[NI][3][3], r[3][3][3];
