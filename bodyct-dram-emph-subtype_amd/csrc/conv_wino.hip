@@ -59,6 +59,13 @@ __device__ __forceinline__ void tile_origin(const WinoGeom& g, int t, int& b, in
   x0 = g.nx * tx * g.d + rx;
 }
 
+// Winograd-domain buffers are blocked by the GEMM M tile: [t / 256][point][t % 256][channel], so the
+// 256 x C operand tile of a point is one contiguous run and a workgroup of the transforms writes /
+// reads a compact region (all points of its tiles) instead of one 256-B row in each of 64-216 planes.
+__device__ __host__ __forceinline__ long wino_index(int t, int npts, int C) {
+  return (((long)(t >> 8) * npts) * 256 + (t & 255)) * C;
+}
+
 // ---- 1-D transforms (Lavin & Gray): F(2,3) with points {0, 1, -1, inf}, F(4,3) with {0, +-1, +-2, inf} --
 // B^T d   (n + 2 -> n + 2)
 __device__ __forceinline__ void bt2(float* a) {
@@ -171,15 +178,16 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
   constexpr int NI = NZ + 2, NJ = NY + 2, NK = NX + 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cblks = C >> 6;
-  const long plane = (long)g.Tpad * C;
+  const long plane = 256L * C;            // point stride inside a 256-tile block (see wino_index)
   const long total = (long)g.Tpad * cblks;
   for (long w = blockIdx.x * 4L + wave; w < total; w += gridDim.x * 4L) {
     const int t = (int)(w / cblks);
     const int c = (int)(w - (long)t * cblks) * 64 + lane;
+    float* o = out + wino_index(t, g.npts, C) + c;
     float v[NI][NJ][NK];
     if (t >= g.T) {
 #pragma unroll
-      for (int i = 0; i < NI * NJ * NK; ++i) out[i * plane + (long)t * C + c] = 0.f;
+      for (int i = 0; i < NI * NJ * NK; ++i) o[i * plane] = 0.f;
       continue;
     }
     int b, z0, y0, x0;
@@ -273,7 +281,6 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
           for (int i = 0; i < NI; ++i) v[i][j][k] = col[i];
         }
     }
-    float* o = out + (long)t * C + c;
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -301,13 +308,13 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
   const int cblks = N >> 6;
   const int cb = blockIdx.x % cblks, tb = blockIdx.x / cblks;
   const int c = cb * 64 + lane;
-  const long plane = (long)g.Tpad * N;
+  const long plane = 256L * N;
   const float bv = bias ? bias[c] : 0.f;
   float s1 = 0.f, s2 = 0.f;
   for (int q = wave; q < WINO_TPB; q += 4) {
     const int t = tb * WINO_TPB + q;
     if (t >= g.T) break;
-    const float* src = mh + (long)t * N + c;
+    const float* src = mh + wino_index(t, g.npts, N) + c;
     float o[NZ][NY][NX];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -491,7 +498,7 @@ template <int NJ>
 __global__ __launch_bounds__(512) void wino_gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ Bw,
                                                            float* __restrict__ Y, const int Mpad, const int N,
                                                            const int K, const int m_tiles, const int n_tiles,
-                                                           const int nblk) {
+                                                           const int nblk, const int npts) {
   constexpr int BN = 64 * NJ;
   constexpr int STAGE = (256 + BN) * 32;
   __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
@@ -504,9 +511,9 @@ __global__ __launch_bounds__(512) void wino_gemm_nn_kernel(const float* __restri
   const int r0 = L / n_tiles;
   const int mt = r0 % m_tiles;
   const int xi = r0 / m_tiles;
-  const float* Ab = A + ((long)xi * Mpad + (long)mt * 256) * K;
+  const float* Ab = A + (((long)mt * npts + xi) * 256) * K;
   const float* Bb = Bw + ((long)xi * N + (long)nt * BN) * K;
-  float* Yb = Y + ((long)xi * Mpad + (long)mt * 256) * N + nt * BN;
+  float* Yb = Y + (((long)mt * npts + xi) * 256) * N + nt * BN;
 
   // DMA pieces (8 rows x 128 B each): A rows 32*wave + 8j + sub, B rows 8*NJ*wave + 8jj + sub.
   // 16-B slot swizzle slot ^ ((row >> 1) & 7) applied on the source address.
@@ -616,14 +623,16 @@ __global__ __launch_bounds__(512) void wino_gemm_tn_kernel(const float* __restri
   const int t1 = (t0 + kper < Tpad) ? t0 + kper : Tpad;
   int bcol = nt * BN + (lane % BQ) * 4;
   if (bcol > N - 4) bcol = N - 4;
-  const float* Ab = Ah + ((long)xi * Tpad + t0 + lane / AQ) * M + mt * BM + (lane % AQ) * 4;
-  const float* Bb = Bh + ((long)xi * Tpad + t0 + lane / BQ) * N + bcol;
+  const float* Ab = Ah + (long)(lane / AQ) * M + mt * BM + (lane % AQ) * 4;
+  const float* Bb = Bh + (long)(lane / BQ) * N + bcol;
 
   auto issue = [&](int it, int stage) __attribute__((always_inline)) {
     float* as = lds + stage * STAGE;
     float* bs = as + 32 * BM;
-    const float* ag = Ab + (long)it * 32 * M;
-    const float* bg = Bb + (long)it * 32 * N;
+    const int tt = t0 + it * 32;           // 32 rows of one 256-tile block: [tt / 256][xi][tt % 256 ..]
+    const long row = ((long)(tt >> 8) * npts + xi) * 256 + (tt & 255);
+    const float* ag = Ab + row * M;
+    const float* bg = Bb + row * N;
 #pragma unroll
     for (int j = 0; j < APW; ++j) {
       const int p = APW * wave + j;
@@ -795,7 +804,7 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
   const int m_tiles = g.Tpad / 256, n_tiles = N / (64 * nj);
   const int nblk = g.npts * m_tiles * n_tiles;
 #define WNN(NJ_) \
-  hipLaunchKernelGGL((wino_gemm_nn_kernel<NJ_>), dim3(nblk), dim3(512), 0, s, A, U, Y, g.Tpad, N, K, m_tiles, n_tiles, nblk)
+  hipLaunchKernelGGL((wino_gemm_nn_kernel<NJ_>), dim3(nblk), dim3(512), 0, s, A, U, Y, g.Tpad, N, K, m_tiles, n_tiles, nblk, g.npts)
   if (nj == 4) WNN(4);
   else if (nj == 2) WNN(2);
   else WNN(1);
