@@ -1,6 +1,6 @@
 """bench.py -- CT volumes/sec of the Med3D + dRAM train step on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|3]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 0|1|2|3|4]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = forward + loss + backward + (N>1: RCCL gradient all-reduce, SyncBN exchanges) +
@@ -35,6 +35,9 @@ CONFIGS = {
     1: ("resnet18segcls", 2, (128, 256, 256), 6943.0),
     2: ("resnet18segreg", 2, (128, 256, 256), 6941.6),
     3: ("resnet50segreg", 1, (128, 256, 256), 10313.4),
+    # configs[4] geometry (full-resolution volume) in fp32 without activation checkpointing: a capacity /
+    # int32-offset check of the kernels at 8x the voxels, not a BASELINE metric (that one asks for bf16)
+    4: ("resnet50segreg", 1, (256, 512, 512), 8 * 10313.4),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters
 
