@@ -34,6 +34,53 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert ctypes.sizeof(_lib.DramTensorRef) == 40 and ctypes.sizeof(_lib.DramChunkRef) == 16
 
 
+def test_conv_plan_is_host_side_and_consistent(monkeypatch):
+    """The library's conv plan (direct / 3-D Winograd pipeline / fused in-plane Winograd) is pure host
+    logic: same answers without a GPU; packed-weight sizes, workspaces and forced modes agree."""
+    from bodyct_dram_emph_subtype_amd import _lib
+    lib = _lib.load()
+    for k in ("DRAM_CONV_ALGO", "DRAM_WINO_TILING", "DRAM_W2D_V"):
+        monkeypatch.delenv(k, raising=False)
+
+    def desc(B, D, H, W, Ci, Co, k=3, s=1, dil=1):
+        pad = dil * (k - 1) // 2
+        o = lambda n: (n + 2 * pad - (dil * (k - 1) + 1)) // s + 1
+        return _lib.DramConvDesc(B, D, H, W, Ci, o(D), o(H), o(W), Co, k, s, pad, dil)
+
+    # BASELINE configs[1] layers (batch 2): (desc, forward plan, weight-gradient plan, Winograd points)
+    table = [(desc(2, 16, 32, 32, 512, 512, dil=4), 1, 1, 216),    # layer4: F(4,3) on all three axes
+             (desc(2, 16, 32, 32, 256, 256, dil=2), 1, 1, 144),    # layer3: 4x4x2 tiles
+             (desc(2, 64, 128, 128, 128, 64), 1, None, 144),       # decoder, wide input
+             (desc(2, 64, 128, 128, 64, 64), 2, 2, None),          # decoder, narrow: fused in-plane kernels
+             (desc(2, 32, 64, 64, 64, 64), 2, 2, None),            # layer1
+             (desc(2, 32, 64, 64, 64, 128, s=2), 0, 0, None),      # strided: direct
+             (desc(2, 16, 32, 32, 512, 2048, k=1), 0, 0, None)]    # 1x1x1: direct
+    for d, fwd, wg, pts in table:
+        assert lib.dram_conv_algo(ctypes.byref(d)) == fwd, (d.Cin, d.Cout, d.D)
+        if wg is not None:
+            assert lib.dram_conv_wgrad_algo(ctypes.byref(d)) == wg, (d.Cin, d.Cout, d.D)
+        if pts is not None:
+            assert lib.dram_wino_num_points(ctypes.byref(d)) == pts
+            assert lib.dram_wino_workspace(ctypes.byref(d), 0) >= 4 * pts * 256 * (d.Cin + d.Cout)
+            assert lib.dram_wino_v_elems(ctypes.byref(d)) % (pts * 256 * d.Cin) == 0
+    # small volumes keep the finer tiling (at least 512 tiles) and still prefer the pipeline to 16 direct workgroups
+    small = desc(1, 8, 16, 16, 512, 512, dil=4)
+    assert lib.dram_conv_algo(ctypes.byref(small)) == 1 and lib.dram_wino_num_points(ctypes.byref(small)) == 64
+    # forced modes
+    d = table[3][0]
+    monkeypatch.setenv("DRAM_CONV_ALGO", "1")
+    assert lib.dram_conv_algo(ctypes.byref(d)) == 0 and lib.dram_conv_wgrad_algo(ctypes.byref(d)) == 0
+    monkeypatch.setenv("DRAM_CONV_ALGO", "2")
+    assert lib.dram_conv_algo(ctypes.byref(d)) == 1 and lib.dram_conv_wgrad_algo(ctypes.byref(d)) == 1
+    monkeypatch.setenv("DRAM_WINO_TILING", "2,2,2")
+    assert lib.dram_wino_num_points(ctypes.byref(d)) == 64
+    monkeypatch.setenv("DRAM_CONV_ALGO", "3")
+    assert lib.dram_conv_algo(ctypes.byref(d)) == 2 and lib.dram_conv_wgrad_algo(ctypes.byref(d)) == 2
+    assert lib.dram_wgrad_w2d_workspace(ctypes.byref(d)) > 0
+    odd = desc(1, 9, 11, 13, 96, 64)                                 # Cin not a multiple of 64: no 3-D pipeline
+    assert lib.dram_wino_applicable(ctypes.byref(odd)) == 0 and lib.dram_wino2d_applicable(ctypes.byref(odd)) == 1
+
+
 def test_factories_conf_and_state_dict_contract():
     from bodyct_dram_emph_subtype_amd import med3d, utils
     m = utils.get_model_by_name("med3ddram18")
