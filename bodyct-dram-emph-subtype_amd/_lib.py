@@ -44,6 +44,12 @@ SIGNATURES = {
     "dram_conv3d_bwd_weight": (I, [P, P, P, DP, P, SZ, P]),
     "dram_conv_num_mtiles": (I, [DP]),
     "dram_conv_algo": (I, [DP]),
+    "dram_conv1x1_applicable": (I, [DP]),
+    "dram_conv1x1_num_stat_rows": (I, [DP]),
+    "dram_conv1x1_fwd": (I, [P, P, P, P, P, DP, P]),
+    "dram_conv1x1_bwd_data": (I, [P, P, P, P, P, DP, P]),
+    "dram_conv1x1_bwd_weight_workspace": (SZ, [DP]),
+    "dram_conv1x1_bwd_weight": (I, [P, P, P, DP, P, SZ, P]),
     "dram_wgrad_w2d_applicable": (I, [DP]),
     "dram_wgrad_w2d_workspace": (SZ, [DP]),
     "dram_wgrad_w2d": (I, [P, P, P, DP, P, SZ, P]),

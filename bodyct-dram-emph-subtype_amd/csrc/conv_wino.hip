@@ -494,11 +494,20 @@ __global__ __launch_bounds__(512) void wino_wgrad_out_kernel(const float* __rest
 
 // ------------------------------------------------------------------------------------------
 // NN batched GEMM:  Y[xi][m][n] = sum_k A[xi][m][k] * Bw[xi][n][k]     (M = Tpad, K % 32 == 0)
+// Optional fused epilogue (the 1x1x1 convolutions of the Bottleneck blocks run this kernel as a plain
+// GEMM, npts = 1): bias, += add * (gate > 0) (identity-shortcut gradient), per-M-tile BatchNorm sums.
+struct GemmEpilogue {
+  const float* bias;
+  const float* add;
+  const float* gate;
+  float* stats;      // [m_tiles][2][N]
+};
+
 template <int NJ>
 __global__ __launch_bounds__(512) void wino_gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ Bw,
                                                            float* __restrict__ Y, const int Mpad, const int N,
                                                            const int K, const int m_tiles, const int n_tiles,
-                                                           const int nblk, const int npts) {
+                                                           const int nblk, const int npts, const GemmEpilogue ep) {
   constexpr int BN = 64 * NJ;
   constexpr int STAGE = (256 + BN) * 32;
   __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
@@ -581,6 +590,14 @@ __global__ __launch_bounds__(512) void wino_gemm_nn_kernel(const float* __restri
     }
   }
 
+  const bool fused = ep.bias || ep.add || ep.stats;       // uniform
+  float s1[NJ], s2[NJ], bv[NJ];
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj) {
+    s1[nj] = 0.f;
+    s2[nj] = 0.f;
+    bv[nj] = ep.bias ? ep.bias[nt * BN + wn * NJ * 32 + nj * 32 + li] : 0.f;
+  }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -588,8 +605,43 @@ __global__ __launch_bounds__(512) void wino_gemm_nn_kernel(const float* __restri
       const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
       float* o = Yb + (long)row * N + wn * NJ * 32 + li;
 #pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) o[nj * 32] = acc[mi][nj][e];
+      for (int nj = 0; nj < NJ; ++nj) {
+        float v = acc[mi][nj][e];
+        if (fused) {
+          v += bv[nj];
+          if (ep.add) {
+            const long oo = (o + nj * 32) - Y;
+            const float av = ep.add[oo];
+            v += ep.gate ? (ep.gate[oo] > 0.f ? av : 0.f) : av;
+          }
+          s1[nj] += v;
+          s2[nj] += v * v;
+        }
+        o[nj * 32] = v;
+      }
     }
+  if (ep.stats) {
+    __syncthreads();
+    float* red = lds;  // [8 waves][2][32 * NJ]
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+      const float t1 = s1[nj] + __shfl_xor(s1[nj], 32, 64);
+      const float t2 = s2[nj] + __shfl_xor(s2[nj], 32, 64);
+      if (lh == 0) {
+        red[(wave * 2 + 0) * 32 * NJ + nj * 32 + li] = t1;
+        red[(wave * 2 + 1) * 32 * NJ + nj * 32 + li] = t2;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, cc = tid - which * BN;       // column within the workgroup's BN
+      const int cwn = cc / (32 * NJ), c2 = cc - cwn * 32 * NJ;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += red[((cwn * 4 + w) * 2 + which) * 32 * NJ + c2];   // wave = wn * 4 + wm
+      ep.stats[((long)mt * 2 + which) * N + nt * BN + cc] = v;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -788,7 +840,7 @@ bool plan_tn(const DramConvDesc* d, const WinoGeom& g, TnPlan& p) {
   const int base = g.npts * p.m_tiles * p.n_tiles;
   const int k32 = g.Tpad / 32;
   int ns = 1;
-  while (base * ns < 512 && ns * 2 <= k32 / 4 && ns < 16) ns *= 2;
+  while (base * ns < 512 && ns * 2 <= k32 / 4 && ns < (g.npts == 1 ? 64 : 16)) ns *= 2;
   p.nsplit = ns;
   p.kper = ((k32 + ns - 1) / ns) * 32;
   return true;
@@ -799,12 +851,16 @@ int grid_for(long waves) {
   return (int)(b > 65536 ? 65536 : (b < 1 ? 1 : b));
 }
 
-int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, int K, hipStream_t s) {
-  const int nj = nj_for(N);
-  const int m_tiles = g.Tpad / 256, n_tiles = N / (64 * nj);
+int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, int K, hipStream_t s,
+           const GemmEpilogue ep = GemmEpilogue{nullptr, nullptr, nullptr, nullptr}) {
+  int nj = nj_for(N);
+  const int m_tiles = g.Tpad / 256;
+  while (nj > 1 && (long)g.npts * m_tiles * (N / (64 * nj)) < 512) nj >>= 1;   // single-point GEMMs: fill the chip first
+  const int n_tiles = N / (64 * nj);
   const int nblk = g.npts * m_tiles * n_tiles;
-#define WNN(NJ_) \
-  hipLaunchKernelGGL((wino_gemm_nn_kernel<NJ_>), dim3(nblk), dim3(512), 0, s, A, U, Y, g.Tpad, N, K, m_tiles, n_tiles, nblk, g.npts)
+#define WNN(NJ_)                                                                                                   \
+  hipLaunchKernelGGL((wino_gemm_nn_kernel<NJ_>), dim3(nblk), dim3(512), 0, s, A, U, Y, g.Tpad, N, K, m_tiles, n_tiles, \
+                     nblk, g.npts, ep)
   if (nj == 4) WNN(4);
   else if (nj == 2) WNN(2);
   else WNN(1);
@@ -840,6 +896,102 @@ int run_conv(const float* in, const float* U, const float* bias, const float* ad
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------------------------------
+// 1x1x1 convolutions (Bottleneck conv1 / conv3, reference med3d.py:152-157) as plain GEMMs on the
+// batched-GEMM kernels above (one "point", M = voxels): no transform, no packing beyond the transposed
+// copy for the data gradient.  Geometry for the kernels: Tpad = M, npts = 1 (the blocked index is t*C).
+namespace {
+bool c1_ok(const DramConvDesc* d) {
+  if (!d || d->k != 1 || d->stride != 1 || d->pad != 0) return false;
+  if (d->B < 1 || d->D < 1 || d->H < 1 || d->W < 1) return false;
+  if (d->Do != d->D || d->Ho != d->H || d->Wo != d->W) return false;
+  if (d->Cin < 64 || d->Cout < 64 || d->Cin % 64 != 0 || d->Cout % 64 != 0) return false;
+  const long long M = (long long)d->B * d->D * d->H * d->W;
+  const long long cmax = d->Cin > d->Cout ? d->Cin : d->Cout;
+  return M % 256 == 0 && M * cmax < (1LL << 31);
+}
+WinoGeom c1_geom(const DramConvDesc* d) {
+  WinoGeom g{};
+  g.B = d->B; g.D = d->D; g.H = d->H; g.W = d->W; g.d = 1;
+  g.nz = g.ny = g.nx = 1;
+  g.npts = 1;
+  g.T = g.Tpad = d->B * d->D * d->H * d->W;
+  return g;
+}
+__global__ void slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, const long n, const int nsplit) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[(long)k * n + i];
+    out[i] = s;
+  }
+}
+}  // namespace
+
+extern "C" int dram_conv1x1_applicable(const DramConvDesc* d) { return c1_ok(d) ? 1 : 0; }
+
+extern "C" int dram_conv1x1_num_stat_rows(const DramConvDesc* d) {
+  if (!c1_ok(d)) return DRAM_ERR_UNSUPPORTED;
+  return c1_geom(d).Tpad / 256;
+}
+
+/* w2d: the reference weight [Cout][Cin][1][1][1] itself (= GEMM B operand, K = Cin contiguous) */
+extern "C" int dram_conv1x1_fwd(const float* x, const float* w2d, const float* bias, float* y, float* stats_partial,
+                                const DramConvDesc* d, dram_stream_t stream) {
+  if (!x || !w2d || !y) return DRAM_ERR_BAD_ARG;
+  if (!c1_ok(d)) return DRAM_ERR_UNSUPPORTED;
+  return run_nn(x, w2d, y, c1_geom(d), d->Cout, d->Cin, (hipStream_t)stream,
+                GemmEpilogue{bias, nullptr, nullptr, stats_partial});
+}
+
+/* wt: transposed weight [Cin][Cout] (dram_pack_conv_weight's wb with taps = 1) */
+extern "C" int dram_conv1x1_bwd_data(const float* dy, const float* wt, float* dx, const float* add, const float* gate,
+                                     const DramConvDesc* d, dram_stream_t stream) {
+  if (!dy || !wt || !dx || (gate && !add)) return DRAM_ERR_BAD_ARG;
+  if (!c1_ok(d)) return DRAM_ERR_UNSUPPORTED;
+  return run_nn(dy, wt, dx, c1_geom(d), d->Cin, d->Cout, (hipStream_t)stream, GemmEpilogue{nullptr, add, gate, nullptr});
+}
+
+extern "C" size_t dram_conv1x1_bwd_weight_workspace(const DramConvDesc* d) {
+  if (!c1_ok(d)) return 0;
+  TnPlan p;
+  plan_tn(d, c1_geom(d), p);
+  return (size_t)p.nsplit * d->Cout * d->Cin * sizeof(float);
+}
+
+extern "C" int dram_conv1x1_bwd_weight(const float* x, const float* dy, float* dw, const DramConvDesc* d, void* workspace,
+                                       size_t workspace_bytes, dram_stream_t stream) {
+  if (!x || !dy || !dw) return DRAM_ERR_BAD_ARG;
+  if (!c1_ok(d)) return DRAM_ERR_UNSUPPORTED;
+  const WinoGeom g = c1_geom(d);
+  TnPlan p;
+  plan_tn(d, g, p);
+  const size_t need = (size_t)p.nsplit * d->Cout * d->Cin * sizeof(float);
+  if (p.nsplit > 1 && (!workspace || workspace_bytes < need)) return DRAM_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* slab = p.nsplit > 1 ? (float*)workspace : dw;      // one split: the GEMM writes dw[co][ci] directly
+  const int nblk = p.nsplit * p.m_tiles * p.n_tiles;
+#define C1TN(WM_, MI_, NJ_)                                                                                         \
+  hipLaunchKernelGGL((wino_gemm_tn_kernel<WM_, MI_, NJ_>), dim3(nblk), dim3(512), 0, s, dy, x, slab, g.Tpad, d->Cout, \
+                     d->Cin, p.m_tiles, p.n_tiles, p.nsplit, p.kper, nblk, 1)
+  if (p.bm == 256 && p.bn == 256) C1TN(4, 2, 4);
+  else if (p.bm == 256 && p.bn == 128) C1TN(4, 2, 2);
+  else if (p.bm == 256 && p.bn == 64) C1TN(4, 2, 1);
+  else if (p.bm == 128 && p.bn == 256) C1TN(2, 2, 2);
+  else if (p.bm == 128 && p.bn == 128) C1TN(2, 2, 1);
+  else if (p.bm == 64 && p.bn == 256) C1TN(2, 1, 2);
+  else if (p.bm == 64 && p.bn == 128) C1TN(2, 1, 1);
+  else return DRAM_ERR_UNSUPPORTED;
+#undef C1TN
+  DRAM_LAUNCH_CHECK();
+  if (p.nsplit > 1) {
+    const long n = (long)d->Cout * d->Cin;
+    const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(grid), dim3(256), 0, s, slab, dw, n, p.nsplit);
+    DRAM_LAUNCH_CHECK();
+  }
+  return DRAM_OK;
+}
 
 // ------------------------------------------------------------------------------------------
 extern "C" int dram_wino_applicable(const DramConvDesc* d) {
@@ -881,6 +1033,7 @@ extern "C" int dram_conv_algo(const DramConvDesc* d) {
   const char* v = getenv("DRAM_CONV_ALGO");   // read per call: tests switch it between cases
   const int algo = v ? atoi(v) : 0;
   if (algo == 1) return 0;
+  if (c1_ok(d)) return 3;                              // 1x1x1: plain GEMM on the batched-GEMM kernels
   const bool w3 = dram_wino_applicable(d) != 0, w2 = dram_wino2d_applicable(d) != 0;
   if (algo == 2) return w3 ? 1 : 0;
   if (algo == 3) return w2 ? 2 : 0;
@@ -920,6 +1073,7 @@ extern "C" int dram_conv_wgrad_algo(const DramConvDesc* d) {
   const char* v = getenv("DRAM_CONV_ALGO");
   const int algo = v ? atoi(v) : 0;
   if (algo == 1) return 0;
+  if (c1_ok(d)) return 3;
   const bool w3 = dram_wino_applicable(d) != 0, w2 = dram_wgrad_w2d_applicable(d) != 0;
   if (algo == 2) return w3 ? 1 : 0;
   if (algo == 3) return w2 ? 2 : 0;

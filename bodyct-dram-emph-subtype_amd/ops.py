@@ -242,8 +242,8 @@ def conv3d_fwd_keep(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, 
     y = torch.empty(g.out_shape, device=x.device, dtype=torch.float32)
     stats = None
     if want_stats:
-        nt = {0: _L().dram_conv_num_mtiles, 1: _L().dram_wino_num_stat_rows,
-              2: _L().dram_wino2d_num_stat_rows}[algo](ctypes.byref(d))
+        nt = {0: _L().dram_conv_num_mtiles, 1: _L().dram_wino_num_stat_rows, 2: _L().dram_wino2d_num_stat_rows,
+              3: _L().dram_conv1x1_num_stat_rows}[algo](ctypes.byref(d))
         if nt <= 0:
             raise RuntimeError(f"dram_conv_num_mtiles rejected {g}")
         stats = torch.empty((nt, 2, g.Cout), device=x.device, dtype=torch.float32)
@@ -257,6 +257,11 @@ def conv3d_fwd_keep(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, 
             _chk(_L().dram_wino_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), _p(v), ctypes.byref(d), _p(ws),
                                            nbytes, _stream()), f"dram_wino_conv3d_fwd{g}")
         return y, stats, v
+    if algo == 3:                                    # 1x1x1: plain GEMM, wf [1, Cout, Cin] is the weight itself
+        with _span("conv1x1_gemm", g.flops, f"fwd {g}"):
+            _chk(_L().dram_conv1x1_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), ctypes.byref(d), _stream()),
+                 f"dram_conv1x1_fwd{g}")
+        return y, stats, None
     if algo == 2:
         with _span("conv_wino2d_kernel", g.flops, f"fwd {g}"):
             _chk(_L().dram_wino2d_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), ctypes.byref(d), _stream()),
@@ -287,6 +292,11 @@ def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] =
             _chk(_L().dram_wino_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d), _p(ws),
                                                 nbytes, _stream()), f"dram_wino_conv3d_bwd_data{g}")
         return dx
+    if algo == 3:
+        with _span("conv1x1_gemm", g.flops, f"dgrad {g}"):
+            _chk(_L().dram_conv1x1_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d), _stream()),
+                 f"dram_conv1x1_bwd_data{g}")
+        return dx
     if algo == 2:
         with _span("conv_wino2d_kernel", g.flops, f"dgrad {g}"):
             _chk(_L().dram_wino2d_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d),
@@ -307,6 +317,13 @@ def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] 
     dw = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
     _req(dw, "dw", shape=shape)
     walgo = _L().dram_conv_wgrad_algo(ctypes.byref(d))
+    if walgo == 3:
+        nbytes = _L().dram_conv1x1_bwd_weight_workspace(ctypes.byref(d))
+        ws = _workspace(max(nbytes, 4), x.device)
+        with _span("conv1x1_gemm", g.flops, f"wgrad {g}"):
+            _chk(_L().dram_conv1x1_bwd_weight(_p(x), _p(dy), _p(dw), ctypes.byref(d), _p(ws), nbytes, _stream()),
+                 f"dram_conv1x1_bwd_weight{g}")
+        return dw
     if walgo == 2:
         nbytes = _L().dram_wgrad_w2d_workspace(ctypes.byref(d))
         ws = _workspace(nbytes, x.device)

@@ -145,8 +145,25 @@ size_t dram_wgrad_w2d_workspace(const DramConvDesc* desc);
 int dram_wgrad_w2d(const float* x, const float* dy, float* dw, const DramConvDesc* desc, void* workspace,
                    size_t workspace_bytes, dram_stream_t stream);
 
+/* 1x1x1 stride-1 convolutions (Bottleneck conv1 / conv3, med3d.py:152-157) as plain GEMMs on the
+ * batched-GEMM kernels of the Winograd pipeline (M = voxels, a multiple of 256; Cin, Cout multiples of
+ * 64), with the same fused epilogues as dram_conv3d_*.  w2d is the reference weight [Cout][Cin][1][1][1]
+ * as it is; wt its transpose [Cin][Cout] (dram_pack_conv_weight's wb with taps = 1).
+ * stats_partial rows: dram_conv1x1_num_stat_rows(desc).  Weight gradient: split over voxels into slabs
+ * (workspace), summed in a fixed order. */
+int dram_conv1x1_applicable(const DramConvDesc* desc);
+int dram_conv1x1_num_stat_rows(const DramConvDesc* desc);
+int dram_conv1x1_fwd(const float* x, const float* w2d, const float* bias, float* y, float* stats_partial,
+                     const DramConvDesc* desc, dram_stream_t stream);
+int dram_conv1x1_bwd_data(const float* dy, const float* wt, float* dx, const float* add, const float* gate,
+                          const DramConvDesc* desc, dram_stream_t stream);
+size_t dram_conv1x1_bwd_weight_workspace(const DramConvDesc* desc);
+int dram_conv1x1_bwd_weight(const float* x, const float* dy, float* dw, const DramConvDesc* desc, void* workspace,
+                            size_t workspace_bytes, dram_stream_t stream);
+
 /* The library's plan for one convolution: 0 direct implicit GEMM (dram_conv3d_*), 1 Winograd
- * F(2x2x2,3x3x3) pipeline (dram_wino_*), 2 fused in-plane Winograd (dram_wino2d_*).
+ * F(2x2x2,3x3x3) pipeline (dram_wino_*), 2 fused in-plane Winograd (dram_wino2d_*), 3 1x1x1 GEMM
+ * (dram_conv1x1_*; dram_conv_wgrad_algo likewise).
  * env DRAM_CONV_ALGO: 1 = always direct, 2 / 3 = path 1 / 2 wherever applicable (tests). */
 int dram_conv_algo(const DramConvDesc* desc);
 

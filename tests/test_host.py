@@ -54,7 +54,8 @@ def test_conv_plan_is_host_side_and_consistent(monkeypatch):
              (desc(2, 64, 128, 128, 64, 64), 2, 2, None),          # decoder, narrow: fused in-plane kernels
              (desc(2, 32, 64, 64, 64, 64), 2, 2, None),            # layer1
              (desc(2, 32, 64, 64, 64, 128, s=2), 0, 0, None),      # strided: direct
-             (desc(2, 16, 32, 32, 512, 2048, k=1), 0, 0, None)]    # 1x1x1: direct
+             (desc(2, 16, 32, 32, 512, 2048, k=1), 3, 3, None),    # 1x1x1 on a 256-multiple of voxels: plain GEMM
+             (desc(1, 5, 6, 7, 128, 64, k=1), 0, 0, None)]         # 1x1x1, ragged voxel count: direct kernel
     for d, fwd, wg, pts in table:
         assert lib.dram_conv_algo(ctypes.byref(d)) == fwd, (d.Cin, d.Cout, d.D)
         if wg is not None:

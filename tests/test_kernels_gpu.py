@@ -97,6 +97,54 @@ def test_conv3d_fwd_bwd(ops, monkeypatch, case):
         assert rel_l2(dw.cpu(), gw_ref) < 5e-6
 
 
+C1_CASES = [
+    # B, D, H, W, Cin, Cout    (1x1x1 convolutions with a 256-multiple of voxels: the batched-GEMM kernels)
+    (1, 4, 8, 8, 64, 64),
+    (2, 8, 8, 8, 128, 256),
+    (1, 8, 16, 16, 256, 64),
+    (1, 8, 16, 32, 512, 192),           # Cout only a multiple of 64; the weight gradient splits over voxels
+]
+
+
+@pytest.mark.parametrize("case", C1_CASES, ids=[str(c) for c in C1_CASES])
+def test_conv1x1_gemm_path(ops, monkeypatch, case):
+    """Bottleneck 1x1x1 convolutions as plain GEMMs (plan 3): forward with bias + fused BN sums, data
+    gradient with the fused shortcut-gradient epilogue, weight gradient; and agreement with the direct kernel."""
+    monkeypatch.delenv("DRAM_CONV_ALGO", raising=False)
+    B, D, H, W, Cin, Cout = case
+    x = rnd(B, Cin, D, H, W, seed=1).requires_grad_(True)
+    w = (rnd(Cout, Cin, 1, 1, 1, seed=2) * 0.1).requires_grad_(True)
+    bias = rnd(Cout, seed=3)
+    y_ref = F.conv3d(x, w, bias)
+    gy = rnd(*y_ref.shape, seed=4)
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, [x, w], gy)
+    g = ops.ConvGeom(B, D, H, W, Cin, Cout, 1, 1, 0, 1)
+    assert ops.conv_algo(g) == 3
+    wf, wb = ops.pack_conv_weight(w.detach().to(DEV), True, True, g)
+    assert wf.shape == (1, Cout, Cin) and wb.shape == (1, Cin, Cout)
+    xd, gyd = to_ndhwc(x.detach()), to_ndhwc(gy)
+    y, stats = ops.conv3d_fwd(xd, wf, bias.to(DEV), g, True)
+    assert rel_l2(to_ncdhw(y), y_ref.detach()) < 2e-6
+    s = ops.reduce_partials(stats).cpu()
+    yr = y_ref.detach().double()
+    assert torch.allclose(s[0], yr.sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[1], (yr * yr).sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    y2, st2 = ops.conv3d_fwd(xd, wf, None, g, False)
+    assert st2 is None and rel_l2(to_ncdhw(y2), F.conv3d(x, w).detach()) < 2e-6
+    add = rnd(B, Cin, D, H, W, seed=5)
+    gate = rnd(B, Cin, D, H, W, seed=6)
+    dx = ops.conv3d_bwd_data(gyd, wb, g)
+    assert rel_l2(to_ncdhw(dx), gx_ref) < 2e-6
+    dx2 = ops.conv3d_bwd_data(gyd, wb, g, to_ndhwc(add), to_ndhwc(gate))
+    assert rel_l2(to_ncdhw(dx2), gx_ref + add * (gate > 0).float()) < 2e-6
+    dw = ops.conv3d_bwd_weight(xd, gyd, g)
+    assert rel_l2(dw.cpu(), gw_ref) < 5e-6
+    assert torch.equal(dw, ops.conv3d_bwd_weight(xd, gyd, g))
+    monkeypatch.setenv("DRAM_CONV_ALGO", "1")
+    y1, _ = ops.conv3d_fwd(xd, wf, bias.to(DEV), g, False)        # same packed layout (taps = 1): direct kernel
+    assert rel_l2(y.cpu(), y1.cpu()) < 2e-6
+
+
 V3_CASES = [
     # forced v3 plan "tz3,bn", then (B, D, H, W, Cin, Cout, dil)
     ("8,64", (1, 9, 10, 17, 64, 64, 1)),
