@@ -23,9 +23,11 @@
 // GEMM kernels: 512 threads (8 waves as 4(M) x 2(N)), tile 256 x (64*NJ) x 32, operands staged by
 // LDS-DMA (global_load_lds_dwordx4), double-buffered, one barrier per K-step; NN form reads both
 // operands with the ds_read_b128 k-permutation trick of conv_igemm.hip, TN form reads [t][c] rows
-// with ds_read_b32 (lanes = consecutive channels).
+// with ds_read_b32 (lanes = consecutive channels).  Opt-in bf16 matrix-core forms of both (DRAM_MATH,
+// split-bf16 operand images, see split_pack / wino_gemm_nn_bf16_kernel / wino_gemm_tn_bf16_kernel).
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "common.h"
 
 namespace {
@@ -64,6 +66,25 @@ __device__ __forceinline__ void tile_origin(const WinoGeom& g, int t, int& b, in
 // reads a compact region (all points of its tiles) instead of one 256-B row in each of 64-216 planes.
 __device__ __host__ __forceinline__ long wino_index(int t, int npts, int C) {
   return (((long)(t >> 8) * npts) * 256 + (t & 255)) * C;
+}
+
+// ---- split-bf16 operand image (math modes "bf16x3" / "bf16", see wino_gemm_nn_bf16_kernel) -------------
+// A GEMM operand row of C fp32 channels becomes, per 32-channel block, 32 bf16 "hi" values (64 B) followed
+// by 32 bf16 "lo" values (64 B): hi = bf16(v) (round to nearest even), lo = bf16(v - hi), so hi + lo carries
+// 16 mantissa bits of v.  Same bytes per row as fp32, so every buffer size and DMA pattern is unchanged.
+// Lanes are consecutive channels: the even lane of a pair writes the dword (hi_e, hi_e+1), the odd lane
+// (lo_e, lo_e+1); the partner's half arrives by a quad-permute DPP move (no LDS).
+__device__ __forceinline__ int split_pos(int lane) {      // dword position inside the lane's 64-channel block
+  return (lane >> 5) * 32 + (lane & 1) * 16 + ((lane & 31) >> 1);
+}
+__device__ __forceinline__ float split_pack(float v, bool odd) {
+  const __bf16 h = (__bf16)v;
+  const __bf16 l = (__bf16)(v - (float)h);
+  const unsigned hb = __builtin_bit_cast(unsigned short, h), lb = __builtin_bit_cast(unsigned short, l);
+  const unsigned send = odd ? hb : lb;
+  const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  const unsigned lo16 = odd ? recv : hb, hi16 = odd ? lb : recv;
+  return __uint_as_float(lo16 | (hi16 << 16));
 }
 
 // ---- 1-D transforms (Lavin & Gray): F(2,3) with points {0, 1, -1, inf}, F(4,3) with {0, +-1, +-2, inf} --
@@ -172,7 +193,7 @@ template <int N> __device__ __forceinline__ constexpr float g_coef(int r, int k)
 // row re-applied to the raw planes (36 live values, 3.7x the loads) measured 2x SLOWER: the kernel is
 // bound by vector-memory instructions, not registers.
 // Rows t in [T, Tpad) are written as zeros (the TN GEMM contracts over t).
-template <int MODE, int NZ, int NY, int NX>
+template <int MODE, int NZ, int NY, int NX, bool SPLIT>
 __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                       const WinoGeom g, const int C) {
   constexpr int NI = NZ + 2, NJ = NY + 2, NK = NX + 2;
@@ -183,7 +204,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
   for (long w = blockIdx.x * 4L + wave; w < total; w += gridDim.x * 4L) {
     const int t = (int)(w / cblks);
     const int c = (int)(w - (long)t * cblks) * 64 + lane;
-    float* o = out + wino_index(t, g.npts, C) + c;
+    float* o = out + wino_index(t, g.npts, C) + (SPLIT ? c - lane + split_pos(lane) : c);
     float v[NI][NJ][NK];
     if (t >= g.T) {
 #pragma unroll
@@ -286,7 +307,8 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int k = 0; k < NK; ++k) o[((i * NJ + j) * NK + k) * plane] = v[i][j][k];
+        for (int k = 0; k < NK; ++k)
+          o[((i * NJ + j) * NK + k) * plane] = SPLIT ? split_pack(v[i][j][k], lane & 1) : v[i][j][k];
   }
 }
 
@@ -392,7 +414,8 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 //   blockIdx.y == 1: ub[xi][ci][co], taps flipped  (data-gradient B operand, K = co contiguous)
 template <int NZ, int NY, int NX>
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ uf,
-                                                          float* __restrict__ ub, const int Cout, const int Cin) {
+                                                          float* __restrict__ ub, const int Cout, const int Cin,
+                                                          const int split) {
   constexpr int NI = NZ + 2, NJ = NY + 2, NK = NX + 2;
   const bool bwd = blockIdx.y == 1;
   float* dst = bwd ? ub : uf;
@@ -404,6 +427,8 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
   if (!bwd) { ci = (int)(i % Cin); co = (int)(i / Cin); }
   else { co = (int)(i % Cout); ci = (int)(i / Cout); }
   const float* src = w + ((long)co * Cin + ci) * 27;
+  const int lane = threadIdx.x & 63;       // == K index mod 64 (K = the contiguous dimension, a multiple of 64)
+  const long io = split ? i - lane + split_pos(lane) : i;
   float gw[3][3][3];
 #pragma unroll
   for (int a = 0; a < 27; ++a) (&gw[0][0][0])[a] = src[bwd ? 26 - a : a];
@@ -428,7 +453,8 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int k = 0; k < NK; ++k) dst[((long)(a * NJ + j) * NK + k) * n + i] = u[j][k];
+      for (int k = 0; k < NK; ++k)
+        dst[((long)(a * NJ + j) * NK + k) * n + io] = split ? split_pack(u[j][k], lane & 1) : u[j][k];
   }
 }
 
@@ -645,6 +671,121 @@ __global__ __launch_bounds__(512) void wino_gemm_nn_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------
+// The same NN batched GEMM on the bf16 matrix cores, operands in the split-bf16 image (split_pack):
+//   NT = 3 ("bf16x3"):  a*b ~= ah*bh + ah*bl + al*bh   -- fp32 accumulation, the dropped al*bl term and the
+//                       split residues are <= 2^-16 relative per product (fp32 MFMA: 2^-24)
+//   NT = 1 ("bf16"):    a*b ~= ah*bh                    -- bf16 operands, fp32 accumulation (autocast-like)
+// v_mfma_f32_32x32x16_bf16 runs 32 cycles for 16 k (the fp32 32x32x2 form: 64 cycles for 2 k), so three
+// products per k cost 96 cycles where the fp32 kernel spends 512.  Tile, DMA pattern, swizzle and epilogue
+// are those of wino_gemm_nn_kernel (the image has the same bytes per row); per 32-channel stage a lane-half
+// reads hi slot 2j + lh and lo slot 4 + 2j + lh (8 channels each) for the two k16 steps j.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int NJ, int NT>
+__global__ __launch_bounds__(512) void wino_gemm_nn_bf16_kernel(const float* __restrict__ A, const float* __restrict__ Bw,
+                                                                float* __restrict__ Y, const int Mpad, const int N,
+                                                                const int K, const int m_tiles, const int n_tiles,
+                                                                const int nblk, const int npts) {
+  constexpr int BN = 64 * NJ;
+  constexpr int STAGE = (256 + BN) * 32;
+  __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = xcd_remap(blockIdx.x, nblk);
+  const int nt = L % n_tiles;
+  const int r0 = L / n_tiles;
+  const int mt = r0 % m_tiles;
+  const int xi = r0 / m_tiles;
+  const float* Ab = A + (((long)mt * npts + xi) * 256) * K;
+  const float* Bb = Bw + ((long)xi * N + (long)nt * BN) * K;
+  float* Yb = Y + (((long)mt * npts + xi) * 256) * N + nt * BN;
+
+  const int sub = lane >> 3, pslot = lane & 7;
+  const int s_even = pslot ^ (lane >> 4), s_odd = s_even ^ 4;
+  int aoff[4], boff[NJ];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) aoff[j] = (32 * wave + 8 * j + sub) * K + ((j & 1) ? s_odd : s_even) * 4;
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int nrow = 8 * NJ * wave + 8 * jj + sub;
+    boff[jj] = nrow * K + (pslot ^ ((nrow >> 1) & 7)) * 4;
+  }
+  auto issue = [&](int it, int stage) __attribute__((always_inline)) {
+    float* as = lds + stage * STAGE + 32 * wave * 32;
+    float* bs = lds + stage * STAGE + 256 * 32 + 8 * NJ * wave * 32;
+    const float* ag = Ab + it * 32;
+    const float* bg = Bb + it * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ag + aoff[j]),
+                                       (__attribute__((address_space(3))) void*)(as + j * 8 * 32), 16, 0, 0);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bg + boff[jj]),
+                                       (__attribute__((address_space(3))) void*)(bs + jj * 8 * 32), 16, 0, 0);
+  };
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int rsw = (li >> 1) & 7;
+  const int a_row = (wm * 64 + li) * 32;
+  const int b_row = 256 * 32 + (wn * NJ * 32 + li) * 32;
+  const int niter = K / 32;
+
+  issue(0, 0);
+  for (int it = 0; it < niter; ++it) {
+    __syncthreads();
+    if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
+    const float* st = lds + (it & 1) * STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int sh = ((2 * j + lh) ^ rsw) * 4, sl = ((4 + 2 * j + lh) ^ rsw) * 4;
+      bf16x8 ah[2], al[2], bh[NJ], bl[NJ];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        ah[mi] = *reinterpret_cast<const bf16x8*>(st + a_row + mi * 32 * 32 + sh);
+        if (NT > 1) al[mi] = *reinterpret_cast<const bf16x8*>(st + a_row + mi * 32 * 32 + sl);
+      }
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) {
+        bh[nj] = *reinterpret_cast<const bf16x8*>(st + b_row + nj * 32 * 32 + sh);
+        if (NT > 1) bl[nj] = *reinterpret_cast<const bf16x8*>(st + b_row + nj * 32 * 32 + sl);
+      }
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          if (NT > 1) {
+            acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[nj], acc[mi][nj], 0, 0, 0);
+            acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[nj], acc[mi][nj], 0, 0, 0);
+          }
+          acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[nj], acc[mi][nj], 0, 0, 0);
+        }
+    }
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      float* o = Yb + (long)row * N + wn * NJ * 32 + li;
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) o[nj * 32] = acc[mi][nj][e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // TN batched GEMM (weight gradient):
 //   slab[split][xi][m][n] = sum_{t in split} Ah[xi][t][m] * Bh[xi][t][n]
 // 8 waves as WMW (M) x 8/WMW (N), wave tile 32*MI x 32*NJ; M % (WMW*32*MI) == 0, N may be ragged
@@ -747,6 +888,161 @@ __global__ __launch_bounds__(512) void wino_gemm_tn_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------
+// TN batched GEMM on the bf16 matrix cores (weight gradient in the "bf16x3" / "bf16" math modes): both
+// operands are split-bf16 images [t][channel] and the contraction runs over the ROW index t, so an MFMA
+// operand (8 consecutive t of one channel per lane) is a transposed read of the LDS image:
+// ds_read_b64_tr_b16 hands a 16-lane group the 4 rows x 16 columns block it addresses, column-major.
+// The image keeps the DMA's lane-linear rows; to spread the 4 rows of a block over the banks the 64-B
+// chunks (= the hi or the lo half of one 32-channel block) are XOR-swizzled by (row & 3) inside each
+// 256-B window, applied on the source address of the DMA and on the read address.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <int WMW, int MI, int NJ, int NT>
+__global__ __launch_bounds__(512) void wino_gemm_tn_bf16_kernel(const float* __restrict__ Ah, const float* __restrict__ Bh,
+                                                                float* __restrict__ slab, const int Tpad, const int M,
+                                                                const int N, const int m_tiles, const int n_tiles,
+                                                                const int nsplit, const int kper, const int nblk,
+                                                                const int npts) {
+  constexpr int WNW = 8 / WMW;
+  constexpr int BM = WMW * 32 * MI, BN = WNW * 32 * NJ;
+  static_assert(BM % 64 == 0 && BM <= 256 && BN % 64 == 0 && BN <= 256, "one DMA piece = 256 floats");
+  constexpr int STAGE = 32 * (BM + BN);
+  constexpr int AQ = BM / 4, ARPP = 64 / AQ, APW = BM / 64;
+  constexpr int BQ = BN / 4, BRPP = 64 / BQ, BPW = BN / 64;
+  __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int L = xcd_remap(blockIdx.x, nblk);
+  const int nt = L % n_tiles; L /= n_tiles;
+  const int mt = L % m_tiles; L /= m_tiles;
+  const int split = L % nsplit;
+  const int xi = L / nsplit;
+  const int t0 = split * kper;
+  const int t1 = (t0 + kper < Tpad) ? t0 + kper : Tpad;
+
+  // DMA source columns: the piece j of a wave covers stage rows (APW * wave + j) * ARPP + lane / AQ, whose
+  // low two bits are (j * ARPP + lane / AQ) & 3 (APW * ARPP == 4).
+  int acol[APW], bcol[BPW];
+#pragma unroll
+  for (int j = 0; j < APW; ++j) {
+    const int r3 = (j * ARPP + lane / AQ) & 3, slot = lane % AQ;
+    acol[j] = mt * BM + ((((slot >> 2) ^ r3) << 2) | (slot & 3)) * 4;
+  }
+#pragma unroll
+  for (int j = 0; j < BPW; ++j) {
+    const int r3 = (j * BRPP + lane / BQ) & 3, slot = lane % BQ;
+    int c = nt * BN + ((((slot >> 2) ^ r3) << 2) | (slot & 3)) * 4;
+    bcol[j] = c > N - 4 ? N - 4 : c;
+  }
+  const float* Ab = Ah + (long)(lane / AQ) * M;
+  const float* Bb = Bh + (long)(lane / BQ) * N;
+
+  auto issue = [&](int it, int stage) __attribute__((always_inline)) {
+    float* as = lds + stage * STAGE;
+    float* bs = as + 32 * BM;
+    const int tt = t0 + it * 32;
+    const long row = ((long)(tt >> 8) * npts + xi) * 256 + (tt & 255);
+    const float* ag = Ab + row * M;
+    const float* bg = Bb + row * N;
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+      const int p = APW * wave + j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ag + (long)(p * ARPP) * M + acol[j]),
+                                       (__attribute__((address_space(3))) void*)(as + p * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int jj = 0; jj < BPW; ++jj) {
+      const int p = BPW * wave + jj;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bg + (long)(p * BRPP) * N + bcol[jj]),
+                                       (__attribute__((address_space(3))) void*)(bs + p * 256), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave % WMW, wn = wave / WMW;
+  const int niter = (t1 - t0) / 32;
+
+  // transposed-read addresses (bytes inside a stage): 16-lane group g4 = (k half, column half), lane 4q + p
+  // of the group addresses row q, columns 4p .. 4p + 3 of its block
+  const int g4 = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
+  const int rrow = (g4 >> 1) * 8 + q;
+  const int cbyte = (g4 & 1) * 32 + p4 * 8;
+  int a_hi[MI], a_lo[MI], b_hi[NJ], b_lo[NJ];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int ch = 2 * (wm * MI + mi);
+    a_hi[mi] = rrow * BM * 4 + ((ch ^ q) * 64) + cbyte;
+    a_lo[mi] = rrow * BM * 4 + (((ch + 1) ^ q) * 64) + cbyte;
+  }
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj) {
+    const int ch = 2 * (wn * NJ + nj);
+    b_hi[nj] = 32 * BM * 4 + rrow * BN * 4 + ((ch ^ q) * 64) + cbyte;
+    b_lo[nj] = 32 * BM * 4 + rrow * BN * 4 + (((ch + 1) ^ q) * 64) + cbyte;
+  }
+  auto frag = [&](const char* st, int off, int rstride) __attribute__((always_inline)) {
+    const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + off));
+    const s16x4 r1 =
+        __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + off + 4 * rstride));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+
+  if (niter > 0) issue(0, 0);
+  for (int it = 0; it < niter; ++it) {
+    __syncthreads();
+    if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
+    const char* st = reinterpret_cast<const char*>(lds + (it & 1) * STAGE);
+#pragma unroll
+    for (int s16 = 0; s16 < 2; ++s16) {
+      bf16x8 ah[MI], al[MI], bh[NJ], bl[NJ];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        ah[mi] = frag(st, a_hi[mi] + s16 * 16 * BM * 4, BM * 4);
+        if (NT > 1) al[mi] = frag(st, a_lo[mi] + s16 * 16 * BM * 4, BM * 4);
+      }
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) {
+        bh[nj] = frag(st, b_hi[nj] + s16 * 16 * BN * 4, BN * 4);
+        if (NT > 1) bl[nj] = frag(st, b_lo[nj] + s16 * 16 * BN * 4, BN * 4);
+      }
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          if (NT > 1) {
+            acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[nj], acc[mi][nj], 0, 0, 0);
+            acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[nj], acc[mi][nj], 0, 0, 0);
+          }
+          acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[nj], acc[mi][nj], 0, 0, 0);
+        }
+    }
+  }
+
+  float* sb = slab + (((long)split * npts + xi) * M + mt * BM) * N + nt * BN;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm * 32 * MI + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      float* o = sb + (long)row * N + wn * 32 * NJ + li;
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj)
+        if (nt * BN + wn * 32 * NJ + nj * 32 + li < N) o[nj * 32] = acc[mi][nj][e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // instantiated tilings (z, y, x outputs per tile): 2x2x2, 4x2x2, 4x4x2, 4x4x4
 #define WINO_TILING_DISPATCH(g_, CALL_)                                 \
@@ -756,6 +1052,17 @@ __global__ __launch_bounds__(512) void wino_gemm_tn_kernel(const float* __restri
     else if ((g_).nz == 4) { CALL_(4, 2, 2); }                          \
     else { CALL_(2, 2, 2); }                                            \
   } while (0)
+// Arithmetic of the Winograd-domain GEMMs, DRAM_MATH = "f32" (default: fp32 MFMA) | "bf16x3" (split-bf16
+// operands, three bf16 MFMA products per fp32 product, ~2^-16 per product) | "bf16" (bf16 operands, fp32
+// accumulation).  Read per call, like the other overrides: tests switch it between cases.
+int math_mode() {
+  const char* e = getenv("DRAM_MATH");
+  if (!e) return 0;
+  if (!strcmp(e, "bf16x3")) return 1;
+  if (!strcmp(e, "bf16")) return 2;
+  return 0;
+}
+
 bool wino_geom_ok(const DramConvDesc* d) {
   if (!d) return false;
   if (d->B < 1 || d->D < 1 || d->H < 1 || d->W < 1) return false;
@@ -784,6 +1091,7 @@ void pick_tiling(const DramConvDesc* d, int& nz, int& ny, int& nx) {
       for (int i = 0; i < 4; ++i)
         if (cand[i][0] == a && cand[i][1] == b && cand[i][2] == c) { nz = a; ny = b; nx = c; return; }
   }
+  if (math_mode() == 2) { nz = ny = nx = 2; return; }   // bf16 operands: F(4,3) amplifies their 2^-9 rounding 3-17x
   const int sz = (d->D + d->dil - 1) / d->dil, sy = (d->H + d->dil - 1) / d->dil, sx = (d->W + d->dil - 1) / d->dil;
   // F(4,3) on all three axes pays only on GEMM-dominated (>= 512 x 256 channel) layers: its 216-value
   // input transform spills into the AGPR half of the register file (measured: -12 % on 512->512,
@@ -852,12 +1160,22 @@ int grid_for(long waves) {
 }
 
 int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, int K, hipStream_t s,
-           const GemmEpilogue ep = GemmEpilogue{nullptr, nullptr, nullptr, nullptr}) {
+           const GemmEpilogue ep = GemmEpilogue{nullptr, nullptr, nullptr, nullptr}, const int math = 0) {
   int nj = nj_for(N);
   const int m_tiles = g.Tpad / 256;
   while (nj > 1 && (long)g.npts * m_tiles * (N / (64 * nj)) < 512) nj >>= 1;   // single-point GEMMs: fill the chip first
   const int n_tiles = N / (64 * nj);
   const int nblk = g.npts * m_tiles * n_tiles;
+  if (math) {      // split-bf16 operand images (Winograd pipeline only; no fused epilogue there)
+#define WNB(NJ_, NT_)                                                                                                  \
+  hipLaunchKernelGGL((wino_gemm_nn_bf16_kernel<NJ_, NT_>), dim3(nblk), dim3(512), 0, s, A, U, Y, g.Tpad, N, K, m_tiles, \
+                     n_tiles, nblk, g.npts)
+    if (math == 1) { if (nj == 4) WNB(4, 3); else if (nj == 2) WNB(2, 3); else WNB(1, 3); }
+    else { if (nj == 4) WNB(4, 1); else if (nj == 2) WNB(2, 1); else WNB(1, 1); }
+#undef WNB
+    DRAM_LAUNCH_CHECK();
+    return DRAM_OK;
+  }
 #define WNN(NJ_)                                                                                                   \
   hipLaunchKernelGGL((wino_gemm_nn_kernel<NJ_>), dim3(nblk), dim3(512), 0, s, A, U, Y, g.Tpad, N, K, m_tiles, n_tiles, \
                      nblk, g.npts, ep)
@@ -878,12 +1196,20 @@ int run_conv(const float* in, const float* U, const float* bias, const float* ad
   if (!ws || ws_bytes < need) return DRAM_ERR_WORKSPACE;
   float* V = v_keep ? v_keep : (float*)ws;          // kept for the weight gradient when the caller asks
   float* Mh = (float*)ws + (size_t)g.npts * g.Tpad * K;
-#define W_IN(NZ_, NY_, NX_) \
-  hipLaunchKernelGGL((wino_in_kernel<0, NZ_, NY_, NX_>), dim3(grid_for((long)g.Tpad * (K / 64))), dim3(256), 0, s, in, V, g, K)
+  const int math = math_mode();
+#define W_IN(NZ_, NY_, NX_)                                                                                              \
+  do {                                                                                                                   \
+    if (math)                                                                                                            \
+      hipLaunchKernelGGL((wino_in_kernel<0, NZ_, NY_, NX_, true>), dim3(grid_for((long)g.Tpad * (K / 64))), dim3(256), 0, s, \
+                         in, V, g, K);                                                                                   \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((wino_in_kernel<0, NZ_, NY_, NX_, false>), dim3(grid_for((long)g.Tpad * (K / 64))), dim3(256), 0, \
+                         s, in, V, g, K);                                                                                \
+  } while (0)
   WINO_TILING_DISPATCH(g, W_IN);
 #undef W_IN
   DRAM_LAUNCH_CHECK();
-  const int rc = run_nn(V, U, Mh, g, N, K, s);
+  const int rc = run_nn(V, U, Mh, g, N, K, s, GemmEpilogue{nullptr, nullptr, nullptr, nullptr}, math);
   if (rc != DRAM_OK) return rc;
   const int ntb = (g.T + WINO_TPB - 1) / WINO_TPB;
 #define W_OUT(NZ_, NY_, NX_)                                                                                              \
@@ -1117,7 +1443,8 @@ extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, const
   const dim3 grid((unsigned)((n + 255) / 256), 2);
   const WinoGeom g = make_geom(d);
 #define W_WT(NZ_, NY_, NX_) \
-  hipLaunchKernelGGL((wino_weight_kernel<NZ_, NY_, NX_>), grid, dim3(256), 0, (hipStream_t)stream, w, uf, ub, d->Cout, d->Cin)
+  hipLaunchKernelGGL((wino_weight_kernel<NZ_, NY_, NX_>), grid, dim3(256), 0, (hipStream_t)stream, w, uf, ub, d->Cout, d->Cin, \
+                     math_mode() ? 1 : 0)
   WINO_TILING_DISPATCH(g, W_WT);
 #undef W_WT
   DRAM_LAUNCH_CHECK();
@@ -1181,25 +1508,41 @@ extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache,
   float* V = (float*)workspace;                               // [64][Tpad][Cin]
   float* Dh = V + (size_t)g.npts * g.Tpad * d->Cin;           // [npts][Tpad][Cout]
   float* slab = Dh + (size_t)g.npts * g.Tpad * d->Cout;       // [nsplit][npts][Cout][Cin]
+  const int math = math_mode();      // the cached V is in the image of the mode it was written in: same mode here
+#define W_INT(MODE_, NZ_, NY_, NX_, SRC_, DST_, C_)                                                                      \
+  do {                                                                                                                   \
+    if (math)                                                                                                            \
+      hipLaunchKernelGGL((wino_in_kernel<MODE_, NZ_, NY_, NX_, true>), dim3(grid_for((long)g.Tpad * ((C_) / 64))),        \
+                         dim3(256), 0, s, SRC_, DST_, g, C_);                                                            \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((wino_in_kernel<MODE_, NZ_, NY_, NX_, false>), dim3(grid_for((long)g.Tpad * ((C_) / 64))),       \
+                         dim3(256), 0, s, SRC_, DST_, g, C_);                                                            \
+  } while (0)
   if (v_cache) V = const_cast<float*>(v_cache);
   else {
-#define W_INX(NZ_, NY_, NX_)                                                                                           \
-  hipLaunchKernelGGL((wino_in_kernel<0, NZ_, NY_, NX_>), dim3(grid_for((long)g.Tpad * (d->Cin / 64))), dim3(256), 0, s, x, V, \
-                     g, d->Cin)
+#define W_INX(NZ_, NY_, NX_) W_INT(0, NZ_, NY_, NX_, x, V, d->Cin)
     WINO_TILING_DISPATCH(g, W_INX);
 #undef W_INX
     DRAM_LAUNCH_CHECK();
   }
-#define W_INDY(NZ_, NY_, NX_)                                                                                            \
-  hipLaunchKernelGGL((wino_in_kernel<1, NZ_, NY_, NX_>), dim3(grid_for((long)g.Tpad * (d->Cout / 64))), dim3(256), 0, s, dy, Dh, \
-                     g, d->Cout)
+#define W_INDY(NZ_, NY_, NX_) W_INT(1, NZ_, NY_, NX_, dy, Dh, d->Cout)
   WINO_TILING_DISPATCH(g, W_INDY);
 #undef W_INDY
+#undef W_INT
   DRAM_LAUNCH_CHECK();
   const int nblk = g.npts * p.nsplit * p.m_tiles * p.n_tiles;
-#define WTN(WM_, MI_, NJ_)                                                                                       \
-  hipLaunchKernelGGL((wino_gemm_tn_kernel<WM_, MI_, NJ_>), dim3(nblk), dim3(512), 0, s, Dh, V, slab, g.Tpad, d->Cout, \
-                     d->Cin, p.m_tiles, p.n_tiles, p.nsplit, p.kper, nblk, g.npts)
+#define WTN(WM_, MI_, NJ_)                                                                                             \
+  do {                                                                                                                 \
+    if (math == 1)                                                                                                     \
+      hipLaunchKernelGGL((wino_gemm_tn_bf16_kernel<WM_, MI_, NJ_, 3>), dim3(nblk), dim3(512), 0, s, Dh, V, slab, g.Tpad, \
+                         d->Cout, d->Cin, p.m_tiles, p.n_tiles, p.nsplit, p.kper, nblk, g.npts);                       \
+    else if (math == 2)                                                                                                \
+      hipLaunchKernelGGL((wino_gemm_tn_bf16_kernel<WM_, MI_, NJ_, 1>), dim3(nblk), dim3(512), 0, s, Dh, V, slab, g.Tpad, \
+                         d->Cout, d->Cin, p.m_tiles, p.n_tiles, p.nsplit, p.kper, nblk, g.npts);                       \
+    else                                                                                                               \
+      hipLaunchKernelGGL((wino_gemm_tn_kernel<WM_, MI_, NJ_>), dim3(nblk), dim3(512), 0, s, Dh, V, slab, g.Tpad,       \
+                         d->Cout, d->Cin, p.m_tiles, p.n_tiles, p.nsplit, p.kper, nblk, g.npts);                       \
+  } while (0)
   if (p.bm == 256 && p.bn == 256) WTN(4, 2, 4);
   else if (p.bm == 256 && p.bn == 128) WTN(4, 2, 2);
   else if (p.bm == 256 && p.bn == 64) WTN(4, 2, 1);

@@ -102,7 +102,13 @@ int dram_conv_num_mtiles(const DramConvDesc* desc);
  *   v_keep / v_cache: optional [dram_wino_v_elems(desc)] floats; the forward pass leaves the
  *                         transformed input there and the weight gradient reuses it instead of
  *                         transforming x again (x may then be NULL).
- * Deterministic (no atomics; the weight gradient sums its slabs in a fixed order). */
+ * Deterministic (no atomics; the weight gradient sums its slabs in a fixed order).
+ * Arithmetic of the Winograd-domain GEMMs: fp32 MFMA by default.  The environment variable
+ * DRAM_MATH = "bf16x3" | "bf16" (opt-in, read per call) switches uf / ub / V and the transformed
+ * gradients to a split-bf16 image of the same size (hi = bf16(v), lo = bf16(v - hi) per 32-channel
+ * block) and the GEMMs to v_mfma_f32_32x32x16_bf16: three products hi*hi + hi*lo + lo*hi per fp32
+ * product ("bf16x3", ~2^-16 per product) or hi*hi alone ("bf16", F(2,3) tiles only).  Weights packed
+ * and V cached under one mode must be consumed under the same mode. */
 int dram_wino_applicable(const DramConvDesc* desc);
 int dram_conv_wgrad_algo(const DramConvDesc* desc);
 int dram_wino_num_points(const DramConvDesc* desc);

@@ -249,6 +249,41 @@ def test_conv3d_winograd_path(ops, monkeypatch, case, tiling):
     assert rel_l2(y.cpu(), y1.cpu()) < tol
 
 
+MATH_TOL = {  # measured rel-L2 vs fp64 (tools/math_check.py): fp32 6.5e-7 / 1.1e-5, bf16x3 9.8e-6 / 1.7e-4, bf16 5.2e-3 / 9e-2
+    ("bf16x3", "2,2,2"): 3e-5, ("bf16x3", "4,4,4"): 5e-4, ("bf16", "2,2,2"): 1.5e-2, ("bf16", "4,4,4"): 0.25}
+
+
+@pytest.mark.parametrize("tiling", ["2,2,2", "4,4,4"], ids=["F222", "F444"])
+@pytest.mark.parametrize("math", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("case", [WINO_CASES[1], WINO_CASES[4], WINO_CASES[6]], ids=str)
+def test_conv3d_winograd_bf16_math_modes(ops, monkeypatch, case, math, tiling):
+    """DRAM_MATH = bf16x3 / bf16: the Winograd-domain GEMMs on the bf16 matrix cores (split-bf16 operand
+    images written by the transforms; NN form for forward / data gradient, transposed-LDS-read TN form for
+    the weight gradient, with and without the cached transformed input) against F.conv3d in fp32."""
+    monkeypatch.setenv("DRAM_CONV_ALGO", "2")
+    monkeypatch.setenv("DRAM_WINO_TILING", tiling)
+    monkeypatch.setenv("DRAM_MATH", math)
+    tol = MATH_TOL[(math, tiling)]
+    B, D, H, W, Cin, Cout, dil = case
+    x = rnd(B, Cin, D, H, W, seed=1).requires_grad_(True)
+    w = (rnd(Cout, Cin, 3, 3, 3, seed=2) * 0.1).requires_grad_(True)
+    bias = rnd(Cout, seed=3)
+    y_ref = F.conv3d(x, w, bias, 1, dil, dil)
+    gy = rnd(*y_ref.shape, seed=4)
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, [x, w], gy)
+    g = ops.ConvGeom(B, D, H, W, Cin, Cout, 3, 1, dil, dil)
+    wf, wb = ops.pack_conv_weight(w.detach().to(DEV), True, True, g)
+    xd, gyd = to_ndhwc(x.detach()), to_ndhwc(gy)
+    y, _, v = ops.conv3d_fwd_keep(xd, wf, bias.to(DEV), g, False, True)
+    assert rel_l2(to_ncdhw(y), y_ref.detach()) < tol
+    assert rel_l2(to_ncdhw(ops.conv3d_bwd_data(gyd, wb, g)), gx_ref) < tol
+    dw = ops.conv3d_bwd_weight(xd, gyd, g)
+    assert rel_l2(dw.cpu(), gw_ref) < tol
+    assert torch.equal(ops.conv3d_bwd_weight(xd, gyd, g, v_cache=v), dw)
+    if math == "bf16x3":            # the split really carries ~16 mantissa bits: far below one bf16 ulp (4e-3)
+        assert rel_l2(to_ncdhw(y), y_ref.detach()) > 1e-7
+
+
 W2D_CASES = [
     # B, D, H, W, Cin, Cout      (DRAM_CONV_ALGO=3: fused in-plane Winograd wherever applicable)
     (1, 16, 8, 8, 64, 64),
