@@ -61,6 +61,7 @@ SIGNATURES = {
     "dram_wino_applicable": (I, [DP]),
     "dram_conv_wgrad_algo": (I, [DP]),
     "dram_wino_num_points": (I, [DP]),
+    "dram_wino_num_points_bwd": (I, [DP]),
     "dram_wino_pack_weight": (I, [P, P, P, DP, P]),
     "dram_wino_workspace": (SZ, [DP, I]),
     "dram_wino_num_stat_rows": (I, [DP]),

@@ -1083,7 +1083,7 @@ long long tiles_for(const DramConvDesc* d, int nz, int ny, int nx) {
 }
 
 // instantiated tilings: 4x4x4, 4x4x2, 4x2x2, 2x2x2;  DRAM_WINO_TILING = "z,y,x" forces one (tests)
-void pick_tiling(const DramConvDesc* d, int& nz, int& ny, int& nx) {
+void pick_tiling(const DramConvDesc* d, const int pass, int& nz, int& ny, int& nx) {
   static const int cand[4][3] = {{4, 4, 4}, {4, 4, 2}, {4, 2, 2}, {2, 2, 2}};
   if (const char* e = getenv("DRAM_WINO_TILING")) {
     int a = 0, b = 0, c = 0;
@@ -1096,7 +1096,10 @@ void pick_tiling(const DramConvDesc* d, int& nz, int& ny, int& nx) {
   // F(4,3) on all three axes pays only on GEMM-dominated (>= 512 x 256 channel) layers: its 216-value
   // input transform spills into the AGPR half of the register file (measured: -12 % on 512->512,
   // +5 % on 128->64)
-  const bool wide = (long long)d->Cin * d->Cout >= 512LL * 256;
+  // ... or when the transformed tensor is narrow: the data gradient (pass 1) of a <= 64-output-channel
+  // layer transforms only dy (measured 576->64: 1.41 vs 1.74 ms, 128->64 @ 64x128x128: 3.38 vs 3.55 ms).
+  // Forward and weight gradient (passes 0, 2) share one tiling: the cached V serves both.
+  const bool wide = (long long)d->Cin * d->Cout >= 512LL * 256 || (pass == 1 && d->Cout <= 64);
   for (int i = wide ? 0 : 1; i < 4; ++i) {
     nz = cand[i][0]; ny = cand[i][1]; nx = cand[i][2];
     if (nz == 4 && sz % 4 != 0) continue;
@@ -1106,10 +1109,10 @@ void pick_tiling(const DramConvDesc* d, int& nz, int& ny, int& nx) {
   }
 }
 
-WinoGeom make_geom(const DramConvDesc* d) {
+WinoGeom make_geom(const DramConvDesc* d, const int pass = 0) {   // pass: 0 forward, 1 data gradient, 2 weight gradient
   WinoGeom g{};
   g.B = d->B; g.D = d->D; g.H = d->H; g.W = d->W; g.d = d->dil;
-  pick_tiling(d, g.nz, g.ny, g.nx);
+  pick_tiling(d, pass, g.nz, g.ny, g.nx);
   g.npts = (g.nz + 2) * (g.ny + 2) * (g.nx + 2);
   auto tiles = [&](int n, int per) { return ((n + g.d - 1) / g.d + per - 1) / per; };
   g.Tz = tiles(g.D, g.nz); g.Ty = tiles(g.H, g.ny); g.Tx = tiles(g.W, g.nx);
@@ -1120,10 +1123,13 @@ WinoGeom make_geom(const DramConvDesc* d) {
 }
 
 bool wino_size_ok(const DramConvDesc* d) {   // int32 offsets inside one xi plane of the GEMM operands
-  const WinoGeom g = make_geom(d);
-  const long long T = (long long)g.B * g.d * g.d * g.d * g.Tz * g.Ty * g.Tx;
   const long long cmax = d->Cin > d->Cout ? d->Cin : d->Cout;
-  return T > 0 && (T + 255) * cmax < (1LL << 31);
+  for (int pass = 0; pass < 2; ++pass) {
+    const WinoGeom g = make_geom(d, pass);
+    const long long T = (long long)g.B * g.d * g.d * g.d * g.Tz * g.Ty * g.Tx;
+    if (!(T > 0 && (T + 255) * cmax < (1LL << 31))) return false;
+  }
+  return true;
 }
 
 int nj_for(int N) { return N % 256 == 0 ? 4 : (N % 128 == 0 ? 2 : 1); }
@@ -1159,6 +1165,23 @@ int grid_for(long waves) {
   return (int)(b > 65536 ? 65536 : (b < 1 ? 1 : b));
 }
 
+// tile transform into the Winograd domain (MODE 0: B^T x B, MODE 1: A dy A^T), fp32 or split-bf16 image
+template <int MODE>
+int launch_wino_in(const float* src, float* dst, const WinoGeom& g, const int C, const int math, hipStream_t s) {
+  const long units = (long)g.Tpad * (C / 64);
+#define W_IN1(NZ_, NY_, NX_)                                                                                       \
+  do {                                                                                                             \
+    if (math)                                                                                                      \
+      hipLaunchKernelGGL((wino_in_kernel<MODE, NZ_, NY_, NX_, true>), dim3(grid_for(units)), dim3(256), 0, s, src, dst, g, C);  \
+    else                                                                                                           \
+      hipLaunchKernelGGL((wino_in_kernel<MODE, NZ_, NY_, NX_, false>), dim3(grid_for(units)), dim3(256), 0, s, src, dst, g, C); \
+  } while (0)
+  WINO_TILING_DISPATCH(g, W_IN1);
+#undef W_IN1
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
 int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, int K, hipStream_t s,
            const GemmEpilogue ep = GemmEpilogue{nullptr, nullptr, nullptr, nullptr}, const int math = 0) {
   int nj = nj_for(N);
@@ -1189,26 +1212,15 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
 
 // shared by forward (x, uf) and data gradient (dy, ub): in[..., K] -> out[..., N]
 int run_conv(const float* in, const float* U, const float* bias, const float* add, const float* gate, float* out,
-             float* stats, float* v_keep, const DramConvDesc* d, int K, int N, void* ws, size_t ws_bytes,
+             float* stats, float* v_keep, const DramConvDesc* d, int pass, int K, int N, void* ws, size_t ws_bytes,
              hipStream_t s) {
-  const WinoGeom g = make_geom(d);
+  const WinoGeom g = make_geom(d, pass);
   const size_t need = (size_t)g.npts * g.Tpad * ((size_t)K + N) * sizeof(float);
   if (!ws || ws_bytes < need) return DRAM_ERR_WORKSPACE;
   float* V = v_keep ? v_keep : (float*)ws;          // kept for the weight gradient when the caller asks
   float* Mh = (float*)ws + (size_t)g.npts * g.Tpad * K;
   const int math = math_mode();
-#define W_IN(NZ_, NY_, NX_)                                                                                              \
-  do {                                                                                                                   \
-    if (math)                                                                                                            \
-      hipLaunchKernelGGL((wino_in_kernel<0, NZ_, NY_, NX_, true>), dim3(grid_for((long)g.Tpad * (K / 64))), dim3(256), 0, s, \
-                         in, V, g, K);                                                                                   \
-    else                                                                                                                 \
-      hipLaunchKernelGGL((wino_in_kernel<0, NZ_, NY_, NX_, false>), dim3(grid_for((long)g.Tpad * (K / 64))), dim3(256), 0, \
-                         s, in, V, g, K);                                                                                \
-  } while (0)
-  WINO_TILING_DISPATCH(g, W_IN);
-#undef W_IN
-  DRAM_LAUNCH_CHECK();
+  { const int rc0 = launch_wino_in<0>(in, V, g, K, math, s); if (rc0 != DRAM_OK) return rc0; }
   const int rc = run_nn(V, U, Mh, g, N, K, s, GemmEpilogue{nullptr, nullptr, nullptr, nullptr}, math);
   if (rc != DRAM_OK) return rc;
   const int ntb = (g.T + WINO_TPB - 1) / WINO_TPB;
@@ -1343,7 +1355,8 @@ static double wino_cost_per_voxel(double K, double N, double tpad, double npts, 
   const double nt = (double)(long)((N + 255.0) / 256.0);           // 256-column GEMM tiles (fewer columns: one tile)
   const double gemm = 2.0 * pv * K * N / (118e12 * fill(npts * (tpad / 256.0) * nt, 256.0));
   const double traffic = 4.0 * pv * (K + N) / 4.7e12;
-  return (4.0 + 4.0 * pv) * K / 4.9e12 + (gemm > traffic ? gemm : traffic) + (4.0 + 4.0 * pv) * N / 3.4e12;
+  const double in_rate = npts > 200.0 ? 2.7e12 : 4.9e12;     // the 216-value transform runs one wave per SIMD (measured)
+  return (4.0 + 4.0 * pv) * K / in_rate + (gemm > traffic ? gemm : traffic) + (4.0 + 4.0 * pv) * N / 3.4e12;
 }
 // direct implicit GEMM: 8x8x8 / 4x8x8 output tiles x 64..256 columns, two workgroups per CU
 static double direct_rate(const DramConvDesc* d, double N) {
@@ -1367,13 +1380,14 @@ extern "C" int dram_conv_algo(const DramConvDesc* d) {
   double best = 1e30;
   int pick = 0;
   if (w3) {
-    const WinoGeom g = make_geom(d);
+    const WinoGeom g = make_geom(d, 0), gb = make_geom(d, 1);     // forward / data-gradient tilings
     if (g.T >= 128) {
       const double vpad = (double)g.nz * g.ny * g.nx * g.Tpad, pv = g.npts / ((double)g.nz * g.ny * g.nx);
+      const double vpadb = (double)gb.nz * gb.ny * gb.nx * gb.Tpad, pvb = gb.npts / ((double)gb.nz * gb.ny * gb.nx);
       const double direct = vox * 54.0 * d->Cin * d->Cout * 0.5 *
                             (1.0 / direct_rate(d, d->Cout) + 1.0 / direct_rate(d, d->Cin));
-      const double wino = vpad * 0.5 * (wino_cost_per_voxel(d->Cin, d->Cout, g.Tpad, g.npts, pv) +
-                                        wino_cost_per_voxel(d->Cout, d->Cin, g.Tpad, g.npts, pv));
+      const double wino = 0.5 * (vpad * wino_cost_per_voxel(d->Cin, d->Cout, g.Tpad, g.npts, pv) +
+                                 vpadb * wino_cost_per_voxel(d->Cout, d->Cin, gb.Tpad, gb.npts, pvb));
       if (wino < 0.92 * direct) { best = wino; pick = 1; }
     }
   }
@@ -1432,7 +1446,12 @@ extern "C" int dram_conv_wgrad_algo(const DramConvDesc* d) {
 
 extern "C" int dram_wino_num_points(const DramConvDesc* d) {
   if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
-  return make_geom(d).npts;
+  return make_geom(d, 0).npts;
+}
+
+extern "C" int dram_wino_num_points_bwd(const DramConvDesc* d) {
+  if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
+  return make_geom(d, 1).npts;
 }
 
 extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, const DramConvDesc* d,
@@ -1441,11 +1460,18 @@ extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, const
   if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
   const long n = (long)d->Cout * d->Cin;
   const dim3 grid((unsigned)((n + 255) / 256), 2);
-  const WinoGeom g = make_geom(d);
-#define W_WT(NZ_, NY_, NX_) \
-  hipLaunchKernelGGL((wino_weight_kernel<NZ_, NY_, NX_>), grid, dim3(256), 0, (hipStream_t)stream, w, uf, ub, d->Cout, d->Cin, \
-                     math_mode() ? 1 : 0)
-  WINO_TILING_DISPATCH(g, W_WT);
+  const WinoGeom gf = make_geom(d, 0), gb = make_geom(d, 1);      // uf: forward tiling, ub: data-gradient tiling
+  const bool same = gf.nz == gb.nz && gf.ny == gb.ny && gf.nx == gb.nx;
+  float *pf = uf, *pb = same ? ub : nullptr;
+#define W_WT(NZ_, NY_, NX_)                                                                                            \
+  hipLaunchKernelGGL((wino_weight_kernel<NZ_, NY_, NX_>), grid, dim3(256), 0, (hipStream_t)stream, w, pf, pb, d->Cout, \
+                     d->Cin, math_mode() ? 1 : 0)
+  if (pf || pb) WINO_TILING_DISPATCH(gf, W_WT);
+  if (!same && ub) {
+    pf = nullptr;
+    pb = ub;
+    WINO_TILING_DISPATCH(gb, W_WT);
+  }
 #undef W_WT
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
@@ -1460,7 +1486,7 @@ extern "C" int dram_wino_num_stat_rows(const DramConvDesc* d) {
 /* pass: 0 forward, 1 data gradient, 2 weight gradient */
 extern "C" size_t dram_wino_workspace(const DramConvDesc* d, int pass) {
   if (!dram_wino_applicable(d) || pass < 0 || pass > 2) return 0;
-  const WinoGeom g = make_geom(d);
+  const WinoGeom g = make_geom(d, pass);
   size_t n = (size_t)g.npts * g.Tpad * ((size_t)d->Cin + d->Cout);
   if (pass == 2) {
     TnPlan p;
@@ -1475,7 +1501,7 @@ extern "C" int dram_wino_conv3d_fwd(const float* x, const float* uf, const float
                                     dram_stream_t stream) {
   if (!x || !uf || !y) return DRAM_ERR_BAD_ARG;
   if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
-  return run_conv(x, uf, bias, nullptr, nullptr, y, stats_partial, v_keep, d, d->Cin, d->Cout, workspace,
+  return run_conv(x, uf, bias, nullptr, nullptr, y, stats_partial, v_keep, d, 0, d->Cin, d->Cout, workspace,
                   workspace_bytes, (hipStream_t)stream);
 }
 
@@ -1490,7 +1516,7 @@ extern "C" int dram_wino_conv3d_bwd_data(const float* dy, const float* ub, float
                                          size_t workspace_bytes, dram_stream_t stream) {
   if (!dy || !ub || !dx || (gate && !add)) return DRAM_ERR_BAD_ARG;
   if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
-  return run_conv(dy, ub, nullptr, add, gate, dx, nullptr, nullptr, d, d->Cout, d->Cin, workspace, workspace_bytes,
+  return run_conv(dy, ub, nullptr, add, gate, dx, nullptr, nullptr, d, 1, d->Cout, d->Cin, workspace, workspace_bytes,
                   (hipStream_t)stream);
 }
 
@@ -1509,27 +1535,12 @@ extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache,
   float* Dh = V + (size_t)g.npts * g.Tpad * d->Cin;           // [npts][Tpad][Cout]
   float* slab = Dh + (size_t)g.npts * g.Tpad * d->Cout;       // [nsplit][npts][Cout][Cin]
   const int math = math_mode();      // the cached V is in the image of the mode it was written in: same mode here
-#define W_INT(MODE_, NZ_, NY_, NX_, SRC_, DST_, C_)                                                                      \
-  do {                                                                                                                   \
-    if (math)                                                                                                            \
-      hipLaunchKernelGGL((wino_in_kernel<MODE_, NZ_, NY_, NX_, true>), dim3(grid_for((long)g.Tpad * ((C_) / 64))),        \
-                         dim3(256), 0, s, SRC_, DST_, g, C_);                                                            \
-    else                                                                                                                 \
-      hipLaunchKernelGGL((wino_in_kernel<MODE_, NZ_, NY_, NX_, false>), dim3(grid_for((long)g.Tpad * ((C_) / 64))),       \
-                         dim3(256), 0, s, SRC_, DST_, g, C_);                                                            \
-  } while (0)
   if (v_cache) V = const_cast<float*>(v_cache);
   else {
-#define W_INX(NZ_, NY_, NX_) W_INT(0, NZ_, NY_, NX_, x, V, d->Cin)
-    WINO_TILING_DISPATCH(g, W_INX);
-#undef W_INX
-    DRAM_LAUNCH_CHECK();
+    const int rc0 = launch_wino_in<0>(x, V, g, d->Cin, math, s);
+    if (rc0 != DRAM_OK) return rc0;
   }
-#define W_INDY(NZ_, NY_, NX_) W_INT(1, NZ_, NY_, NX_, dy, Dh, d->Cout)
-  WINO_TILING_DISPATCH(g, W_INDY);
-#undef W_INDY
-#undef W_INT
-  DRAM_LAUNCH_CHECK();
+  { const int rc1 = launch_wino_in<1>(dy, Dh, g, d->Cout, math, s); if (rc1 != DRAM_OK) return rc1; }
   const int nblk = g.npts * p.nsplit * p.m_tiles * p.n_tiles;
 #define WTN(WM_, MI_, NJ_)                                                                                             \
   do {                                                                                                                 \

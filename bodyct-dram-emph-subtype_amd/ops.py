@@ -195,11 +195,13 @@ def conv_use_wino(g: "ConvGeom") -> bool:
     return conv_algo(g) == 1
 
 
-def packed_taps(g: "ConvGeom") -> int:
-    """Leading dimension of the packed weights the library's plan expects for g."""
+def packed_taps(g: "ConvGeom", bwd: bool = False) -> int:
+    """Leading dimension of the packed weights the library's plan expects for g (forward operand wf, or
+    with bwd=True the data-gradient operand wb: the Winograd pipeline may tile the two passes differently)."""
     algo = conv_algo(g)
     if algo == 1:
-        return int(_L().dram_wino_num_points(ctypes.byref(g.desc())))
+        fn = _L().dram_wino_num_points_bwd if bwd else _L().dram_wino_num_points
+        return int(fn(ctypes.byref(g.desc())))
     return 48 if algo == 2 else g.taps
 
 
@@ -212,8 +214,9 @@ def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True, g: Optional["ConvG
     taps = w.shape[2] * w.shape[3] * w.shape[4]
     algo = conv_algo(g) if g is not None else 0
     pt = packed_taps(g) if g is not None else taps
+    ptb = packed_taps(g, True) if g is not None else taps
     wf = torch.empty((pt, Cout, Cin), device=w.device, dtype=torch.float32) if want_fwd else None
-    wb = torch.empty((pt, Cin, Cout), device=w.device, dtype=torch.float32) if want_bwd else None
+    wb = torch.empty((ptb, Cin, Cout), device=w.device, dtype=torch.float32) if want_bwd else None
     if algo == 1:
         _chk(_L().dram_wino_pack_weight(_p(w), _p(wf), _p(wb), ctypes.byref(g.desc()), _stream()),
              "dram_wino_pack_weight")
@@ -278,7 +281,7 @@ def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] =
     _req(dy, "dy", shape=g.out_shape)
     algo = conv_algo(g)
     wino = algo == 1
-    _req(wb, "wb", shape=(packed_taps(g), g.Cin, g.Cout))
+    _req(wb, "wb", shape=(packed_taps(g, True), g.Cin, g.Cout))
     if add is not None:
         _req(add, "add", shape=g.in_shape)
     if gate is not None:

@@ -94,7 +94,10 @@ int dram_conv_num_mtiles(const DramConvDesc* desc);
  *                         2 in-plane Winograd z-walking kernel (dram_wgrad_w2d).
  *   dram_wino_num_points: P = Winograd points of desc's tiling: 64 (F(2,3) on every axis) or 96
  *                         (F(4,3) along z when the sub-lattice depth is a multiple of 4).
- *   dram_wino_pack_weight: w [Cout][Cin][27] -> uf [P][Cout][Cin], ub [P][Cin][Cout]
+ *   dram_wino_num_points_bwd: Pb = points of the DATA-GRADIENT tiling of desc (it transforms dy, so a
+ *                         narrow-output layer takes F(4,3) on every axis there while forward and
+ *                         weight gradient, which share the cached V, keep a smaller tile).
+ *   dram_wino_pack_weight: w [Cout][Cin][27] -> uf [P][Cout][Cin], ub [Pb][Cin][Cout]
  *                         (taps flipped, data-gradient operand); either may be NULL.
  *   dram_wino_workspace(desc, pass): bytes for pass 0 forward, 1 data gradient, 2 weight
  *                         gradient (0 when unsupported).
@@ -112,6 +115,7 @@ int dram_conv_num_mtiles(const DramConvDesc* desc);
 int dram_wino_applicable(const DramConvDesc* desc);
 int dram_conv_wgrad_algo(const DramConvDesc* desc);
 int dram_wino_num_points(const DramConvDesc* desc);
+int dram_wino_num_points_bwd(const DramConvDesc* desc);
 int dram_wino_pack_weight(const float* w, float* uf, float* ub, const DramConvDesc* desc, dram_stream_t stream);
 size_t dram_wino_workspace(const DramConvDesc* desc, int pass);
 int dram_wino_num_stat_rows(const DramConvDesc* desc);

@@ -62,6 +62,8 @@ def test_conv_plan_is_host_side_and_consistent(monkeypatch):
             assert lib.dram_conv_wgrad_algo(ctypes.byref(d)) == wg, (d.Cin, d.Cout, d.D)
         if pts is not None:
             assert lib.dram_wino_num_points(ctypes.byref(d)) == pts
+            # the data gradient transforms dy: with <= 64 output channels it takes F(4,3) on every axis
+            assert lib.dram_wino_num_points_bwd(ctypes.byref(d)) == (216 if d.Cout <= 64 else pts)
             assert lib.dram_wino_workspace(ctypes.byref(d), 0) >= 4 * pts * 256 * (d.Cin + d.Cout)
             assert lib.dram_wino_v_elems(ctypes.byref(d)) % (pts * 256 * d.Cin) == 0
     # small volumes keep the finer tiling (at least 512 tiles) and still prefer the pipeline to 16 direct workgroups
