@@ -199,9 +199,11 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
   constexpr int NI = NZ + 2, NJ = NY + 2, NK = NX + 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cblks = C >> 6;
-  const long plane = 256L * C;            // point stride inside a 256-tile block (see wino_index)
+  const long plane0 = 256L * C;           // point stride inside a 256-tile block (see wino_index)
   const long total = (long)g.Tpad * cblks;
   for (long w = blockIdx.x * 4L + wave; w < total; w += gridDim.x * 4L) {
+    long plane = plane0;                  // opaque per iteration: otherwise every point offset k * plane becomes a
+    asm volatile("" : "+s"(plane));       // 64-bit loop invariant held in registers across the whole loop
     const int t = (int)(w / cblks);
     const int c = (int)(w - (long)t * cblks) * 64 + lane;
     float* o = out + wino_index(t, g.npts, C) + (SPLIT ? c - lane + split_pos(lane) : c);
@@ -309,6 +311,145 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < NK; ++k)
           o[((i * NJ + j) * NK + k) * plane] = SPLIT ? split_pack(v[i][j][k], lane & 1) : v[i][j][k];
+  }
+}
+
+// F(4,3) on all three axes: 216 values per (tile, channel) do not fit beside their temporaries in the 256
+// VGPRs of a two-waves-per-SIMD kernel, and with one wave per SIMD (AGPR half of the file) load, compute and
+// store phases no longer overlap: 2.7 TB/s where the smaller tilings reach the ~5.3 TB/s of a write-dominated
+// HBM stream.  Here a (tile, 64-channel block) is TWO units: unit hx keeps only the x points 3hx .. 3hx + 2
+// of every x row as it is loaded (108 live values); both units read the whole tile, the second from L1/L2.
+template <int MODE, int HX, bool SPLIT>
+__device__ __forceinline__ void wino_half444(const float* __restrict__ in, float* __restrict__ o, const WinoGeom& g,
+                                            const int C, const int c, const int lane, const int b, const int z0,
+                                            const int y0, const int x0, const long plane) {
+  constexpr int NI = 6, NJ = 6, NK = 6;
+  float v[NI][NJ][3];
+  if (MODE == 0) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int z = z0 + (i - 1) * g.d;
+      const bool zo = (z >= 0) & (z < g.D);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int y = y0 + (j - 1) * g.d;
+        const bool yo = zo & (y >= 0) & (y < g.H);
+        float row[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const int x = x0 + (k - 1) * g.d;
+          const bool ok = yo & (x >= 0) & (x < g.W);
+          const long oo = ((((long)b * g.D + z) * g.H + y) * g.W + x) * C + c;
+          row[k] = ok ? in[oo] : 0.f;
+        }
+        bt4(row);
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) v[i][j][kk] = row[3 * HX + kk];
+      }
+      // two planes of loads in flight at a time: left alone the scheduler hoists all 216 loads and spills
+      if (i & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        float col[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) col[j] = v[i][j][kk];
+        bt4(col);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) v[i][j][kk] = col[j];
+      }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        float col[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) col[i] = v[i][j][kk];
+        bt4(col);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) v[i][j][kk] = col[i];
+      }
+  } else {
+    float p[4][4][3], q2[4][NJ][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int z = z0 + i * g.d;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int y = y0 + j * g.d;
+        float u[4], r[NK];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int x = x0 + k * g.d;
+          const bool ok = (z < g.D) & (y < g.H) & (x < g.W);
+          const long oo = ((((long)b * g.D + z) * g.H + y) * g.W + x) * C + c;
+          u[k] = ok ? in[oo] : 0.f;
+        }
+        a4(u, r);
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) p[i][j][kk] = r[3 * HX + kk];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        float yy[4], col[NJ];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yy[j] = p[i][j][kk];
+        a4(yy, col);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) q2[i][j][kk] = col[j];
+      }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        float yy[4], col[NI];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yy[i] = q2[i][j][kk];
+        a4(yy, col);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) v[i][j][kk] = col[i];
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk)
+        o[((i * NJ + j) * NK + 3 * HX + kk) * plane] = SPLIT ? split_pack(v[i][j][kk], lane & 1) : v[i][j][kk];
+}
+
+template <int MODE, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void wino_in444_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         const WinoGeom g, const int C) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cblks = C >> 6;
+  const long plane0 = 256L * C;
+  const long total = (long)g.Tpad * cblks * 2;
+  for (long w2 = blockIdx.x * 4L + wave; w2 < total; w2 += gridDim.x * 4L) {
+    const int hx = (int)(w2 & 1);          // the two halves of a tile sit in neighbouring waves: shared L1 lines
+    const long w = w2 >> 1;
+    long plane = plane0;                   // opaque per iteration: otherwise the 108 point offsets k * plane are
+    asm volatile("" : "+s"(plane));        // hoisted out of the loop as 64-bit loop invariants and spilled
+    const int t = (int)(w / cblks);
+    const int c = (int)(w - (long)t * cblks) * 64 + lane;
+    float* o = out + wino_index(t, g.npts, C) + (SPLIT ? c - lane + split_pos(lane) : c);
+    if (t >= g.T) {
+#pragma unroll
+      for (int i = 0; i < 36; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) o[(i * 6 + 3 * hx + kk) * plane] = 0.f;
+      continue;
+    }
+    int b, z0, y0, x0;
+    tile_origin(g, t, b, z0, y0, x0);
+    if (hx == 0) wino_half444<MODE, 0, SPLIT>(in, o, g, C, c, lane, b, z0, y0, x0, plane);
+    else wino_half444<MODE, 1, SPLIT>(in, o, g, C, c, lane, b, z0, y0, x0, plane);
   }
 }
 
@@ -1093,14 +1234,13 @@ void pick_tiling(const DramConvDesc* d, const int pass, int& nz, int& ny, int& n
   }
   if (math_mode() == 2) { nz = ny = nx = 2; return; }   // bf16 operands: F(4,3) amplifies their 2^-9 rounding 3-17x
   const int sz = (d->D + d->dil - 1) / d->dil, sy = (d->H + d->dil - 1) / d->dil, sx = (d->W + d->dil - 1) / d->dil;
-  // F(4,3) on all three axes pays only on GEMM-dominated (>= 512 x 256 channel) layers: its 216-value
-  // input transform spills into the AGPR half of the register file (measured: -12 % on 512->512,
-  // +5 % on 128->64)
-  // ... or when the transformed tensor is narrow: the data gradient (pass 1) of a <= 64-output-channel
-  // layer transforms only dy (measured 576->64: 1.41 vs 1.74 ms, 128->64 @ 64x128x128: 3.38 vs 3.55 ms).
-  // Forward and weight gradient (passes 0, 2) share one tiling: the cached V serves both.
-  const bool wide = (long long)d->Cin * d->Cout >= 512LL * 256 || (pass == 1 && d->Cout <= 64);
-  for (int i = wide ? 0 : 1; i < 4; ++i) {
+  // (pass is kept for per-pass choices; since the 216-value transform runs as two half-tile units --
+  // wino_in444_kernel -- F(4,3) on all three axes wins wherever the extents allow it.  Measured, 4x4x4 vs
+  // 4x4x2 tiles, fwd / dgrad / wgrad ms: 128->64 @ 2x64x128x128 3.39 / 3.13 / 3.51 vs 3.45 / 3.51 / 3.66;
+  // 576->64 @ 2x32x64x64 1.66 / 1.39 / 1.70 vs 1.75 / 1.71 / 1.69; 256->256 dil 2 0.27 / 0.26 / 0.33 vs
+  // 0.33 / 0.31 / 0.34.)
+  (void)pass;
+  for (int i = 0; i < 4; ++i) {
     nz = cand[i][0]; ny = cand[i][1]; nx = cand[i][2];
     if (nz == 4 && sz % 4 != 0) continue;
     if (ny == 4 && sy % 4 != 0) continue;
@@ -1169,6 +1309,13 @@ int grid_for(long waves) {
 template <int MODE>
 int launch_wino_in(const float* src, float* dst, const WinoGeom& g, const int C, const int math, hipStream_t s) {
   const long units = (long)g.Tpad * (C / 64);
+  static const int half = getenv("DRAM_WINO_HALF") ? atoi(getenv("DRAM_WINO_HALF")) : 1;   // A/B switch (tools)
+  if (half && g.nz == 4 && g.ny == 4 && g.nx == 4) {
+    if (math) hipLaunchKernelGGL((wino_in444_kernel<MODE, true>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C);
+    else hipLaunchKernelGGL((wino_in444_kernel<MODE, false>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C);
+    DRAM_LAUNCH_CHECK();
+    return DRAM_OK;
+  }
 #define W_IN1(NZ_, NY_, NX_)                                                                                       \
   do {                                                                                                             \
     if (math)                                                                                                      \
@@ -1355,7 +1502,7 @@ static double wino_cost_per_voxel(double K, double N, double tpad, double npts, 
   const double nt = (double)(long)((N + 255.0) / 256.0);           // 256-column GEMM tiles (fewer columns: one tile)
   const double gemm = 2.0 * pv * K * N / (118e12 * fill(npts * (tpad / 256.0) * nt, 256.0));
   const double traffic = 4.0 * pv * (K + N) / 4.7e12;
-  const double in_rate = npts > 200.0 ? 2.7e12 : 4.9e12;     // the 216-value transform runs one wave per SIMD (measured)
+  const double in_rate = npts > 200.0 ? 4.0e12 : 4.9e12;     // the 216-value transform reads its tile twice (half-tile units)
   return (4.0 + 4.0 * pv) * K / in_rate + (gemm > traffic ? gemm : traffic) + (4.0 + 4.0 * pv) * N / 3.4e12;
 }
 // direct implicit GEMM: 8x8x8 / 4x8x8 output tiles x 64..256 columns, two workgroups per CU
@@ -1398,7 +1545,9 @@ extern "C" int dram_conv_algo(const DramConvDesc* d) {
     const double rf = d->Cout % 64 == 0 ? 200e12 : 155e12, rb = d->Cin % 64 == 0 ? 200e12 : 155e12;
     const double w2d = vox * zt / d->D * 54.0 * d->Cin * d->Cout * 0.5 * (1.0 / rf + 1.0 / rb);
     const double direct = vox * 54.0 * d->Cin * d->Cout / 135e12;
-    if (w2d < 0.92 * direct && w2d < best) { best = w2d; pick = 2; }
+    // the fused kernel needs no workspace (the pipeline: 2 x 3.4-4.5x the activation bytes): it keeps a layer
+    // unless the pipeline is estimated > 15 % faster (64->64: measured 2.28 / 2.17 fused vs 2.11 / 1.98 ms)
+    if (w2d < 0.92 * direct && w2d < 1.15 * best) { best = w2d; pick = 2; }
   }
   return pick;
 }
@@ -1439,7 +1588,10 @@ extern "C" int dram_conv_wgrad_algo(const DramConvDesc* d) {
   }
   if (w2 && d->D >= 8 && vox >= 65536.0) {
     const double w2d = vox * 54.0 * K * N / W2D_WGRAD_RATE;     // direct-equivalent rate, measured
-    if (w2d < 0.92 * direct && w2d < best) { best = w2d; pick = 2; }
+    // same preference as the forward plan: the z-walking kernel keeps a layer unless the pipeline (which
+    // here would also have to transform x again: the fused forward kernel leaves no V) is estimated > 15 %
+    // faster (64->64 @ 2x64x128x128: measured 1.89 vs 2.51 ms)
+    if (w2d < 0.92 * direct && w2d < 1.15 * best) { best = w2d; pick = 2; }
   }
   return pick;
 }

@@ -49,8 +49,10 @@ def test_conv_plan_is_host_side_and_consistent(monkeypatch):
 
     # BASELINE configs[1] layers (batch 2): (desc, forward plan, weight-gradient plan, Winograd points)
     table = [(desc(2, 16, 32, 32, 512, 512, dil=4), 1, 1, 216),    # layer4: F(4,3) on all three axes
-             (desc(2, 16, 32, 32, 256, 256, dil=2), 1, 1, 144),    # layer3: 4x4x2 tiles
-             (desc(2, 64, 128, 128, 128, 64), 1, None, 144),       # decoder, wide input
+             (desc(2, 16, 32, 32, 256, 256, dil=2), 1, 1, 216),    # layer3: 8x16x16 sub-lattices, 4x4x4 tiles too
+             (desc(2, 16, 32, 32, 128, 128), 1, 1, 216),           # layer2: exactly 512 4x4x4 tiles
+             (desc(1, 16, 32, 32, 128, 128), 1, 1, 144),           # ... batch 1: 256 of them -> the 4x4x2 tiling
+             (desc(2, 64, 128, 128, 128, 64), 1, None, 216),       # decoder, wide input
              (desc(2, 64, 128, 128, 64, 64), 2, 2, None),          # decoder, narrow: fused in-plane kernels
              (desc(2, 32, 64, 64, 64, 64), 2, 2, None),            # layer1
              (desc(2, 32, 64, 64, 64, 128, s=2), 0, 0, None),      # strided: direct
@@ -62,8 +64,7 @@ def test_conv_plan_is_host_side_and_consistent(monkeypatch):
             assert lib.dram_conv_wgrad_algo(ctypes.byref(d)) == wg, (d.Cin, d.Cout, d.D)
         if pts is not None:
             assert lib.dram_wino_num_points(ctypes.byref(d)) == pts
-            # the data gradient transforms dy: with <= 64 output channels it takes F(4,3) on every axis
-            assert lib.dram_wino_num_points_bwd(ctypes.byref(d)) == (216 if d.Cout <= 64 else pts)
+            assert lib.dram_wino_num_points_bwd(ctypes.byref(d)) == pts      # same tiling for the data gradient today
             assert lib.dram_wino_workspace(ctypes.byref(d), 0) >= 4 * pts * 256 * (d.Cin + d.Cout)
             assert lib.dram_wino_v_elems(ctypes.byref(d)) % (pts * 256 * d.Cin) == 0
     # small volumes keep the finer tiling (at least 512 tiles) and still prefer the pipeline to 16 direct workgroups
