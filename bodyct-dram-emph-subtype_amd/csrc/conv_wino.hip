@@ -459,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void wino_in444_kernel(const float* __restr
 // TPB consecutive tiles x 64 channels; stats row = tile block.  One xi_z plane at a time: its
 // in-plane A^T . A result is folded into the NZ output planes with the z column of A^T.
 constexpr int WINO_TPB = 16;
+__constant__ float c_at4[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};   // A^T of F(4,3)
 
 template <int NZ, int NY, int NX>
 __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ mh, const float* __restrict__ bias,
@@ -479,8 +480,43 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
     if (t >= g.T) break;
     const float* src = mh + wino_index(t, g.npts, N) + c;
     float o[NZ][NY][NX];
+    constexpr bool ROLLED = NZ == 4 && NY == 4 && NX == 4;
+    if (ROLLED) {
+      // F(4,3)^3: a rolled loop over the z point keeps one plane of loads (36) in flight per wave and ~140
+      // registers; unrolled, the scheduler hoists all 216 loads and the kernel runs one wave per SIMD
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
+      for (int a = 0; a < NZ * NY * NX; ++a) (&o[0][0][0])[a] = 0.f;
+#pragma unroll 1
+      for (int i = 0; i < NI; ++i) {
+        float m[NJ][NK], p[NJ][NX], q2[NY][NX];
+        const float* sp = src + (long)i * (NJ * NK) * plane;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int k = 0; k < NK; ++k) m[j][k] = sp[(j * NK + k) * plane];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) atz<NX>(m[j], p[j]);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+          float col[NJ], r[NY];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) col[j] = p[j][k];
+          atz<NY>(col, r);
+#pragma unroll
+          for (int j = 0; j < NY; ++j) q2[j][k] = r[j];
+        }
+#pragma unroll
+        for (int oz = 0; oz < NZ; ++oz) {
+          const float cf = c_at4[oz][i];
+#pragma unroll
+          for (int j = 0; j < NY; ++j)
+#pragma unroll
+            for (int k = 0; k < NX; ++k) o[oz][j][k] = __builtin_fmaf(cf, q2[j][k], o[oz][j][k]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < (ROLLED ? 0 : NI); ++i) {
       float m[NJ][NK], p[NJ][NX], q2[NY][NX];
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
