@@ -12,7 +12,7 @@ src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
 
 FAMILIES = [("conv_wino2d_kernel", "conv_wino2d"), ("wino_gemm_nn", "wino_gemm_nn"), ("wino_gemm_tn", "wino_gemm_tn"),
-            ("wino_in_kernel", "wino_transforms"), ("wino_out_kernel", "wino_transforms"),
+            ("wino_in_kernel", "wino_transforms"), ("wino_in444", "wino_transforms"), ("wino_out_kernel", "wino_transforms"),
             ("wino_wgrad_out", "wino_transforms"), ("wino_weight", "weight_pack"), ("wino2d_weight", "weight_pack"),
             ("pack_weight", "weight_pack"), ("conv_igemm", "conv_igemm"), ("conv_wgrad", "conv_wgrad"),
             ("wgrad_reduce", "conv_wgrad"), ("stem_", "stem"), ("bn_", "bn/elementwise"), ("colreduce", "bn/elementwise"),
