@@ -71,7 +71,9 @@ __global__ void bn_apply_kernel(const float4* __restrict__ y, const float* __res
     const float4 sh = *reinterpret_cast<const float4*>(shift + 4 * q);
     const float4 v = y[i];
     float4 o;
-    o.x = v.x * sc.x + sh.x; o.y = v.y * sc.y + sh.y; o.z = v.z * sc.z + sh.z; o.w = v.w * sc.w + sh.w;
+    // explicit fma: the backward pass re-derives the ReLU mask from y with the same expression (bitwise)
+    o.x = __builtin_fmaf(v.x, sc.x, sh.x); o.y = __builtin_fmaf(v.y, sc.y, sh.y);
+    o.z = __builtin_fmaf(v.z, sc.z, sh.z); o.w = __builtin_fmaf(v.w, sc.w, sh.w);
     if (RES == 1) {
       const float4 rr = reinterpret_cast<const float4*>(res)[i];
       o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
@@ -116,7 +118,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ a, const float* __restrict__ zz,
                                                         const float* __restrict__ yy, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, float* __restrict__ partial,
-                                                        long rows, int C, int rpb, int relu) {
+                                                        long rows, int C, int rpb, int relu,
+                                                        const float* __restrict__ scale = nullptr,
+                                                        const float* __restrict__ shift = nullptr) {
   constexpr int R = MODE == 0 ? 1 : 2;
   __shared__ float4 sm[R][256];
   const int Q = C >> 2;
@@ -130,21 +134,30 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     const int q = qb + ql;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     if (grp < rg && q < Q) {
-      float4 mu, is;
+      float4 mu, is, sc, sh;
       if (MODE == 1) {
         mu = *reinterpret_cast<const float4*>(mean + 4 * q);
         is = *reinterpret_cast<const float4*>(invstd + 4 * q);
+        if (relu && !zz) {
+          sc = *reinterpret_cast<const float4*>(scale + 4 * q);
+          sh = *reinterpret_cast<const float4*>(shift + 4 * q);
+        }
       }
       for (long r = r0 + grp; r < r1; r += rg) {
         const long o = r * C + 4 * q;
         float4 g = *reinterpret_cast<const float4*>(a + o);
         if (MODE == 1) {
+          const float4 yv = *reinterpret_cast<const float4*>(yy + o);
           if (relu) {
-            const float4 zv = *reinterpret_cast<const float4*>(zz + o);
+            // mask of the forward ReLU: from the saved output z, or (no residual) re-derived from y with the
+            // forward's own expression -- one tensor read less
+            float4 zv;
+            if (zz) zv = *reinterpret_cast<const float4*>(zz + o);
+            else zv = make_float4(__builtin_fmaf(yv.x, sc.x, sh.x), __builtin_fmaf(yv.y, sc.y, sh.y),
+                                  __builtin_fmaf(yv.z, sc.z, sh.z), __builtin_fmaf(yv.w, sc.w, sh.w));
             g.x = zv.x > 0.f ? g.x : 0.f; g.y = zv.y > 0.f ? g.y : 0.f;
             g.z = zv.z > 0.f ? g.z : 0.f; g.w = zv.w > 0.f ? g.w : 0.f;
           }
-          const float4 yv = *reinterpret_cast<const float4*>(yy + o);
           s1.x += g.x * ((yv.x - mu.x) * is.x); s1.y += g.y * ((yv.y - mu.y) * is.y);
           s1.z += g.z * ((yv.z - mu.z) * is.z); s1.w += g.w * ((yv.w - mu.w) * is.w);
         }
@@ -173,17 +186,25 @@ __global__ void bn_bwd_apply_kernel(const float4* __restrict__ dz, const float4*
                                     const float4* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const double* __restrict__ sums, double inv_count, float4* __restrict__ dy, int C,
-                                    long total4, int relu) {
+                                    long total4, int relu, const float* __restrict__ scale,
+                                    const float* __restrict__ shift) {
   const int Q = C >> 2;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const int c = 4 * (int)(i % Q);
     float4 g = dz[i];
+    const float4 yv = y[i];
     if (relu) {
-      const float4 zv = z[i];
+      float4 zv;
+      if (z) zv = z[i];
+      else {   // no residual: the forward mask re-derived from y (same fma as bn_apply_kernel)
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+        zv = make_float4(__builtin_fmaf(yv.x, sc.x, sh.x), __builtin_fmaf(yv.y, sc.y, sh.y),
+                         __builtin_fmaf(yv.z, sc.z, sh.z), __builtin_fmaf(yv.w, sc.w, sh.w));
+      }
       g.x = zv.x > 0.f ? g.x : 0.f; g.y = zv.y > 0.f ? g.y : 0.f;
       g.z = zv.z > 0.f ? g.z : 0.f; g.w = zv.w > 0.f ? g.w : 0.f;
     }
-    const float4 yv = y[i];
     const float4 mu = *reinterpret_cast<const float4*>(mean + c);
     const float4 is = *reinterpret_cast<const float4*>(invstd + c);
     const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
@@ -301,14 +322,14 @@ extern "C" int dram_colsum_nparts(long long rows, int C) {
 }
 
 extern "C" int dram_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean,
-                                  const float* invstd, float* partial, long long rows, int C, int relu,
-                                  dram_stream_t stream) {
+                                  const float* invstd, const float* scale, const float* shift, float* partial,
+                                  long long rows, int C, int relu, dram_stream_t stream) {
   if (!dz || !y || !mean || !invstd || !partial || rows < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
-  if (relu && !z) return DRAM_ERR_BAD_ARG;
+  if (relu && !z && !(scale && shift)) return DRAM_ERR_BAD_ARG;
   const int rpb = rows_per_block(rows);
   const int nparts = (int)((rows + rpb - 1) / rpb);
   hipLaunchKernelGGL((colreduce_kernel<1>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, z, y, mean, invstd,
-                     partial, (long)rows, C, rpb, relu);
+                     partial, (long)rows, C, rpb, relu, scale, shift);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
@@ -324,15 +345,16 @@ extern "C" int dram_colsum(const float* a, float* partial, long long rows, int C
 }
 
 extern "C" int dram_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* mean,
-                                 const float* invstd, const float* gamma, const double* sums, double count,
-                                 float* dy, long long rows, int C, int relu, dram_stream_t stream) {
+                                 const float* invstd, const float* gamma, const float* scale, const float* shift,
+                                 const double* sums, double count, float* dy, long long rows, int C, int relu,
+                                 dram_stream_t stream) {
   if (!dz || !y || !mean || !invstd || !gamma || !sums || !dy || rows < 1 || C < 4 || (C & 3) || count <= 0.0)
     return DRAM_ERR_BAD_ARG;
-  if (relu && !z) return DRAM_ERR_BAD_ARG;
+  if (relu && !z && !(scale && shift)) return DRAM_ERR_BAD_ARG;
   const long total4 = (long)rows * (C >> 2);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)dz, (const float4*)z, (const float4*)y, mean, invstd, gamma, sums, 1.0 / count,
-                     (float4*)dy, C, total4, relu);
+                     (float4*)dy, C, total4, relu, scale, shift);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

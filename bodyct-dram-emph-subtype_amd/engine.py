@@ -71,11 +71,13 @@ class Engine:
                                                          P[bnp + ".running_mean"], P[bnp + ".running_var"],
                                                          BN_MOMENTUM, BN_EPS, False)
         z = ops.bn_apply(y, scale, shift, residual, rs, relu)
-        return z, mean, invstd, count
+        # without a residual the backward pass re-derives the ReLU mask from y (scale, shift) instead of reading z
+        return z, mean, invstd, count, (None if residual is not None else (scale, shift))
 
     def _bn_bwd(self, st: _State, c: dict, dz: Tensor) -> Tensor:
         bnp = c["bn"]
-        part = ops.bn_bwd_reduce(dz, c["z"], c["y"], c["mean"], c["invstd"], True)
+        zmask, (sc, sh) = (c["z"], (None, None)) if c.get("ss") is None else (None, c["ss"])
+        part = ops.bn_bwd_reduce(dz, zmask, c["y"], c["mean"], c["invstd"], True, sc, sh)
         sums = ops.reduce_partials(part)
         # parameter gradients use the LOCAL sums (DDP averages them afterwards), the input
         # gradient the all-reduced ones -- torch SyncBatchNorm semantics.
@@ -83,8 +85,8 @@ class Engine:
         st.grads[bnp + ".bias"] = sums[0].float()
         if st.dist is not None:
             sums = st.dist.all_reduce_sum(sums)
-        return ops.bn_bwd_apply(dz, c["z"], c["y"], c["mean"], c["invstd"], st.P[bnp + ".weight"], sums, c["count"],
-                                True)
+        return ops.bn_bwd_apply(dz, zmask, c["y"], c["mean"], c["invstd"], st.P[bnp + ".weight"], sums, c["count"],
+                                True, sc, sh)
 
     # ------------------------------------------------------------------ conv + BN unit
     def _conv_bn_fwd(self, st: _State, x: Tensor, wname: str, bname: Optional[str], bnp: str, k: int, stride: int,
@@ -94,10 +96,11 @@ class Engine:
         g = ConvGeom(B, D, H, W, Cin, w.shape[0], k, stride, pad, dil)
         wf, wb = ops.pack_conv_weight(w, True, st.need_grad, g)
         y, sp, v = ops.conv3d_fwd_keep(x, wf, st.P[bname] if bname else None, g, st.training, st.need_grad)
-        z, mean, invstd, count = self._bn_fwd(st, y, sp, bnp, residual, rs)
+        z, mean, invstd, count, ss = self._bn_fwd(st, y, sp, bnp, residual, rs)
         c = None
         if st.need_grad:
-            c = dict(x=x, y=y, z=z, mean=mean, invstd=invstd, g=g, wb=wb, count=count, w=wname, b=bname, bn=bnp, v=v)
+            c = dict(x=x, y=y, z=z, mean=mean, invstd=invstd, g=g, wb=wb, count=count, w=wname, b=bname, bn=bnp, v=v,
+                     ss=ss)
         return z, c
 
     def _conv_bn_bwd(self, st: _State, c: dict, dz: Tensor, need_dx=True, add=None, gate=None):
@@ -173,7 +176,7 @@ class Engine:
         lungs4 = None if lungs is None else lungs.reshape(B, *lungs.shape[-3:]).contiguous()
 
         y0, sp0 = ops.stem_fwd(x4, P["conv1.weight"], training)
-        xs, mean0, invstd0, count0 = self._bn_fwd(st, y0, sp0, "bn1", None, 1)
+        xs, mean0, invstd0, count0, ss0 = self._bn_fwd(st, y0, sp0, "bn1", None, 1)
         xp, amax = ops.maxpool_fwd(xs)
 
         h = xp
@@ -209,7 +212,7 @@ class Engine:
         dense_list = [dense[:, :n0], dense[:, n0:]]
         saved = None
         if need_grad:
-            saved = dict(st=st, x4=x4, y0=y0, xs=xs, mean0=mean0, invstd0=invstd0, count0=count0, amax=amax,
+            saved = dict(st=st, x4=x4, y0=y0, xs=xs, mean0=mean0, invstd0=invstd0, count0=count0, ss0=ss0, amax=amax,
                          blocks=block_ctx, cu1=cu1, cu2=cu2, cu3=cu3, xup3=xup3, hw=hw, dense=dense, lungs4=lungs4,
                          denom=denom, n0=n0, n1=n1, xs_shape=tuple(xs.shape))
         return dense_list, outs, saved
@@ -268,7 +271,7 @@ class Engine:
         # d = gradient w.r.t. the max-pooled stem output
         dxs = ops.maxpool_bwd(d, saved["amax"], saved["xs_shape"], dskip_stem)
         c0 = dict(z=saved["xs"], y=saved["y0"], mean=saved["mean0"], invstd=saved["invstd0"], count=saved["count0"],
-                  bn="bn1")
+                  bn="bn1", ss=saved["ss0"])
         dy0 = self._bn_bwd(st, c0, dxs)
         st.grads["conv1.weight"] = ops.stem_bwd_weight(saved["x4"], dy0)
         if st.dist is not None:

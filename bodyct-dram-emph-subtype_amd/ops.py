@@ -447,31 +447,45 @@ def _rows(t: Tensor) -> int:
     return t.numel() // t.shape[-1]
 
 
-def bn_bwd_reduce(dz: Tensor, z: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, relu: bool) -> Tensor:
+def _mask_args(z, y, scale, shift, relu):
+    """ReLU mask source of the BN backward kernels: the saved output z, or (z None) scale / shift to
+    re-derive it from y."""
+    C = y.shape[-1]
+    if relu and z is not None:
+        _req(z, "z", shape=y.shape)
+    elif relu:
+        if scale is None or shift is None:
+            raise ValueError("BN backward with ReLU needs z, or scale and shift")
+        _req(scale, "scale", shape=(C,))
+        _req(shift, "shift", shape=(C,))
+
+
+def bn_bwd_reduce(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, invstd: Tensor, relu: bool,
+                  scale: Optional[Tensor] = None, shift: Optional[Tensor] = None) -> Tensor:
     _req(dz, "dz", shape=y.shape)
     _req(y, "y")
-    if relu:
-        _req(z, "z", shape=y.shape)
+    _mask_args(z, y, scale, shift, relu)
     C = y.shape[-1]
     _req(mean, "mean", shape=(C,))
     _req(invstd, "invstd", shape=(C,))
     rows = _rows(y)
     nparts = _L().dram_colsum_nparts(rows, C)
     partial = torch.empty((nparts, 2, C), device=y.device, dtype=torch.float32)
-    _chk(_L().dram_bn_bwd_reduce(_p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(partial), rows, C, int(relu),
-                                 _stream()), "dram_bn_bwd_reduce")
+    _chk(_L().dram_bn_bwd_reduce(_p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(scale), _p(shift), _p(partial), rows, C,
+                                 int(relu), _stream()), "dram_bn_bwd_reduce")
     return partial
 
 
-def bn_bwd_apply(dz: Tensor, z: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, sums: Tensor,
-                 count: float, relu: bool) -> Tensor:
+def bn_bwd_apply(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, sums: Tensor,
+                 count: float, relu: bool, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None) -> Tensor:
     C = y.shape[-1]
     _req(dz, "dz", shape=y.shape)
+    _mask_args(z, y, scale, shift, relu)
     _req(sums, "sums", dtype=torch.float64, shape=(2, C))
     _req(gamma, "gamma", shape=(C,))
     dy = torch.empty_like(y)
-    _chk(_L().dram_bn_bwd_apply(_p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums), float(count), _p(dy),
-                                _rows(y), C, int(relu), _stream()), "dram_bn_bwd_apply")
+    _chk(_L().dram_bn_bwd_apply(_p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(scale), _p(shift), _p(sums),
+                                float(count), _p(dy), _rows(y), C, int(relu), _stream()), "dram_bn_bwd_apply")
     return dy
 
 

@@ -218,15 +218,19 @@ int dram_bn_apply(const float* y, const float* scale, const float* shift, const 
                   int relu, dram_stream_t stream);
 
 /* Backward, phase 1: g = dz * (z > 0) (relu != 0) ; partial[p][0][c] = sum g,
- * partial[p][1][c] = sum g * xhat, xhat = (y-mean)*invstd.  nparts from dram_colsum_nparts. */
+ * partial[p][1][c] = sum g * xhat, xhat = (y-mean)*invstd.  nparts from dram_colsum_nparts.
+ * The ReLU mask comes from the saved output z, or -- z == NULL, for a BatchNorm without residual --
+ * is re-derived from y as fma(y, scale, shift) > 0 with the forward's scale / shift vectors
+ * (bitwise the forward's decision; saves one tensor read in each phase). */
 int dram_colsum_nparts(long long rows, int C);
 int dram_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean,
-                       const float* invstd, float* partial, long long rows, int C, int relu,
-                       dram_stream_t stream);
+                       const float* invstd, const float* scale, const float* shift, float* partial,
+                       long long rows, int C, int relu, dram_stream_t stream);
 /* phase 2: dy = gamma*invstd*(g - sums[0]/count - xhat*sums[1]/count) */
 int dram_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* mean,
-                      const float* invstd, const float* gamma, const double* sums, double count,
-                      float* dy, long long rows, int C, int relu, dram_stream_t stream);
+                      const float* invstd, const float* gamma, const float* scale, const float* shift,
+                      const double* sums, double count, float* dy, long long rows, int C, int relu,
+                      dram_stream_t stream);
 /* partial[p][0][c] = sum_rows a[row][c]  (conv-bias gradient) */
 int dram_colsum(const float* a, float* partial, long long rows, int C, dram_stream_t stream);
 

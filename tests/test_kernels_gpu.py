@@ -448,6 +448,10 @@ def test_batchnorm_relu_residual(ops, C, res):
     assert rel_l2(bs[1].cpu(), gg_ref) < 1e-5 and rel_l2(bs[0].cpu(), gb_ref) < 1e-5
     dy = ops.bn_bwd_apply(gzd, z, yd, mean_d, invstd_d, gamma.detach().to(DEV), bs, n, True)
     assert rel_l2(to_ncdhw(dy), gy_ref) < 2e-5
+    if r is None:      # no residual: the ReLU mask re-derived from y (scale, shift) is bitwise the saved one
+        assert torch.equal(ops.bn_bwd_reduce(gzd, None, yd, mean_d, invstd_d, True, scale, shift), bp)
+        assert torch.equal(ops.bn_bwd_apply(gzd, None, yd, mean_d, invstd_d, gamma.detach().to(DEV), bs, n, True,
+                                            scale, shift), dy)
     cs = ops.reduce_partials(ops.colsum(gzd))[0]
     assert rel_l2(cs.cpu(), gz.double().sum((0, 2, 3, 4))) < 1e-5
 
