@@ -83,20 +83,22 @@ int dram_conv3d_bwd_weight(const float* x, const float* dy, float* dw, const Dra
 int dram_conv_num_mtiles(const DramConvDesc* desc);
 
 /* ------------------------------------------------------------------------- */
-/* Winograd F(2x2x2, 3x3x3) path for stride-1 3x3x3 convolutions with pad == dil and
+/* 3-D Winograd pipeline (F(2,3) or F(4,3) per axis) for stride-1 3x3x3 convolutions with pad == dil and
  * Cin, Cout multiples of 64 (the BasicBlock / Bottleneck conv3x3x3 sites, med3d.py:91-100,
  * and their autograd gradients): 64 instead of 216 multiplies per 2x2x2 output tile and
- * channel pair.  Same tensors and layouts as dram_conv3d_*; the packed weights are the
+ * channel pair with F(2,3), 216 instead of 1728 per 4x4x4 tile with F(4,3).  Same tensors and layouts as dram_conv3d_*; the packed weights are the
  * transformed ones and every pass needs a caller-owned workspace.
  *   dram_wino_applicable: 1 when the geometry is supported.
  *   dram_conv_wgrad_algo: plan for the WEIGHT gradient of desc, decided separately from
  *                         dram_conv_algo: 0 direct (dram_conv3d_bwd_weight), 1 this pipeline,
  *                         2 in-plane Winograd z-walking kernel (dram_wgrad_w2d).
- *   dram_wino_num_points: P = Winograd points of desc's tiling: 64 (F(2,3) on every axis) or 96
- *                         (F(4,3) along z when the sub-lattice depth is a multiple of 4).
- *   dram_wino_num_points_bwd: Pb = points of the DATA-GRADIENT tiling of desc (it transforms dy, so a
- *                         narrow-output layer takes F(4,3) on every axis there while forward and
- *                         weight gradient, which share the cached V, keep a smaller tile).
+ *   dram_wino_num_points: P = Winograd points of desc's tiling (outputs per tile along z, y, x: the
+ *                         largest of 4x4x4 / 4x4x2 / 4x2x2 / 2x2x2 whose F(4,3) axes divide the
+ *                         dilation sub-lattice extent and that leaves >= 512 tiles):
+ *                         216, 144, 96 or 64.
+ *   dram_wino_num_points_bwd: Pb = points of the DATA-GRADIENT tiling of desc (the plan may tile that
+ *                         pass on its own; forward and weight gradient share the cached V and so
+ *                         one tiling).  Today Pb == P.
  *   dram_wino_pack_weight: w [Cout][Cin][27] -> uf [P][Cout][Cin], ub [Pb][Cin][Cout]
  *                         (taps flipped, data-gradient operand); either may be NULL.
  *   dram_wino_workspace(desc, pass): bytes for pass 0 forward, 1 data gradient, 2 weight
