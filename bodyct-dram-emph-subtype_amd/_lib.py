@@ -79,7 +79,8 @@ SIGNATURES = {
     "dram_bn_apply": (I, [P, P, P, P, I, I, I, I, I, P, I, I, I, I, I, I, P]),
     "dram_colsum_nparts": (I, [LL, I]),
     "dram_bn_bwd_reduce": (I, [P, P, P, P, P, P, P, P, LL, I, I, P]),
-    "dram_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, D, P, LL, I, I, P]),
+    "dram_bn_bwd_apply_nparts": (I, [LL, I]),
+    "dram_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, D, P, P, LL, I, I, P]),
     "dram_colsum": (I, [P, P, LL, I, P]),
     "dram_maxpool_fwd": (I, [P, P, P, I, I, I, I, I, P]),
     "dram_maxpool_bwd": (I, [P, P, P, P, I, I, I, I, I, P]),

@@ -187,8 +187,9 @@ __global__ void bn_bwd_apply_kernel(const float4* __restrict__ dz, const float4*
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const double* __restrict__ sums, double inv_count, float4* __restrict__ dy, int C,
                                     long total4, int relu, const float* __restrict__ scale,
-                                    const float* __restrict__ shift) {
+                                    const float* __restrict__ shift, float* __restrict__ colpart) {
   const int Q = C >> 2;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // colpart: this thread's channel quad is fixed (256 % Q == 0)
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const int c = 4 * (int)(i % Q);
     float4 g = dz[i];
@@ -219,6 +220,20 @@ __global__ void bn_bwd_apply_kernel(const float4* __restrict__ dz, const float4*
     BN_BWD_1(x, 0) BN_BWD_1(y, 1) BN_BWD_1(z, 2) BN_BWD_1(w, 3)
 #undef BN_BWD_1
     dy[i] = o;
+    cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
+  }
+  if (colpart) {   // per-block column sums of dy: the gradient of the bias of the convolution in front
+    __shared__ float4 sm[256];
+    sm[threadIdx.x] = cs;
+    __syncthreads();
+    if ((int)threadIdx.x < Q) {
+      float4 t = sm[threadIdx.x];
+      for (int k = threadIdx.x + Q; k < 256; k += Q) {
+        const float4 u = sm[k];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      *reinterpret_cast<float4*>(colpart + (long)blockIdx.x * C + 4 * threadIdx.x) = t;
+    }
   }
 }
 
@@ -344,17 +359,26 @@ extern "C" int dram_colsum(const float* a, float* partial, long long rows, int C
   return DRAM_OK;
 }
 
+// rows of colsum_partial written by dram_bn_bwd_apply, or DRAM_ERR_UNSUPPORTED when a thread's channel quad is
+// not fixed across its grid-stride loop (C / 4 must divide 256)
+extern "C" int dram_bn_bwd_apply_nparts(long long rows, int C) {
+  if (rows < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
+  if (256 % (C >> 2) != 0) return DRAM_ERR_UNSUPPORTED;
+  return ew_grid((long)rows * (C >> 2));
+}
+
 extern "C" int dram_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* mean,
                                  const float* invstd, const float* gamma, const float* scale, const float* shift,
-                                 const double* sums, double count, float* dy, long long rows, int C, int relu,
-                                 dram_stream_t stream) {
+                                 const double* sums, double count, float* dy, float* colsum_partial, long long rows,
+                                 int C, int relu, dram_stream_t stream) {
   if (!dz || !y || !mean || !invstd || !gamma || !sums || !dy || rows < 1 || C < 4 || (C & 3) || count <= 0.0)
     return DRAM_ERR_BAD_ARG;
   if (relu && !z && !(scale && shift)) return DRAM_ERR_BAD_ARG;
+  if (colsum_partial && dram_bn_bwd_apply_nparts(rows, C) < 1) return DRAM_ERR_UNSUPPORTED;
   const long total4 = (long)rows * (C >> 2);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)dz, (const float4*)z, (const float4*)y, mean, invstd, gamma, sums, 1.0 / count,
-                     (float4*)dy, C, total4, relu, scale, shift);
+                     (float4*)dy, C, total4, relu, scale, shift, colsum_partial);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

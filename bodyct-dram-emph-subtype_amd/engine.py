@@ -42,6 +42,7 @@ class _State:
         self.need_grad = need_grad
         self.dist = dist
         self.grads: Dict[str, Tensor] = {}
+        self.nbt: List[Tensor] = []
 
 
 class Engine:
@@ -65,7 +66,7 @@ class Engine:
             mean, invstd, scale, shift = ops.bn_finalize(sums, count, P[bnp + ".weight"], P[bnp + ".bias"],
                                                          P[bnp + ".running_mean"], P[bnp + ".running_var"],
                                                          BN_MOMENTUM, BN_EPS, True)
-            P[bnp + ".num_batches_tracked"].add_(1)
+            st.nbt.append(P[bnp + ".num_batches_tracked"])      # incremented together at the end of forward
         else:
             mean, invstd, scale, shift = ops.bn_finalize(None, 1.0, P[bnp + ".weight"], P[bnp + ".bias"],
                                                          P[bnp + ".running_mean"], P[bnp + ".running_var"],
@@ -85,6 +86,13 @@ class Engine:
         st.grads[bnp + ".bias"] = sums[0].float()
         if st.dist is not None:
             sums = st.dist.all_reduce_sum(sums)
+        if c.get("b"):    # the convolution in front has a bias: its gradient = column sums of dy, taken on the way
+            dy, colpart = ops.bn_bwd_apply(dz, zmask, c["y"], c["mean"], c["invstd"], st.P[bnp + ".weight"], sums,
+                                           c["count"], True, sc, sh, want_colsum=True)
+            if colpart is None:
+                colpart = ops.colsum(dy)
+            st.grads[c["b"]] = ops.reduce_partials(colpart)[0].float()
+            return dy
         return ops.bn_bwd_apply(dz, zmask, c["y"], c["mean"], c["invstd"], st.P[bnp + ".weight"], sums, c["count"],
                                 True, sc, sh)
 
@@ -107,8 +115,6 @@ class Engine:
         dy = self._bn_bwd(st, c, dz)
         st.grads[c["w"]] = ops.conv3d_bwd_weight(c["x"], dy, c["g"], v_cache=c.get("v"))
         c["v"] = None                                   # release the cached Winograd-domain input
-        if c["b"]:
-            st.grads[c["b"]] = ops.reduce_partials(ops.colsum(dy))[0].float()
         self._grad_ready(st, c)
         if not need_dx:
             return None
@@ -215,6 +221,8 @@ class Engine:
             saved = dict(st=st, x4=x4, y0=y0, xs=xs, mean0=mean0, invstd0=invstd0, count0=count0, ss0=ss0, amax=amax,
                          blocks=block_ctx, cu1=cu1, cu2=cu2, cu3=cu3, xup3=xup3, hw=hw, dense=dense, lungs4=lungs4,
                          denom=denom, n0=n0, n1=n1, xs_shape=tuple(xs.shape))
+        if st.nbt:
+            torch._foreach_add_(st.nbt, 1)               # one launch for all num_batches_tracked counters
         return dense_list, outs, saved
 
     def backward(self, saved: dict, g_dense: List[Optional[Tensor]], g_outs: List[Optional[Tensor]]):

@@ -477,16 +477,24 @@ def bn_bwd_reduce(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, invs
 
 
 def bn_bwd_apply(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, sums: Tensor,
-                 count: float, relu: bool, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None) -> Tensor:
+                 count: float, relu: bool, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
+                 want_colsum: bool = False):
+    """-> dy, or (dy, partial [P,1,C] column sums of dy) with want_colsum (None when C is unsupported there)."""
     C = y.shape[-1]
     _req(dz, "dz", shape=y.shape)
     _mask_args(z, y, scale, shift, relu)
+    colpart = None
+    if want_colsum:
+        npart = _L().dram_bn_bwd_apply_nparts(_rows(y), C)
+        if npart >= 1:
+            colpart = torch.empty((npart, 1, C), device=y.device, dtype=torch.float32)
     _req(sums, "sums", dtype=torch.float64, shape=(2, C))
     _req(gamma, "gamma", shape=(C,))
     dy = torch.empty_like(y)
     _chk(_L().dram_bn_bwd_apply(_p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(scale), _p(shift), _p(sums),
-                                float(count), _p(dy), _rows(y), C, int(relu), _stream()), "dram_bn_bwd_apply")
-    return dy
+                                float(count), _p(dy), _p(colpart), _rows(y), C, int(relu), _stream()),
+         "dram_bn_bwd_apply")
+    return (dy, colpart) if want_colsum else dy
 
 
 def colsum(a: Tensor) -> Tensor:

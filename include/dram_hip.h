@@ -228,11 +228,15 @@ int dram_colsum_nparts(long long rows, int C);
 int dram_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean,
                        const float* invstd, const float* scale, const float* shift, float* partial,
                        long long rows, int C, int relu, dram_stream_t stream);
-/* phase 2: dy = gamma*invstd*(g - sums[0]/count - xhat*sums[1]/count) */
+/* phase 2: dy = gamma*invstd*(g - sums[0]/count - xhat*sums[1]/count).
+ * colsum_partial: NULL, or [dram_bn_bwd_apply_nparts(rows, C)][C] -- per-workgroup column sums of dy (the
+ * bias gradient of the convolution in front, med3d.py:67/:76/:226, without a pass of its own); nparts < 1
+ * => unsupported for this C (C / 4 must divide 256), use dram_colsum. */
+int dram_bn_bwd_apply_nparts(long long rows, int C);
 int dram_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* mean,
                       const float* invstd, const float* gamma, const float* scale, const float* shift,
-                      const double* sums, double count, float* dy, long long rows, int C, int relu,
-                      dram_stream_t stream);
+                      const double* sums, double count, float* dy, float* colsum_partial, long long rows,
+                      int C, int relu, dram_stream_t stream);
 /* partial[p][0][c] = sum_rows a[row][c]  (conv-bias gradient) */
 int dram_colsum(const float* a, float* partial, long long rows, int C, dram_stream_t stream);
 

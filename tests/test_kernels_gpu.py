@@ -452,6 +452,13 @@ def test_batchnorm_relu_residual(ops, C, res):
         assert torch.equal(ops.bn_bwd_reduce(gzd, None, yd, mean_d, invstd_d, True, scale, shift), bp)
         assert torch.equal(ops.bn_bwd_apply(gzd, None, yd, mean_d, invstd_d, gamma.detach().to(DEV), bs, n, True,
                                             scale, shift), dy)
+    dy2, cp = ops.bn_bwd_apply(gzd, z, yd, mean_d, invstd_d, gamma.detach().to(DEV), bs, n, True, want_colsum=True)
+    assert torch.equal(dy2, dy)
+    if cp is not None:     # column sums of dy on the way (bias gradient of a convolution in front)
+        ref = dy.double().reshape(-1, C).sum(0)
+        assert float((ops.reduce_partials(cp)[0] - ref).abs().max()) <= 1e-5 * float(dy.abs().sum() / C) + 1e-6
+    else:
+        assert 256 % (C // 4) != 0
     cs = ops.reduce_partials(ops.colsum(gzd))[0]
     assert rel_l2(cs.cpu(), gz.double().sum((0, 2, 3, 4))) < 1e-5
 
