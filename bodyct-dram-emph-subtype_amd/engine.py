@@ -82,8 +82,9 @@ class Engine:
         sums = ops.reduce_partials(part)
         # parameter gradients use the LOCAL sums (DDP averages them afterwards), the input
         # gradient the all-reduced ones -- torch SyncBatchNorm semantics.
-        st.grads[bnp + ".weight"] = sums[1].float()
-        st.grads[bnp + ".bias"] = sums[0].float()
+        sf = sums.float()                                  # one conversion; the two gradients are its rows
+        st.grads[bnp + ".weight"] = sf[1]
+        st.grads[bnp + ".bias"] = sf[0]
         if st.dist is not None:
             sums = st.dist.all_reduce_sum(sums)
         if c.get("b"):    # the convolution in front has a bias: its gradient = column sums of dy, taken on the way
