@@ -30,11 +30,8 @@
 
 namespace {
 
-constexpr int W2_TZ = 16;                               // tile depth
-constexpr int W2_HROWS = (W2_TZ + 2) * 10 * 10;         // 1800 halo voxels
-constexpr int W2_NPIECE = (W2_HROWS + 15) / 16;         // DMA pieces of 16 rows x 64 B
-constexpr int W2_HQ = (W2_NPIECE + 7) / 8;              // pieces per wave
-constexpr int W2_HALO = W2_NPIECE * 256;                // floats
+constexpr int W2_TZ16 = 16;                             // tile depth of the 8-wave kernel (18 x 10 x 10 halo voxels,
+                                                        // DMA pieces of 16 rows x 64 B); 8 for the other variants
 constexpr int W2_BK = 16;                               // channels per chunk
 
 struct W2dGeom {
@@ -93,20 +90,38 @@ __device__ __forceinline__ int kx(int off, int gk) {
   return r;
 }
 
-template <int NJ>
-__global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restrict__ in, const float* __restrict__ u2,
-                                                          const float* __restrict__ bias, float* __restrict__ out,
-                                                          float* __restrict__ stats, const float* __restrict__ add,
-                                                          const float* __restrict__ gate, const W2dGeom g) {
+// NW waves per workgroup, tile depth 2 * NW; WS weight stages.  <NJ, 8, 2> is the kernel described above (one
+// 147-KB workgroup per CU).  <NJ, 4, 1>: 8-deep tiles, 256 threads, 63-KB halo + ONE weight stage = 79 KB, so
+// TWO workgroups share a CU and run out of phase: the barrier / weight-DMA / halo-reload stretches of one
+// fall into the MFMA stretches of the other (the two waves of a SIMD belong to different workgroups).
+template <int NJ, int NW = 8, int WS = 2>   // WS: 2 = two whole-point stages, 1 = one, 3 = one stage refilled tap by tap
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wino2d_kernel(const float* __restrict__ in, const float* __restrict__ u2,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              float* __restrict__ stats, const float* __restrict__ add,
+                                                              const float* __restrict__ gate, const W2dGeom g) {
+  constexpr int W2_TZ = 2 * NW;
+  constexpr int W2_HROWS = (W2_TZ + 2) * 10 * 10;
+  constexpr int W2_NPIECE = (W2_HROWS + 15) / 16;
+  constexpr int W2_HQ = (W2_NPIECE + NW - 1) / NW;
+  constexpr int W2_HALO = W2_NPIECE * 256;
   constexpr int BN = 32 * NJ;
   constexpr int BROWS = 3 * BN;             // weight rows per xi: (z-tap, n)
   constexpr int BST = BROWS * 16;           // floats per weight stage
   constexpr int BPIECE = BROWS / 16;        // 6 * NJ DMA pieces
-  constexpr int PB = (BPIECE + 7) / 8;
-  __shared__ __attribute__((aligned(1024))) float lds[W2_HALO + 2 * BST];
+  constexpr int PB = (BPIECE + NW - 1) / NW;
+  static_assert(WS != 3 || (NW == 4 && NJ == 2), "tap ring: one DMA piece per wave and tap");
+  // SEPARATE LDS arrays for the halo and each weight stage (tap slot), not one array carved by offsets: the
+  // wait-count pass asks alias analysis whether a ds_read may touch the target of an outstanding LDS-DMA,
+  // and only distinct objects answer no.  Carved from one array, every point began with "s_waitcnt vmcnt(0)"
+  // right behind the DMA issue of the NEXT point's weights -- the double buffering was waited away (the
+  // 1 460 "barrier wait" cycles per point of the phase timing in DESIGN.md).
+  constexpr int TAP = BN * 16;               // floats per z-tap slot
+  __shared__ __attribute__((aligned(1024))) float lds[W2_HALO];
+  __shared__ __attribute__((aligned(1024))) float wsa0[TAP], wsa1[TAP], wsa2[TAP];       // stage 0, taps 0..2
+  __shared__ __attribute__((aligned(1024))) float wsb0[WS == 2 ? TAP : 64], wsb1[WS == 2 ? TAP : 64],
+      wsb2[WS == 2 ? TAP : 64];                                                       // stage 1
   __shared__ int htab[W2_NPIECE * 16];
   float* halo = lds;
-  float* bst = lds + W2_HALO;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -128,7 +143,7 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
   // offset of the voxel at channel 0 with the slot swizzle in its two low bits
   // (offsets are multiples of Ci >= 16), or -1 for rows outside the volume.
   const int pslot = lane & 3;
-  for (int rp = tid; rp < W2_NPIECE * 16; rp += 512) {
+  for (int rp = tid; rp < W2_NPIECE * 16; rp += 64 * NW) {
     const int yh = (rp / 10) % 10;
     const int rl = rp ^ ((yh >> 1) & 1);                      // logical row = (zh*10 + yh)*10 + xh
     const int zh = rl / 100, xh = rl % 10;
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
   int boff[PB];
 #pragma unroll
   for (int j = 0; j < PB; ++j) {
-    int row = 16 * (wave + 8 * j) + (lane >> 2);
+    int row = 16 * (wave + NW * j) + (lane >> 2);
     if (row >= BROWS) row = 0;
     const int a = row / BN, n = row - a * BN;
     boff[j] = (a * g.No + n0 + n) * g.Ci + (pslot ^ bswz(n)) * 4;
@@ -150,23 +165,25 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
   auto issue_halo = [&](int c) __attribute__((always_inline)) {
 #pragma unroll 1   // a rolled loop: the unrolled address math of 15 pieces spilled accumulators to scratch
     for (int q = 0; q < W2_HQ; ++q) {
-      if (wave + 8 * q < W2_NPIECE) {   // wave-uniform
-        const int ho = htab[16 * (wave + 8 * q) + (lane >> 2)];
+      if (wave + NW * q < W2_NPIECE) {   // wave-uniform
+        const int ho = htab[16 * (wave + NW * q) + (lane >> 2)];
         const float* src = ho >= 0 ? in + (long)((ho & ~3) + ((pslot ^ (ho & 3)) << 2) + c * W2_BK) : g_w2d_zero;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(halo + (wave + 8 * q) * 256), 16, 0,
+                                         (__attribute__((address_space(3))) void*)(halo + (wave + NW * q) * 256), 16, 0,
                                          0);
       }
     }
   };
-  auto issue_b = [&](int c, int xi, int stage) __attribute__((always_inline)) {
+  // pieces of 16 rows; a z-tap slot holds BN rows = BN / 16 pieces, so piece pb lives in tap pb / (BN / 16)
+  auto issue_b = [&](int c, int xi, int stage, int only = -1) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
-      if (wave + 8 * j < BPIECE) {      // wave-uniform
+      if ((only < 0 || only == j) && wave + NW * j < BPIECE) {      // wave-uniform
         const float* src = u2 + xi * xi_stride + c * W2_BK + boff[j];
+        const int pb = wave + NW * j, tap = pb / (BN / 16), pin = pb - tap * (BN / 16);
+        float* slot = stage == 0 ? (tap == 0 ? wsa0 : (tap == 1 ? wsa1 : wsa2)) : (tap == 0 ? wsb0 : (tap == 1 ? wsb1 : wsb2));
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(bst + stage * BST + (wave + 8 * j) * 256),
-                                         16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(slot + pin * 256), 16, 0, 0);
       }
     }
   };
@@ -202,16 +219,17 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
     issue_b(c, 0, 0);
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) {
-      __syncthreads();                  // weights of xi (and, at xi = 0, the halo) have landed
-      if (xi + 1 < 16) issue_b(c, xi + 1, (xi + 1) & 1);
+      if (WS != 3 || xi == 0) __syncthreads();   // weights of xi (and, at xi = 0, the halo) have landed
+      const int stage = WS == 2 ? (xi & 1) : 0;
+      if (WS == 2 && xi + 1 < 16) issue_b(c, xi + 1, stage ^ 1);
       const int xy = xi >> 2, xx = xi & 3;
       const int p0 = kBP[xy][0], p1 = kBP[xy][1], q0 = kBP[xx][0], q1 = kBP[xx][1];
       const float s00 = kBS[xy][0] * kBS[xx][0], s01 = kBS[xy][0] * kBS[xx][1];
       const float s10 = kBS[xy][1] * kBS[xx][0], s11 = kBS[xy][1] * kBS[xx][1];
-      const float* bs = bst + (xi & 1) * BST;
       f32x16 t[NJ];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
+        const float* wtap = stage == 0 ? (a == 0 ? wsa0 : (a == 1 ? wsa1 : wsa2)) : (a == 0 ? wsb0 : (a == 1 ? wsb1 : wsb2));
 #pragma unroll
         for (int gk = 0; gk < 2; ++gk) {
           const f32x4 r00 = *reinterpret_cast<const f32x4*>(halo + kx(abase[p0][q0], gk) + a * 1600);
@@ -222,7 +240,7 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
           f32x4 bf[NJ];
 #pragma unroll
           for (int nj = 0; nj < NJ; ++nj)
-            bf[nj] = *reinterpret_cast<const f32x4*>(bs + (a * BN + nj * 32) * 16 + kx(bbase, gk));
+            bf[nj] = *reinterpret_cast<const f32x4*>(wtap + nj * 32 * 16 + kx(bbase, gk));
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -238,6 +256,15 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
             }
           }
           __builtin_amdgcn_sched_barrier(0);   // keep one (tap, k-group)'s operands live at a time
+        }
+        if (WS == 3 && !(xi == 15 && a == 2)) {
+          // tap ring (one 4-KB slot per z-tap, NW == 4 and BN == 64: piece j of a wave IS tap j): every wave is
+          // done with slot a -> refill it with the next point's tap a, two taps ahead of its use.  A wave's
+          // DMAs land in order: all but the newest must be there (the next tap's); none is newer at the end.
+          if (xi == 15 && a >= 1) asm volatile("s_waitcnt vmcnt(0)");
+          else asm volatile("s_waitcnt vmcnt(1)");
+          __builtin_amdgcn_s_barrier();
+          if (xi + 1 < 16) issue_b(c, xi + 1, 0, a);
         }
       }
       // output transform on the fly: y[oy][ox] += A^T[oy][xi_y] * A^T[ox][xi_x] * t
@@ -256,6 +283,10 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
           }
         }
       __builtin_amdgcn_sched_barrier(0);   // the adds stay here, in the shadow of this xi's last MFMAs
+      if (WS == 1 && xi + 1 < 16) {
+        __syncthreads();                  // single weight stage: every wave has read xi's weights
+        issue_b(c, xi + 1, 0);
+      }
     }
   }
 
@@ -297,7 +328,7 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
   }
   if (stats) {
     __syncthreads();
-    float* red = lds;  // [8 waves][2][BN]
+    float* red = lds;  // [NW waves][2][BN]
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
       const float t1 = s1[nj] + __shfl_xor(s1[nj], 32, 64);
@@ -312,7 +343,7 @@ __global__ __launch_bounds__(512) void conv_wino2d_kernel(const float* __restric
       const int which = tid / BN, cc = tid - which * BN;
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) v += red[(w * 2 + which) * BN + cc];
+      for (int w = 0; w < NW; ++w) v += red[(w * 2 + which) * BN + cc];
       stats[((long)mt * 2 + which) * g.No + n0 + cc] = v;
     }
   }
@@ -366,9 +397,13 @@ __global__ __launch_bounds__(512) void conv_wino2d16_kernel(const float* __restr
   constexpr int BST = BROWS * 16;
   constexpr int BPIECE = BROWS / 16;
   constexpr int PB = (BPIECE + 7) / 8;
-  __shared__ __attribute__((aligned(1024))) float lds[2 * V2_HALO + 2 * BST];
+  // separate LDS objects per buffer (see conv_wino2d_kernel): only then the wait-count pass lets the reads of one
+  // buffer run under the outstanding DMAs into the other -- carved from one array the halo prefetch was waited
+  // for at every point, which is why this variant first measured no better than the single-buffered one
+  __shared__ __attribute__((aligned(1024))) float lds[V2_HALO];     // halo buffer 0 (and the stats scratch)
+  __shared__ __attribute__((aligned(1024))) float halo1[V2_HALO];   // halo buffer 1
+  __shared__ __attribute__((aligned(1024))) float wst0[BST], wst1[BST];
   __shared__ int htab[V2_NPIECE * 16];
-  float* bst = lds + 2 * V2_HALO;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -404,11 +439,11 @@ __global__ __launch_bounds__(512) void conv_wino2d16_kernel(const float* __restr
   }
   const long xi_stride = 3L * g.No * g.Ci;
 
-  auto issue_halo_piece = [&](int c, int p, int buf) __attribute__((always_inline)) {
+  auto issue_halo_piece = [&](int c, int p, float* buf) __attribute__((always_inline)) {
     const int ho = htab[16 * p + (lane >> 2)];
     const float* src = ho >= 0 ? in + (long)((ho & ~3) + ((pslot ^ (ho & 3)) << 2) + c * W2_BK) : g_w2d_zero;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(lds + buf * V2_HALO + p * 256), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(buf + p * 256), 16, 0, 0);
   };
   auto issue_b = [&](int c, int xi, int stage) __attribute__((always_inline)) {
 #pragma unroll
@@ -416,7 +451,7 @@ __global__ __launch_bounds__(512) void conv_wino2d16_kernel(const float* __restr
       if (wave + 8 * j < BPIECE) {      // wave-uniform
         const float* src = u2 + xi * xi_stride + c * W2_BK + boff[j];
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(bst + stage * BST + (wave + 8 * j) * 256),
+                                         (__attribute__((address_space(3))) void*)((stage ? wst1 : wst0) + (wave + 8 * j) * 256),
                                          16, 0, 0);
       }
     }
@@ -450,11 +485,12 @@ __global__ __launch_bounds__(512) void conv_wino2d16_kernel(const float* __restr
   __syncthreads();                      // htab complete
 #pragma unroll 1
   for (int q = 0; q < 8; ++q)
-    if (wave + 8 * q < V2_NPIECE) issue_halo_piece(0, wave + 8 * q, 0);
+    if (wave + 8 * q < V2_NPIECE) issue_halo_piece(0, wave + 8 * q, lds);
   issue_b(0, 0, 0);
 
-  for (int c = 0; c < nchunk; ++c) {
-    const float* hb = lds + (c & 1) * V2_HALO;
+  // one 16-channel chunk: reads halo buffer hb, prefetches the next chunk's halo into hn (inlined twice with the
+  // two buffers in either role, so that each copy names its LDS objects)
+  auto chunk = [&](const int c, const float* hb, float* hn) __attribute__((always_inline)) {
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) {
       __syncthreads();                  // weights of (c, xi) have landed (at xi = 0 also the rest of halo c)
@@ -463,13 +499,13 @@ __global__ __launch_bounds__(512) void conv_wino2d16_kernel(const float* __restr
       if (c + 1 < nchunk) {             // next chunk's halo: 4 pieces per point, waves 0-3 / 4-7 alternate
         const int w4 = wave - 4 * (xi & 1);
         const int p = xi * 4 + w4;
-        if (w4 >= 0 && w4 < 4 && p < V2_NPIECE) issue_halo_piece(c + 1, p, (c + 1) & 1);
+        if (w4 >= 0 && w4 < 4 && p < V2_NPIECE) issue_halo_piece(c + 1, p, hn);
       }
       const int xy = xi >> 2, xx = xi & 3;
       const int p0 = kBP[xy][0], p1 = kBP[xy][1], q0 = kBP[xx][0], q1 = kBP[xx][1];
       const float s00 = kBS[xy][0] * kBS[xx][0], s01 = kBS[xy][0] * kBS[xx][1];
       const float s10 = kBS[xy][1] * kBS[xx][0], s11 = kBS[xy][1] * kBS[xx][1];
-      const float* bs = bst + (xi & 1) * BST;
+      const float* bs = (xi & 1) ? wst1 : wst0;
       f32x4 t[NB];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -510,6 +546,10 @@ __global__ __launch_bounds__(512) void conv_wino2d16_kernel(const float* __restr
           }
         }
     }
+  };
+  for (int c = 0; c < nchunk; c += 2) {
+    chunk(c, lds, halo1);
+    if (c + 1 < nchunk) chunk(c + 1, halo1, lds);
   }
 
   // ---- epilogue: D register i of a 16x16 block <-> row 4*kq + i = tile (ty = kq, tx = i), column lr ---
@@ -623,16 +663,18 @@ bool w2d_ok(const DramConvDesc* d, int K, int N) {
   return (long long)d->B * d->D * d->H * d->W * cmax < (1LL << 31);
 }
 
-// Kernel variant: 1 = 32x32x2 kernel (16-deep tiles), 2 = 16x16x4 kernel (8-deep tiles).  The two
-// measure within 0-4 % of each other on full tiles (variant 1 ahead on the largest layers), so the
-// choice is made on waste: variant 2 when 16-deep tiles would pad the depth more than 8-deep ones, or
-// when they would leave the chip under-filled (one workgroup per CU: 128 tiles on 256 CUs run at half
-// rate, 256 half-size tiles do not).  DRAM_W2D_V forces one (tests).
-int w2d_variant(const DramConvDesc* d, int n_tiles) {
+// Kernel variant: 1 = 32x32x2 kernel, 8 waves, 16-deep tiles; 2 = 16x16x4 kernel, 8-deep tiles, double-buffered
+// halo; 3 = 32x32x2 kernel as two 4-wave workgroups per CU, 8-deep tiles, weights refilled tap by tap.
+// Measured (fwd / dgrad ms, 64->64 @ 2x64x128x128): 2.15 / 2.01, 2.28 / 2.14, 2.13 / 1.94; 64->32 forward
+// (32 columns): 1.36, 1.35, 1.39.  So 64-column launches take variant 3; 32-column ones variant 1, or 2 when
+// 16-deep tiles would pad the depth more than 8-deep ones or leave the chip under-filled (one workgroup per
+// CU: 128 tiles on 256 CUs run at half rate, 256 half-size tiles do not).  DRAM_W2D_V forces one (tests).
+int w2d_variant(const DramConvDesc* d, int n_tiles, int BN) {
   if (const char* e = getenv("DRAM_W2D_V")) {
     const int v = atoi(e);
-    if (v == 1 || v == 2) return v;
+    if (v >= 1 && v <= 3) return v;
   }
+  if (BN == 64) return 3;
   const int z16 = (d->D + 15) / 16, z8 = (d->D + 7) / 8;
   if (z16 * 16 != z8 * 8) return 2;
   const long cols = (long)d->B * ((d->H + 7) / 8) * ((d->W + 7) / 8) * n_tiles;
@@ -644,9 +686,9 @@ W2dGeom make_w2d(const DramConvDesc* d, int K, int N, int BN, int* variant = nul
   W2dGeom g{};
   g.B = d->B; g.D = d->D; g.H = d->H; g.W = d->W; g.Ci = K; g.No = N;
   g.n_tiles = N / BN;
-  const int v = w2d_variant(d, g.n_tiles);
+  const int v = w2d_variant(d, g.n_tiles, BN);
   if (variant) *variant = v;
-  const int tz = v == 1 ? W2_TZ : V2_TZ;
+  const int tz = v == 1 ? W2_TZ16 : V2_TZ;
   g.nz = (g.D + tz - 1) / tz;
   g.ny = (g.H + 7) / 8;
   g.nx = (g.W + 7) / 8;
@@ -665,6 +707,11 @@ int run_w2d(const float* in, const float* u2, const float* bias, const float* ad
       hipLaunchKernelGGL((conv_wino2d_kernel<2>), dim3(g.nblk), dim3(512), 0, s, in, u2, bias, out, stats, add, gate, g);
     else
       hipLaunchKernelGGL((conv_wino2d_kernel<1>), dim3(g.nblk), dim3(512), 0, s, in, u2, bias, out, stats, add, gate, g);
+  } else if (variant == 3) {
+    if (BN == 64)
+      hipLaunchKernelGGL((conv_wino2d_kernel<2, 4, 3>), dim3(g.nblk), dim3(256), 0, s, in, u2, bias, out, stats, add, gate, g);
+    else
+      hipLaunchKernelGGL((conv_wino2d_kernel<1, 4, 1>), dim3(g.nblk), dim3(256), 0, s, in, u2, bias, out, stats, add, gate, g);
   } else {
     if (BN == 64)
       hipLaunchKernelGGL((conv_wino2d16_kernel<4>), dim3(g.nblk), dim3(512), 0, s, in, u2, bias, out, stats, add, gate, g);

@@ -295,7 +295,7 @@ W2D_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", ["1", "2"], ids=["mfma32x32x2", "mfma16x16x4"])
+@pytest.mark.parametrize("variant", ["1", "2", "3"], ids=["mfma32x32x2", "mfma16x16x4", "mfma32x32x2-2wg"])
 @pytest.mark.parametrize("case", W2D_CASES, ids=[str(c) for c in W2D_CASES])
 def test_conv3d_fused_inplane_winograd(ops, monkeypatch, case, variant):
     """conv_wino2d_kernel (halo in LDS, A fragments B^T v B formed on the fly, output transform
