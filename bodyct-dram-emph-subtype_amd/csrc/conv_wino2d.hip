@@ -666,7 +666,7 @@ bool w2d_ok(const DramConvDesc* d, int K, int N) {
 // Kernel variant: 1 = 32x32x2 kernel, 8 waves, 16-deep tiles; 2 = 16x16x4 kernel, 8-deep tiles, double-buffered
 // halo; 3 = 32x32x2 kernel as two 4-wave workgroups per CU, 8-deep tiles, weights refilled tap by tap.
 // Measured (fwd / dgrad ms, 64->64 @ 2x64x128x128): 2.15 / 2.01, 2.28 / 2.14, 2.13 / 1.94; 64->32 forward
-// (32 columns): 1.36, 1.35, 1.39.  So 64-column launches take variant 3; 32-column ones variant 1, or 2 when
+// (32 columns): 1.36, 1.35, 1.39.  So 64-column launches on >= 1024 tiles take variant 3; the others variant 1, or 2 when
 // 16-deep tiles would pad the depth more than 8-deep ones or leave the chip under-filled (one workgroup per
 // CU: 128 tiles on 256 CUs run at half rate, 256 half-size tiles do not).  DRAM_W2D_V forces one (tests).
 int w2d_variant(const DramConvDesc* d, int n_tiles, int BN) {
@@ -674,10 +674,10 @@ int w2d_variant(const DramConvDesc* d, int n_tiles, int BN) {
     const int v = atoi(e);
     if (v >= 1 && v <= 3) return v;
   }
-  if (BN == 64) return 3;
   const int z16 = (d->D + 15) / 16, z8 = (d->D + 7) / 8;
-  if (z16 * 16 != z8 * 8) return 2;
   const long cols = (long)d->B * ((d->H + 7) / 8) * ((d->W + 7) / 8) * n_tiles;
+  if (BN == 64 && cols * z8 >= 1024) return 3;       // two 4-wave workgroups per CU: at least two rounds of 512 slots
+  if (z16 * 16 != z8 * 8) return 2;
   auto fill = [](long wgs) { return (double)wgs / (double)(((wgs + 255) / 256) * 256); };
   return fill(cols * z16) + 0.05 < fill(cols * z8) ? 2 : 1;
 }
