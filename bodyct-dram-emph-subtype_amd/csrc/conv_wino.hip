@@ -339,8 +339,11 @@ __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float
         for (int k = 0; k < NK; ++k) {
           const int x = x0 + (k - 1) * g.d;
           const bool ok = yo & (x >= 0) & (x < g.W);
-          const long oo = ((((long)b * g.D + z) * g.H + y) * g.W + x) * C + c;
-          row[k] = ok ? in[oo] : 0.f;
+          // branch-free: a wave-uniform "ok ? load : 0" becomes a branch around every load, and the loads of a
+          // row are then waited for one row at a time (6 in flight per wave)
+          const long oo = ok ? ((((long)b * g.D + z) * g.H + y) * g.W + x) * C + c : c;
+          const float ld = in[oo];
+          row[k] = ok ? ld : 0.f;
         }
         bt4(row);
 #pragma unroll
@@ -384,8 +387,9 @@ __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float
         for (int k = 0; k < 4; ++k) {
           const int x = x0 + k * g.d;
           const bool ok = (z < g.D) & (y < g.H) & (x < g.W);
-          const long oo = ((((long)b * g.D + z) * g.H + y) * g.W + x) * C + c;
-          u[k] = ok ? in[oo] : 0.f;
+          const long oo = ok ? ((((long)b * g.D + z) * g.H + y) * g.W + x) * C + c : c;
+          const float ld = in[oo];
+          u[k] = ok ? ld : 0.f;
         }
         a4(u, r);
 #pragma unroll
