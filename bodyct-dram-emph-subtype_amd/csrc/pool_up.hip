@@ -27,25 +27,36 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     int ax = 0, ay = 0, az = 0, aw = 0;
     bool first = true;
-    // scan order kd, kh, kw; strict '>' keeps the first maximum (ATen max_pool3d semantics)
+    // scan order kd, kh, kw; strict '>' keeps the first maximum (ATen max_pool3d semantics).  The nine taps of a
+    // plane are loaded together (clamped coordinates, validity flags) -- a guarded load per tap is waited for
+    // one at a time
     for (int kz = 0; kz < 3; ++kz) {
       const int zi = 2 * zo - 1 + kz;
       if (zi < 0 || zi >= D) continue;
-      for (int ky = 0; ky < 3; ++ky) {
-        const int yi = 2 * yo - 1 + ky;
-        if (yi < 0 || yi >= H) continue;
+      float4 t[3][3];
+      bool ok[3][3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const int xi = 2 * xo - 1 + kx;
-          if (xi < 0 || xi >= W) continue;
-          const float4 t = *reinterpret_cast<const float4*>(x + ((((b * D + zi) * H + yi) * W + xi) * (long)C + 4 * q));
+          const int yi = 2 * yo - 1 + ky, xi = 2 * xo - 1 + kx;
+          ok[ky][kx] = (yi >= 0) & (yi < H) & (xi >= 0) & (xi < W);
+          const int yc = yi < 0 ? 0 : (yi >= H ? H - 1 : yi), xc = xi < 0 ? 0 : (xi >= W ? W - 1 : xi);
+          t[ky][kx] = *reinterpret_cast<const float4*>(x + ((((b * D + zi) * H + yc) * W + xc) * (long)C + 4 * q));
+        }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          if (!ok[ky][kx]) continue;
+          const float4 tv = t[ky][kx];
           const int tap = (kz * 3 + ky) * 3 + kx;
-          if (first || t.x > m.x || t.x != t.x) { m.x = t.x; ax = tap; }
-          if (first || t.y > m.y || t.y != t.y) { m.y = t.y; ay = tap; }
-          if (first || t.z > m.z || t.z != t.z) { m.z = t.z; az = tap; }
-          if (first || t.w > m.w || t.w != t.w) { m.w = t.w; aw = tap; }
+          if (first || tv.x > m.x || tv.x != tv.x) { m.x = tv.x; ax = tap; }
+          if (first || tv.y > m.y || tv.y != tv.y) { m.y = tv.y; ay = tap; }
+          if (first || tv.z > m.z || tv.z != tv.z) { m.z = tv.z; az = tap; }
+          if (first || tv.w > m.w || tv.w != tv.w) { m.w = tv.w; aw = tap; }
           first = false;
         }
-      }
     }
     reinterpret_cast<float4*>(y)[i] = m;
     reinterpret_cast<uchar4*>(amax)[i] = make_uchar4((unsigned char)ax, (unsigned char)ay, (unsigned char)az,
@@ -69,26 +80,38 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
     const int zlo = zi >> 1, zhi = (zi + 1) >> 1;  // ceil((zi-1)/2) == zi>>1 for zi>=0
     const int ylo = yi >> 1, yhi = (yi + 1) >> 1;
     const int xlo = xi >> 1, xhi = (xi + 1) >> 1;
-    for (int zo = zlo; zo <= zhi; ++zo) {
-      if (zo >= Do) continue;
-      const int kz = zi - (2 * zo - 1);
-      for (int yo = ylo; yo <= yhi; ++yo) {
-        if (yo >= Ho) continue;
-        const int ky = yi - (2 * yo - 1);
-        for (int xo = xlo; xo <= xhi; ++xo) {
-          if (xo >= Wo) continue;
-          const int kx = xi - (2 * xo - 1);
-          const unsigned char tap = (unsigned char)((kz * 3 + ky) * 3 + kx);
+    // the (up to) 2 x 2 x 2 windows containing this voxel: all eight (argmax, dy) pairs are loaded together with
+    // clamped window indices, invalid ones are skipped afterwards -- in the original scan order
+    uchar4 am[2][2][2];
+    float4 gg[2][2][2];
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+      for (int dy_ = 0; dy_ < 2; ++dy_)
+#pragma unroll
+        for (int dx_ = 0; dx_ < 2; ++dx_) {
+          const int zo = min(zlo + dz, Do - 1), yo = min(ylo + dy_, Ho - 1), xo = min(xlo + dx_, Wo - 1);
           const long o = ((((b * Do + zo) * Ho + yo) * Wo + xo) * (long)Q + q);
-          const uchar4 a = reinterpret_cast<const uchar4*>(amax)[o];
-          const float4 g = reinterpret_cast<const float4*>(dy)[o];
+          am[dz][dy_][dx_] = reinterpret_cast<const uchar4*>(amax)[o];
+          gg[dz][dy_][dx_] = reinterpret_cast<const float4*>(dy)[o];
+        }
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+      for (int dy_ = 0; dy_ < 2; ++dy_)
+#pragma unroll
+        for (int dx_ = 0; dx_ < 2; ++dx_) {
+          const int zo = zlo + dz, yo = ylo + dy_, xo = xlo + dx_;
+          if (zo > zhi || zo >= Do || yo > yhi || yo >= Ho || xo > xhi || xo >= Wo) continue;
+          const int kz = zi - (2 * zo - 1), ky = yi - (2 * yo - 1), kx = xi - (2 * xo - 1);
+          const unsigned char tap = (unsigned char)((kz * 3 + ky) * 3 + kx);
+          const uchar4 a = am[dz][dy_][dx_];
+          const float4 g = gg[dz][dy_][dx_];
           if (a.x == tap) s.x += g.x;
           if (a.y == tap) s.y += g.y;
           if (a.z == tap) s.z += g.z;
           if (a.w == tap) s.w += g.w;
         }
-      }
-    }
     reinterpret_cast<float4*>(dx)[i] = s;
   }
 }
