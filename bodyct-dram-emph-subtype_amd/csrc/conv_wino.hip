@@ -778,22 +778,32 @@ __global__ __launch_bounds__(512) void wino_gemm_nn_kernel(const float* __restri
     __syncthreads();   // tile `it` has landed; stage (it+1)&1 is free again
     if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
     const float* st = lds + (it & 1) * STAGE;
+    // operand fragments double-buffered in registers: the reads of k-group gk + 1 are issued in front of the
+    // MFMAs of gk (left to the scheduler they came one MFMA before their use)
+    f32x4 a0[2], a1[2], bf[2][NJ];
+    auto frag = [&](int gk, int buf) __attribute__((always_inline)) {
+      const int so = ((2 * gk + lh) ^ rsw) * 4;
+      a0[buf] = *reinterpret_cast<const f32x4*>(st + a_row + so);
+      a1[buf] = *reinterpret_cast<const f32x4*>(st + a_row + 32 * 32 + so);
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) bf[buf][nj] = *reinterpret_cast<const f32x4*>(st + b_row + nj * 32 * 32 + so);
+    };
+    frag(0, 0);
 #pragma unroll
     for (int gk = 0; gk < 4; ++gk) {
-      const int so = ((2 * gk + lh) ^ rsw) * 4;
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(st + a_row + so);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(st + a_row + 32 * 32 + so);
-      f32x4 bf[NJ];
-#pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) bf[nj] = *reinterpret_cast<const f32x4*>(st + b_row + nj * 32 * 32 + so);
+      if (gk + 1 < 4) frag(gk + 1, (gk + 1) & 1);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj) {
-          acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bf[nj][e], acc[0][nj], 0, 0, 0);
-          acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bf[nj][e], acc[1][nj], 0, 0, 0);
+          acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[gk & 1][e], bf[gk & 1][nj][e], acc[0][nj], 0, 0, 0);
+          acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[gk & 1][e], bf[gk & 1][nj][e], acc[1][nj], 0, 0, 0);
         }
       }
+      // pin the order inside the region: the (2 + NJ) fragment reads of the next group first, then the MFMAs
+      if (gk + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8 * NJ, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
