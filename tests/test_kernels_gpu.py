@@ -498,6 +498,20 @@ def test_upcat(ops, case):
     assert torch.equal(to_ncdhw(dskip), gk_ref)
 
 
+def test_upcat_tiled_forward(ops, monkeypatch):
+    """>= 512 output blocks and Cu % 64 == 0: the LDS-tiled forward kernel (ragged extents, cropped skip, two
+    64-channel blocks) against the oracle and against the untiled kernel (same corner order; fma contraction may
+    differ between the two kernels, the copied skip channels are identical)."""
+    B, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck = 1, 33, 30, 35, 128, 67, 62, 70, 64
+    src, skip = rnd(B, Cu, Ds, Hs, Ws, seed=1), rnd(B, Ck, Dk, Hk, Wk, seed=2)
+    cat_ref = orc.crop_concat(orc.upsample2_trilinear(src), skip)
+    cat = ops.upcat_fwd(to_ndhwc(src), to_ndhwc(skip))
+    assert rel_l2(to_ncdhw(cat), cat_ref) < 1e-6
+    monkeypatch.setenv("DRAM_UPCAT_UNTILED", "1")
+    cat2 = ops.upcat_fwd(to_ndhwc(src), to_ndhwc(skip))
+    assert rel_l2(cat2.cpu(), cat.cpu()) < 2e-6 and torch.equal(cat2[..., Cu:], cat[..., Cu:])
+
+
 @pytest.mark.parametrize("mode", ["cls", "reg", "reg_nolungs"])
 def test_head(ops, mode):
     B, D, H, W = 2, 4, 6, 5
