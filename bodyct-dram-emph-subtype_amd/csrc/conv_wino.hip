@@ -1322,7 +1322,6 @@ bool wino_size_ok(const DramConvDesc* d) {   // int32 offsets inside one xi plan
   return true;
 }
 
-int nj_for(int N) { return N % 256 == 0 ? 4 : (N % 128 == 0 ? 2 : 1); }
 
 // wgrad: M = Cout, N = Cin.  Tile = the largest (BM, BN) that divides M and wastes < 13 % of N;
 // split over t so that >= ~512 workgroups are in flight.
@@ -1381,9 +1380,20 @@ int launch_wino_in(const float* src, float* dst, const WinoGeom& g, const int C,
 
 int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, int K, hipStream_t s,
            const GemmEpilogue ep = GemmEpilogue{nullptr, nullptr, nullptr, nullptr}, const int math = 0) {
-  int nj = nj_for(N);
+  // N tile = 64 * nj columns.  One workgroup per CU (64-128 KB of LDS), so a launch runs in whole rounds of 256
+  // workgroups: 864 workgroups of 256 columns (layer4, 216 points) take 4 rounds with the last 3/8 full, 1728 of
+  // 128 columns take 7 (measured 0.747 -> 0.706 ms).  Pick the width with the least rounds x width x per-column
+  // cost (narrower tiles re-read the M operand more often: +3 % / +10 %, measured).
   const int m_tiles = g.Tpad / 256;
-  while (nj > 1 && (long)g.npts * m_tiles * (N / (64 * nj)) < 512) nj >>= 1;   // single-point GEMMs: fill the chip first
+  int nj = 1;
+  double best = 1e30;
+  for (int c = 4; c >= 1; c >>= 1) {
+    if (N % (64 * c) != 0) continue;
+    const long wgs = (long)g.npts * m_tiles * (N / (64 * c));
+    const double cost = (double)((wgs + 255) / 256) * c * (c == 4 ? 1.0 : (c == 2 ? 1.03 : 1.10));
+    if (cost < best) { best = cost; nj = c; }
+  }
+  if (const char* e = getenv("DRAM_NN_NJ")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && N % (64 * v) == 0) nj = v; }
   const int n_tiles = N / (64 * nj);
   const int nblk = g.npts * m_tiles * n_tiles;
   if (math) {      // split-bf16 operand images (Winograd pipeline only; no fused epilogue there)
