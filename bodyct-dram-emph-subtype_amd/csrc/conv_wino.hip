@@ -1340,6 +1340,16 @@ bool plan_tn(const DramConvDesc* d, const WinoGeom& g, TnPlan& p) {
   }
   p.m_tiles = M / p.bm;
   p.n_tiles = (N + p.bn - 1) / p.bn;
+  // whole rounds of 256 workgroups (one per CU), as in run_nn: half-width tiles when they waste less of the last round
+  if (p.bn >= 128 && (p.bn > 128 || p.bm == 256)) {
+    const long w1 = (long)g.npts * p.m_tiles * p.n_tiles;
+    const int hb = p.bn / 2, hn = (N + hb - 1) / hb;
+    const long w2 = (long)g.npts * p.m_tiles * hn;
+    if (w1 >= 512 && (double)((w2 + 255) / 256) * 0.5 * 1.03 < (double)((w1 + 255) / 256)) {
+      p.bn = hb;
+      p.n_tiles = hn;
+    }
+  }
   const int base = g.npts * p.m_tiles * p.n_tiles;
   const int k32 = g.Tpad / 32;
   int ns = 1;
