@@ -83,7 +83,7 @@ SIGNATURES = {
     "dram_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, D, P, P, LL, I, I, P]),
     "dram_colsum": (I, [P, P, LL, I, P]),
     "dram_maxpool_fwd": (I, [P, P, P, I, I, I, I, I, P]),
-    "dram_maxpool_bwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "dram_maxpool_bwd": (I, [P, P, P, I, P, I, I, I, I, I, P]),
     "dram_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "dram_upcat_bwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "dram_head_nblk": (I, [LL]),

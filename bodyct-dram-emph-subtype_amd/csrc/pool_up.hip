@@ -66,8 +66,8 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
 }
 
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ amax,
-                                   const float* __restrict__ add, float* __restrict__ dx, int D, int H, int W, int C,
-                                   int Do, int Ho, int Wo, long total4) {
+                                   const float* __restrict__ add, int add_stride, float* __restrict__ dx, int D, int H,
+                                   int W, int C, int Do, int Ho, int Wo, long total4) {
   const int Q = C >> 2;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i % Q);
@@ -76,7 +76,9 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
     const int yi = (int)(v % H); v /= H;
     const int zi = (int)(v % D);
     const long b = v / D;
-    float4 s = add ? reinterpret_cast<const float4*>(add)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // add: a tensor shaped like dx, or a channel slice of a wider one (add_stride floats per voxel)
+    float4 s = add ? *reinterpret_cast<const float4*>(add + (i / Q) * (long)add_stride + 4 * q)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
     // windows containing zi: zo with 2zo-1 <= zi <= 2zo+1
     const int zlo = zi >> 1, zhi = (zi + 1) >> 1;  // ceil((zi-1)/2) == zi>>1 for zi>=0
     const int ylo = yi >> 1, yhi = (yi + 1) >> 1;
@@ -360,13 +362,14 @@ extern "C" int dram_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int B
   return DRAM_OK;
 }
 
-extern "C" int dram_maxpool_bwd(const float* dy, const uint8_t* argmax, const float* add, float* dx, int B, int D,
-                                int H, int W, int C, dram_stream_t stream) {
+extern "C" int dram_maxpool_bwd(const float* dy, const uint8_t* argmax, const float* add, int add_stride, float* dx,
+                                int B, int D, int H, int W, int C, dram_stream_t stream) {
   if (!dy || !dx || !argmax || B < 1 || D < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
+  if (add && (add_stride < C || (add_stride & 3) || ((uintptr_t)add & 15))) return DRAM_ERR_BAD_ARG;
   const int Do = (D + 2 - 3) / 2 + 1, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long total4 = (long)B * D * H * W * (C >> 2);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, argmax, add,
-                     dx, D, H, W, C, Do, Ho, Wo, total4);
+                     add_stride, dx, D, H, W, C, Do, Ho, Wo, total4);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

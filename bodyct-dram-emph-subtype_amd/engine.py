@@ -164,10 +164,14 @@ class Engine:
                                    f"{p}.conv_blocks.1.1", 3, 1, 1, 1)
         return zb, (ca, cb, tuple(src.shape), tuple(skip.shape))
 
-    def _up_bwd(self, st, ctx, dz):
+    def _up_bwd(self, st, ctx, dz, skip_view=False):
         ca, cb, src_shape, skip_shape = ctx
         dza = self._conv_bn_bwd(st, cb, dz)
         dcat = self._conv_bn_bwd(st, ca, dza)
+        if skip_view and tuple(skip_shape[1:4]) == tuple(dcat.shape[1:4]):
+            # no crop: the consumer reads the skip half of dcat in place (a channel-slice view) instead of a copy
+            dsrc, _ = ops.upcat_bwd(dcat, src_shape, skip_shape, True, False)
+            return dsrc, dcat[..., src_shape[4]:]
         return ops.upcat_bwd(dcat, src_shape, skip_shape, True, True)
 
     # ------------------------------------------------------------------ whole network
@@ -265,7 +269,7 @@ class Engine:
             st.dist.grads_ready(st.grads, ["fcs.0.weight", "fcs.0.bias", "fcs.1.weight", "fcs.1.bias"])
 
         dxup2 = self._conv_bn_bwd(st, saved["cu3"], dxup3)
-        dxup1, dskip_stem = self._up_bwd(st, saved["cu2"], dxup2)
+        dxup1, dskip_stem = self._up_bwd(st, saved["cu2"], dxup2, skip_view=True)   # consumed by maxpool_bwd
         d, dskip_x1 = self._up_bwd(st, saved["cu1"], dxup1)
 
         # walk the residual stages backwards; x1 (end of layer1) also feeds the us1 skip

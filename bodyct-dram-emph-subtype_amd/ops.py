@@ -536,10 +536,19 @@ def maxpool_bwd(dy: Tensor, argmax: Tensor, in_shape, add_: Optional[Tensor] = N
     oshape = (B, pool_out(D), pool_out(H), pool_out(W), C)
     _req(dy, "dy", shape=oshape)
     _req(argmax, "argmax", dtype=torch.uint8, shape=oshape)
+    add_stride = C
     if add_ is not None:
-        _req(add_, "add", shape=in_shape)
+        # a dense tensor shaped like dx, or a channel slice [..., c0:c0+C] of a dense wider tensor (read in place)
+        if (not add_.is_cuda or add_.dtype != torch.float32 or tuple(add_.shape) != tuple(in_shape)
+                or add_.stride(-1) != 1):
+            raise ValueError("maxpool_bwd: add must be an fp32 device tensor shaped like the pooled input")
+        add_stride = add_.stride(3)
+        want = (D * H * W * add_stride, H * W * add_stride, W * add_stride, add_stride, 1)
+        if tuple(add_.stride()) != want or add_stride % 4 or add_.data_ptr() % 16:
+            raise ValueError("maxpool_bwd: add must be dense or a 16-byte aligned channel slice of a dense tensor")
     dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
-    _chk(_L().dram_maxpool_bwd(_p(dy), _p(argmax), _p(add_), _p(dx), B, D, H, W, C, _stream()), "dram_maxpool_bwd")
+    _chk(_L().dram_maxpool_bwd(_p(dy), _p(argmax), _p(add_), add_stride, _p(dx),
+                               B, D, H, W, C, _stream()), "dram_maxpool_bwd")
     return dx
 
 

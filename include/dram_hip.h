@@ -243,11 +243,13 @@ int dram_colsum(const float* a, float* partial, long long rows, int C, dram_stre
 /* ------------------------------------------------------------------------- */
 /* MaxPool3d(k=3,s=2,p=1) -- med3d.py:206/:275.  argmax: uint8 tap index (first max
  * wins, scan order kd,kh,kw like ATen).  Backward is a gather (deterministic);
- * dx = maxpool^T(dy) (+ add if not NULL). */
+ * dx = maxpool^T(dy) (+ add if not NULL).  add: voxel-major like dx with add_stride floats per voxel
+ * (add_stride == C: a tensor shaped like dx; larger: a channel slice of a wider tensor, e.g. the skip half
+ * of the decoder's concat gradient read in place). */
 int dram_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int B, int D, int H, int W, int C,
                      dram_stream_t stream);
-int dram_maxpool_bwd(const float* dy, const uint8_t* argmax, const float* add, float* dx, int B, int D,
-                     int H, int W, int C, dram_stream_t stream);
+int dram_maxpool_bwd(const float* dy, const uint8_t* argmax, const float* add, int add_stride, float* dx,
+                     int B, int D, int H, int W, int C, dram_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* dRAM up-projection inside the decoder: nn.Upsample(x2, trilinear, align_corners=True)

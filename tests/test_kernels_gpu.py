@@ -481,6 +481,9 @@ def test_maxpool(ops, shape):
     addt = rnd(B, C, D, H, W, seed=3)
     dx = ops.maxpool_bwd(to_ndhwc(gy), am, tuple(xd.shape), to_ndhwc(addt))
     assert rel_l2(to_ncdhw(dx), gx_ref + addt) < 1e-6
+    if C % 4 == 0:      # the add operand as a channel slice of a wider tensor, read in place
+        wide = torch.cat([torch.zeros_like(to_ndhwc(addt))[..., :4], to_ndhwc(addt)], dim=-1).contiguous()
+        assert torch.equal(ops.maxpool_bwd(to_ndhwc(gy), am, tuple(xd.shape), wide[..., 4:]), dx)
 
 
 @pytest.mark.parametrize("case", [(1, 3, 4, 5, 8, 6, 8, 10, 4), (2, 2, 4, 4, 16, 5, 9, 8, 8), (1, 4, 4, 4, 64, 8, 8, 8, 64)])
