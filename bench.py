@@ -9,12 +9,17 @@ fused Adam update on one batch of synthetic volumes already resident in HBM
 conf/med3d18.yaml (resnet18segcls), batch 2 per GPU, 1x128x256x256, fp32.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  roofline     -- dominant single kernel of the step (the one with the largest HIP-event time
-                  among the conv kernels; on config 1 the fused in-plane Winograd conv),
-                  ALGORITHMIC (direct-convolution) FLOPs / HIP-event time measured inside the
-                  timed region; `executed_*` prices the MFMA products the kernel really issues
-  cpu_baseline -- the CPU oracle (oracle/med3d_oracle.py, torch CPU ops) on a bounded
-                  sample of the same workload, host cores stated  (N=1, rank 0 only)
+  roofline     -- the kernel family with the largest time share ON THE CONFIG RUN, from the library's own
+                  kernel timeline (hipEvent pairs around every kernel launch, on the launch stream, inside
+                  the timed region): `achieved` = EXECUTED MFMA FLOPs / time for a matrix-bound family
+                  (a Winograd kernel issues fewer products than the direct convolution it replaces; the
+                  ratio is `algorithmic_speedup`, never part of `frac`) or ALGORITHMIC HBM bytes / time
+                  for a bandwidth-bound one; `frac` = achieved / peak <= 1.  `families` holds the same
+                  numbers for every family (>= 99 % of the GPU time of a step), `whole_step` the
+                  step-level executed-MFMA and HBM fractions.
+  cpu_baseline -- the CPU oracle (oracle/med3d_oracle.py, torch CPU ops): 1 warm-up + 2 timed train steps
+                  of one volume of the same shape, host threads stated (N=1, rank 0 only; runs BEFORE the
+                  GPU section)
 """
 import argparse
 import json
@@ -23,46 +28,66 @@ import sys
 import time
 
 import torch
-import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    # id: (factory, per-GPU batch, (D,H,W), train GFLOP per volume [SURVEY.md §8a])
-    0: ("resnet34segcls", 1, (64, 128, 128), 1259.3),
-    1: ("resnet18segcls", 2, (128, 256, 256), 6943.0),
-    2: ("resnet18segreg", 2, (128, 256, 256), 6941.6),
-    3: ("resnet50segreg", 1, (128, 256, 256), 10313.4),
+    # id: (factory, per-GPU batch, (D,H,W), train GFLOP per volume [SURVEY.md §8a], fused-minimum activation
+    #      elements fwd+bwd per volume [SURVEY.md §8a], parameters)
+    0: ("resnet34segcls", 1, (64, 128, 128), 1259.3, (0.233 + 0.256) * 1e9, 64.79e6),
+    1: ("resnet18segcls", 2, (128, 256, 256), 6943.0, (1.561 + 1.747) * 1e9, 34.48e6),
+    2: ("resnet18segreg", 2, (128, 256, 256), 6941.6, (1.554 + 1.732) * 1e9, 34.48e6),
+    3: ("resnet50segreg", 1, (128, 256, 256), 10313.4, (3.458 + 3.838) * 1e9, 47.86e6),
     # configs[4] geometry (full-resolution volume) in fp32 without activation checkpointing: a capacity /
     # int32-offset check of the kernels at 8x the voxels, not a BASELINE metric (that one asks for bf16)
-    4: ("resnet50segreg", 1, (256, 512, 512), 8 * 10313.4),
+    4: ("resnet50segreg", 1, (256, 512, 512), 8 * 10313.4, (27.67 + 30.70) * 1e9, 47.86e6),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters
+PEAK_HBM_GBS = 8000.0           # same guide: HBM3E ~8 TB/s
 
-
-# profiler span -> (kernel description, key in profiles/r01_pmc_hbm_traffic.json,
-#                   algorithmic MACs / executed MFMA MACs)
-ROOFLINE_KERNELS = {
-    "conv_wino2d_kernel": ("conv_wino2d_kernel<NJ> (fused in-plane Winograd F(2x2,3x3) x direct-z conv, fwd + dgrad, "
-                           "fp32 MFMA 32x32x2)", "conv_wino2d", 54.0 / 24.0),
-    "conv_igemm_kernel": ("conv_igemm*_kernel family (direct implicit-GEMM conv fwd + dgrad, fp32 MFMA 32x32x2)",
-                          "conv_igemm", 1.0),
+FAMILY_DESC = {
+    "conv_wino2d": "conv_wino2d_kernel<NJ,..> (fused in-plane Winograd F(2x2,3x3) x direct-z conv, fwd + dgrad, fp32 MFMA 32x32x2)",
+    "wino_in": "wino_in*_kernel (3-D Winograd input / gradient tile transforms)",
+    "wino_gemm_nn": "wino_gemm_nn_kernel<NJ> (Winograd-domain batched GEMM fwd + dgrad, 1x1x1 GEMMs; fp32 MFMA 32x32x2)",
+    "wino_out": "wino_out_kernel (3-D Winograd output transform + bias / shortcut-gradient / BN-statistics epilogue)",
+    "wino_gemm_tn": "wino_gemm_tn_kernel (Winograd-domain weight-gradient GEMM, fp32 MFMA)",
+    "wino_wgrad_out": "wino_wgrad_out_kernel / slab_sum (slab sum + G^T dU G)",
+    "weight_pack": "weight packing / Winograd weight transforms",
+    "conv_wgrad_w2d": "conv_wgrad_w2d_kernel + reduce (in-plane Winograd weight gradient, fp32 MFMA)",
+    "conv_igemm": "conv_igemm*_kernel (direct implicit-GEMM conv fwd + dgrad, fp32 MFMA 32x32x2)",
+    "conv_wgrad": "conv_wgrad*_kernel + reduce (direct weight gradient, fp32 MFMA)",
+    "stem": "stem_fwd_kernel / stem_wgrad_kernel (7x7x7 stride-2 conv, C_in = 1, fp32 MFMA)",
+    "bn_elementwise": "BN statistics folds, BN-apply(+residual+ReLU), BN backward reduce / apply, add",
+    "pool_up": "max-pool fwd/bwd, trilinear upsample + concat fwd/bwd, up-projection",
+    "head_loss": "1x1x1 heads + pooled scores, dRAM loss kernels",
+    "optim": "adam_multi / sgd_multi (fused multi-tensor optimizer)",
+    "prep": "input transforms",
 }
+# family -> key in profiles/r*_pmc_hbm_traffic.json
+TRAFFIC_KEY = {"conv_wino2d": "conv_wino2d", "wino_in": "wino_in", "wino_gemm_nn": "wino_gemm_nn",
+               "wino_out": "wino_out", "wino_gemm_tn": "wino_gemm_tn", "conv_wgrad_w2d": "conv_wgrad_w2d",
+               "conv_igemm": "conv_igemm", "bn_elementwise": "bn_elementwise", "stem": "stem"}
 
 
-def measured_traffic(key):
-    """HBM bytes per launch of the roofline kernel from rocprofv3 PMC passes (FETCH_SIZE x2
-    gfx950 correction + WRITE_SIZE, separate passes), recorded offline for this exact command
-    (config 1) in profiles/r01_pmc_hbm_traffic.json (tools/profile_round.sh) -- PMC counters
-    cannot be read from inside bench.py."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            return float(json.load(f)[key]["total"])
-    except Exception:  # noqa: BLE001
-        return None
+def measured_traffic():
+    """HBM bytes per launch per family from the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
+    runs, guide's gfx950 corrections; tools/profile_round.sh + tools/summarize_profile.py), recorded for
+    config 1.  PMC counters cannot be read from inside bench.py, so the file carries the fingerprint of the
+    kernel sources it was measured on and is IGNORED (traffic = null) when the sources differ."""
+    import glob
+    from bodyct_dram_emph_subtype_amd import _build
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except Exception:  # noqa: BLE001
+            continue
+        if d.get("source_hash") == _build.source_hash():
+            return d, os.path.relpath(path, ROOT)
+    return None, None
 
 
 def synth_batch(B, dims, rank, device):
@@ -84,6 +109,7 @@ def synth_batch(B, dims, rank, device):
 
 
 def make_step(factory, module, opt, batch):
+    from bodyct_dram_emph_subtype_amd.models import cls_train_loss, reg_train_loss
     image, lung, em, cle, pse = batch
     if factory.endswith("cls"):
         cw = torch.full((6,), 1.0 / 6, device=image.device)
@@ -92,13 +118,11 @@ def make_step(factory, module, opt, batch):
         def step():
             opt.zero_grad(set_to_none=True)
             _, outs = module(image, lung)
-            # models.py:253-258 -- class-weighted CE on [B,6] and [B,3] (K16: torch glue)
-            loss = F.cross_entropy(outs[0], cle, weight=cw) + F.cross_entropy(outs[1], pse, weight=pw)
+            loss, _ = cls_train_loss(outs, cle, pse, cw, pw)     # models.py:253-258 (K16: torch glue)
             loss.backward()
             opt.step()
             return loss
         return step
-    from bodyct_dram_emph_subtype_amd.models import reg_train_loss
     B = image.shape[0]
     cwt = torch.full((B,), 1.0 / 6, device=image.device)
     pwt = torch.full((B,), 1.0 / 3, device=image.device)
@@ -113,12 +137,12 @@ def make_step(factory, module, opt, batch):
     return step
 
 
-def cpu_baseline(factory):
-    """Oracle train step (fwd + loss + bwd + Adam) on the host cores, bounded sample."""
+def cpu_baseline(factory, dims):
+    """Oracle train steps (fwd + loss + bwd + Adam) on the host cores: 1 warm-up + 2 timed steps of ONE
+    volume of the benchmarked shape (BASELINE.md §3 plan).  Bounded: dims are capped at 128x256x256."""
     from oracle import med3d_oracle as orc
     from bodyct_dram_emph_subtype_amd import med3d
-    dims = (64, 256, 256)          # half of one 128x256x256 volume's voxels, batch 1
-    frac = 0.5
+    dims = tuple(min(a, b) for a, b in zip(dims, (128, 256, 256)))
     torch.manual_seed(0)
     kw = dict(n_classes=[6, 3]) if factory.endswith("cls") else {}
     m = getattr(med3d, factory)(**kw)
@@ -127,47 +151,88 @@ def cpu_baseline(factory):
     image, lung, em, cle, pse = synth_batch(1, dims, 0, "cpu")
     mom = {n: (torch.zeros_like(sd[n]), torch.zeros_like(sd[n])) for n in names}
     cores = torch.get_num_threads()
-    t0 = time.perf_counter()
-    leaves = {k: (v.requires_grad_(True) if k in names else v) for k, v in sd.items()}
-    dense, outs = orc.forward(leaves, image, lung, factory, train=True)
-    if factory.endswith("cls"):
-        loss, _ = orc.cls_train_loss(outs, cle, pse, torch.full((6,), 1 / 6), torch.full((3,), 1 / 3))
-    else:
-        loss, _ = orc.reg_train_loss(dense, outs, lung, em, cle, pse, torch.full((1,), 1 / 6), torch.full((1,), 1 / 3))
-    loss.backward()
-    with torch.no_grad():
-        for n in names:
-            orc.adam_step(leaves[n], leaves[n].grad, mom[n][0], mom[n][1], 1, 1e-4)
-    dt = time.perf_counter() - t0
-    return {"value": frac / dt, "unit": "volumes/sec", "cores": cores, "kind": "port",
-            "sample": f"1 train step of {factory} (oracle, torch CPU ops) on 1x1x{dims[0]}x{dims[1]}x{dims[2]} "
-                      f"= {frac} volume of 128x256x256, {dt:.1f} s, scaled by voxel count"}
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        leaves = {k: (v.detach().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+        dense, outs = orc.forward(leaves, image, lung, factory, train=True)
+        if factory.endswith("cls"):
+            loss, _ = orc.cls_train_loss(outs, cle, pse, torch.full((6,), 1 / 6), torch.full((3,), 1 / 3))
+        else:
+            loss, _ = orc.reg_train_loss(dense, outs, lung, em, cle, pse, torch.full((1,), 1 / 6), torch.full((1,), 1 / 3))
+        loss.backward()
+        with torch.no_grad():
+            for n in names:
+                p = leaves[n].detach()
+                orc.adam_step(p, leaves[n].grad, mom[n][0], mom[n][1], it + 1, 1e-4)
+                sd[n] = p
+        times.append(time.perf_counter() - t0)
+    dt = (times[1] + times[2]) / 2
+    return {"value": 1.0 / dt, "unit": "volumes/sec", "cores": cores, "kind": "port",
+            "sample": f"{factory} train step (oracle, torch CPU ops, fwd+loss+bwd+Adam), batch 1 of "
+                      f"1x{dims[0]}x{dims[1]}x{dims[2]}: 1 warm-up ({times[0]:.1f} s) + 2 timed steps "
+                      f"({times[1]:.1f} s, {times[2]:.1f} s), {cores} host threads"}
+
+
+def family_table(fams, steps, step_s):
+    """Per-family roofline rows from the kernel timeline (sums over `steps` steps)."""
+    rows = {}
+    for name, f in fams.items():
+        sec = f["ms"] / 1e3
+        if sec <= 0:
+            continue
+        row = {"bound": f["bound"], "ms_per_step": f["ms"] / steps, "launches_per_step": f["launches"] / steps,
+               "avg_launch_ms": f["ms"] / f["launches"], "step_time_share": sec / (step_s * steps)}
+        if f["bound"] == "mfma":
+            row["achieved"] = f["mfma_flops"] / sec / 1e12
+            row["peak"], row["unit"] = PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
+            row["algorithmic_speedup"] = f["alg_flops"] / f["mfma_flops"] if f["mfma_flops"] > 0 else 1.0
+            row["hbm_gbs_algorithmic"] = f["hbm_bytes"] / sec / 1e9
+        else:
+            row["achieved"] = f["hbm_bytes"] / sec / 1e9
+            row["peak"], row["unit"] = PEAK_HBM_GBS, "GB/s"
+        row["frac"] = row["achieved"] / row["peak"]
+        row["algorithmic_bytes_per_launch"] = f["hbm_bytes"] / f["launches"]
+        rows[name] = row
+    return rows
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)
-    ap.add_argument("--detail", type=str, default="", help="write a per-launch-geometry timing table to this file")
+    ap.add_argument("--detail", type=str, default="", help="write a per-convolution-call timing table to this file")
+    ap.add_argument("--timeline", choices=("in", "off"), default="in",
+                    help="'in': kernel timeline recorded inside the timed region (roofline table); 'off': none")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="keep the data-parallel collectives (RCCL) in place at world size 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    factory, B, dims, gflop_per_vol, act_elems, nparams = CONFIGS[args.config]
+
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(factory, dims)          # first: the GPU burst below is then the tail of the run
+
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import bodyct_dram_emph_subtype_amd as dram
@@ -175,13 +240,13 @@ def main():
     from bodyct_dram_emph_subtype_amd.optim import FusedAdam
     dram.load_library()
 
-    factory, B, dims, gflop_per_vol = CONFIGS[args.config]
     torch.manual_seed(0)
     kw = dict(n_classes=[6, 3]) if factory.endswith("cls") else {}
     module = getattr(med3d, factory)(**kw).to(device).train()
-    if world > 1:
+    dctx = None
+    if use_dist:
         from bodyct_dram_emph_subtype_amd import distributed as ddist
-        ddist.attach(module)
+        dctx = ddist.attach(module, force=args.force_dist)
     opt = FusedAdam(module.parameters(), lr=args.lr)
     batch = synth_batch(B, dims, rank, device)
     step = make_step(factory, module, opt, batch)
@@ -194,20 +259,26 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    prof = ops.KernelProfiler()
-    ops.set_profiler(prof)
+    timeline = ops.KernelTimeline(max_records=max(4096, 2048 * args.steps)) if (args.timeline == "in" and rank == 0) else None
+    prof = None
+    if args.detail and rank == 0:
+        prof = ops.KernelProfiler()
+        ops.set_profiler(prof)
+    if timeline:
+        timeline.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
+    if timeline:
+        timeline.stop()
     ops.set_profiler(None)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    summ = prof.summary()
-    if rank == 0 and args.detail:
+    if rank == 0 and prof is not None:
         rows = sorted(prof.by_launch().items(), key=lambda kv: -kv[1]["ms"])
         with open(args.detail, "w") as f:
             for (fam, det), v in rows:
@@ -215,18 +286,15 @@ def main():
                 f.write(f"{v['ms'] / args.steps:9.3f} ms/step  {v['launches'] // args.steps:3d}x  {tf:7.1f} TF  {fam}  {det}\n")
     if rank == 0:
         vols = args.steps * B * world
-        fam = max(ROOFLINE_KERNELS, key=lambda k: summ.get(k, {}).get("ms", 0.0))
-        kdesc, tkey, ratio = ROOFLINE_KERNELS[fam]
-        s = summ.get(fam, dict(launches=0, ms=0.0, flops=0.0))
-        achieved = (s["flops"] / 1e12) / (s["ms"] / 1e3) if s["ms"] > 0 else 0.0
+        step_s = dt / args.steps
         out = {
-            "metric": "CT volumes/sec (train step, 1x128x256x256)",
+            "metric": f"CT volumes/sec (train step, 1x{dims[0]}x{dims[1]}x{dims[2]})",
             "value": vols / dt,
             "unit": "volumes/sec",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step": 1e3 * step_s,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -238,29 +306,53 @@ def main():
                        "train_gflop_per_volume": gflop_per_vol},
             "loss": float(loss.detach()),
             "peak_hbm_gb": torch.cuda.max_memory_allocated(device) / 1e9,
-            "roofline": {
-                "kernel": kdesc,
-                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "note": "achieved = algorithmic (direct-convolution) FLOPs / time; a Winograd kernel executes "
-                        "fewer MFMA products than that, so frac may exceed 1 -- executed_* is the matrix-pipe view",
-                "algorithmic_over_executed_flops": ratio,
-                "executed_tflops": achieved / ratio, "executed_frac": achieved / ratio / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": measured_traffic(tkey) if args.config == 1 else None,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.json)",
-                "launches_per_step": s["launches"] / max(args.steps, 1),
-                "avg_launch_ms": s["ms"] / max(s["launches"], 1),
-                "step_time_share": (s["ms"] / 1e3) / dt if dt > 0 else 0.0,
-                "whole_step_tflops": gflop_per_vol * vols / world / dt / 1e3,
-                "families": {k: {"ms_per_step": v["ms"] / args.steps,
-                                 "tflops": (v["flops"] / 1e12) / (v["ms"] / 1e3) if v["ms"] > 0 else 0.0}
-                             for k, v in summ.items()},
-            },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(factory)
+        if dctx is not None:
+            out["collectives_per_step"] = {k: v / (args.steps + args.warmup) for k, v in dctx.stats.items()}
+        if timeline:
+            fams = timeline.families()
+            rows = family_table(fams, args.steps, step_s)
+            traffic, tsrc = measured_traffic() if args.config == 1 else (None, None)
+            for name, row in rows.items():
+                key = TRAFFIC_KEY.get(name)
+                row["traffic"] = float(traffic[key]["total"]) if (traffic and key in traffic) else None
+            head = max(rows, key=lambda k: rows[k]["ms_per_step"])
+            h = rows[head]
+            kernel_ms = sum(r["ms_per_step"] for r in rows.values())
+            mfma = sum(f["mfma_flops"] for f in fams.values())
+            hbm = sum(f["hbm_bytes"] for f in fams.values())
+            whole = {
+                "kernel_ms_per_step": kernel_ms, "timeline_coverage_of_step": kernel_ms / (1e3 * step_s),
+                "executed_mfma_tflops": mfma / dt / 1e12, "executed_mfma_frac": mfma / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                "algorithmic_tflops": gflop_per_vol * vols / world / dt / 1e3,
+                "hbm_gbs_algorithmic": hbm / dt / 1e9, "hbm_frac_algorithmic": hbm / dt / 1e9 / PEAK_HBM_GBS,
+                # SURVEY.md §8d whole-step figure: fused-minimum activation traffic + 28 B/param
+                "hbm_gbs_fused_minimum": (act_elems * 4 * B + 28 * nparams) / step_s / 1e9,
+                "hbm_gbs_measured": (traffic["_step_total_bytes"] / step_s / 1e9) if traffic and "_step_total_bytes" in traffic else None,
+                "timeline_records_dropped": timeline.dropped,
+            }
+            if whole["hbm_gbs_measured"] is not None:
+                whole["hbm_frac_measured"] = whole["hbm_gbs_measured"] / PEAK_HBM_GBS
+            out["roofline"] = {
+                "kernel": FAMILY_DESC.get(head, head), "family": head,
+                "bound": h["bound"], "achieved": h["achieved"], "peak": h["peak"], "unit": h["unit"],
+                "frac": h["frac"], "traffic": h["traffic"],
+                "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                "traffic_source": tsrc,
+                "algorithmic_bytes_per_launch": h["algorithmic_bytes_per_launch"],
+                "algorithmic_speedup": h.get("algorithmic_speedup"),
+                "launches_per_step": h["launches_per_step"], "avg_launch_ms": h["avg_launch_ms"],
+                "step_time_share": h["step_time_share"],
+                "note": "achieved = EXECUTED MFMA FLOPs / time (mfma-bound) or ALGORITHMIC HBM bytes / time (hbm-bound) "
+                        "from hipEvent pairs around every kernel launch inside the timed region; algorithmic_speedup = "
+                        "direct-convolution FLOPs / executed FLOPs (Winograd), never part of frac",
+                "families": rows,
+                "whole_step": whole,
+            }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -6,6 +6,7 @@ built library travels with the source tree (nothing is installed anywhere).
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -33,25 +34,69 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _newest_header() -> float:
-    hs = [os.path.join(INCLUDE, "dram_hip.h"), os.path.join(CSRC, "common.h")]
-    return max(os.path.getmtime(h) for h in hs)
+def _read(path: str) -> bytes:
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def abi_hash() -> str:
+    """Fingerprint of the C ABI = sha1 of include/dram_hip.h.  Compiled into the library
+    (dram_abi_hash()) and compared by _lib.load(): a library built from another header is
+    refused instead of being called with shifted arguments."""
+    return hashlib.sha1(_read(os.path.join(INCLUDE, "dram_hip.h"))).hexdigest()[:16]
+
+
+def source_hash() -> str:
+    """Fingerprint of everything the library is compiled from (kernels + headers)."""
+    h = hashlib.sha1()
+    for f in [os.path.join(INCLUDE, "dram_hip.h")] + [os.path.join(CSRC, s) for s in sorted(os.listdir(CSRC))
+                                                      if s.endswith((".hip", ".h"))]:
+        h.update(os.path.basename(f).encode())
+        h.update(_read(f))
+    return h.hexdigest()[:16]
+
+
+def _flags():
+    return ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", f'-DDRAM_ABI_HASH="{abi_hash()}"',
+            "-I", INCLUDE, "-I", CSRC]
+
+
+def have_hipcc() -> bool:
+    try:
+        _hipcc()
+        return True
+    except RuntimeError:
+        return False
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Incremental by CONTENT (not mtime: the tree is copied to the GPU box): an object is
+    rebuilt when the sha1 of its source + every header + the flags differs from the key
+    stored beside it, the library is relinked when any object key changed."""
     os.makedirs(BUILD, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
+    import fcntl
+    with open(os.path.join(BUILD, ".lock"), "w") as lock:     # ranks of one job may all get here at once
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build_locked(force, verbose)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     hipcc = _hipcc()
-    hdr = _newest_header()
-    jobs = []
-    objs = []
+    flags = _flags()
+    hdrs = b"".join(_read(os.path.join(d, f)) for d in (INCLUDE, CSRC) for f in sorted(os.listdir(d))
+                    if f.endswith(".h"))
+    jobs, objs, keys = [], [], []
     for src in _sources():
         s = os.path.join(CSRC, src)
         o = os.path.join(BUILD, src[:-4] + ".o")
+        key = hashlib.sha1(_read(s) + hdrs + " ".join(flags).encode()).hexdigest()
+        kf = o + ".key"
         objs.append(o)
-        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr):
-            jobs.append([hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-I", INCLUDE, "-I", CSRC,
-                         "-c", s, "-o", o])
+        keys.append(key)
+        old = _read(kf).decode() if os.path.exists(kf) else ""
+        if force or not os.path.exists(o) or old != key:
+            jobs.append((key, kf, [hipcc] + flags + ["-c", s, "-o", o]))
 
     def run(cmd):
         if verbose:
@@ -60,13 +105,26 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
 
+    def compile_one(job):
+        key, kf, cmd = job
+        if os.path.exists(kf):
+            os.remove(kf)
+        run(cmd)
+        with open(kf, "w") as f:
+            f.write(key)
+
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
-            list(ex.map(run, jobs))
-    need_link = force or bool(jobs) or not os.path.exists(LIB_PATH) or \
-        any(os.path.getmtime(o) > os.path.getmtime(LIB_PATH) for o in objs)
-    if need_link:
+            list(ex.map(compile_one, jobs))
+    link_key = hashlib.sha1("".join(keys).encode()).hexdigest()
+    lk = LIB_PATH + ".key"
+    old = _read(lk).decode() if os.path.exists(lk) else ""
+    if force or bool(jobs) or not os.path.exists(LIB_PATH) or old != link_key:
+        if os.path.exists(lk):
+            os.remove(lk)
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs)
+        with open(lk, "w") as f:
+            f.write(link_key)
     return LIB_PATH
 
 

@@ -27,6 +27,11 @@ class DramTensorRef(ctypes.Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", ctypes.c_int64)]
 
 
+class DramProfRecord(ctypes.Structure):
+    _fields_ = [("family", ctypes.c_int32), ("variant", ctypes.c_int32), ("mfma_flops", c_double),
+                ("alg_flops", c_double), ("hbm_bytes", c_double), ("ms", c_float), ("pad_", c_float)]
+
+
 class DramChunkRef(ctypes.Structure):
     _fields_ = [("tensor", ctypes.c_int32), ("pad", ctypes.c_int32), ("offset", ctypes.c_int64)]
 
@@ -37,6 +42,13 @@ DP = ctypes.POINTER(DramConvDesc)
 SIGNATURES = {
     "dram_version": (I, []),
     "dram_build_info": (c_char_p, []),
+    "dram_abi_hash": (c_char_p, []),
+    "dram_profile_family_name": (c_char_p, [I]),
+    "dram_profile_family_is_mfma": (I, [I]),
+    "dram_profile_start": (I, [I]),
+    "dram_profile_stop": (I, []),
+    "dram_profile_dropped": (I, []),
+    "dram_profile_read": (I, [P, I]),
     "dram_pack_conv_weight": (I, [P, P, P, I, I, I, P]),
     "dram_conv3d_fwd": (I, [P, P, P, P, P, DP, P]),
     "dram_conv3d_bwd_data": (I, [P, P, P, P, P, DP, P]),
@@ -74,13 +86,13 @@ SIGNATURES = {
     "dram_stem_bwd_weight_workspace": (SZ, [I, I, I, I]),
     "dram_stem_bwd_weight": (I, [P, P, P, I, I, I, I, P, SZ, P]),
     "dram_reduce_partials_stages": (I, [I]),
-    "dram_reduce_partials": (I, [P, P, P, I, I, I, P]),
-    "dram_bn_finalize": (I, [P, D, P, P, P, P, F, F, I, P, P, P, P, I, P]),
+    "dram_reduce_partials": (I, [P, P, P, I, I, I, D, I, P]),
+    "dram_bn_finalize": (I, [P, D, P, P, P, P, P, F, F, I, P, P, P, P, I, P]),
     "dram_bn_apply": (I, [P, P, P, P, I, I, I, I, I, P, I, I, I, I, I, I, P]),
     "dram_colsum_nparts": (I, [LL, I]),
     "dram_bn_bwd_reduce": (I, [P, P, P, P, P, P, P, P, LL, I, I, P]),
     "dram_bn_bwd_apply_nparts": (I, [LL, I]),
-    "dram_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, D, P, P, LL, I, I, P]),
+    "dram_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, D, P, P, P, LL, I, I, P]),
     "dram_colsum": (I, [P, P, LL, I, P]),
     "dram_maxpool_fwd": (I, [P, P, P, I, I, I, I, I, P]),
     "dram_maxpool_bwd": (I, [P, P, P, I, P, I, I, I, I, I, P]),
@@ -105,6 +117,7 @@ SIGNATURES = {
 }
 
 OPT_CHUNK = 16384
+ABI_VERSION = 2
 _LIB = None
 
 
@@ -112,22 +125,29 @@ def lib_path() -> str:
     return _build.LIB_PATH
 
 
-def load(build_if_missing: bool = True) -> ctypes.CDLL:
-    """Load (building first when the .so is absent and hipcc is present)."""
+def load(build: bool = True) -> ctypes.CDLL:
+    """Load libdram_hip.so.  With hipcc present the (content-hash incremental) build runs first,
+    so a library older than the sources is never loaded; either way the library must carry the
+    fingerprint of THIS include/dram_hip.h -- a stale build would be called with shifted
+    arguments (wild device writes), so it is refused."""
     global _LIB
     if _LIB is not None:
         return _LIB
     path = lib_path()
-    if not os.path.exists(path):
-        if not build_if_missing:
-            raise RuntimeError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    if build and _build.have_hipcc():
         _build.build_library()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.dram_version() != 1:
+    if lib.dram_version() != ABI_VERSION:
         raise RuntimeError("libdram_hip.so ABI version mismatch")
+    got, want = lib.dram_abi_hash().decode(), _build.abi_hash()
+    if got != want:
+        raise RuntimeError(f"libdram_hip.so was built from another include/dram_hip.h (library {got}, header {want}): "
+                           "rebuild with __graft_entry__.build()")
     _LIB = lib
     return lib

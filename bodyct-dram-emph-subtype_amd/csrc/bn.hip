@@ -16,7 +16,7 @@ namespace {
 // stage 2 (same kernel, double input, S = 1) folds the S rows.  Fixed order -> deterministic.
 template <typename T>
 __global__ void reduce_partials_kernel(const T* __restrict__ partial, double* __restrict__ out, int nparts,
-                                       int RC) {
+                                       int RC, double tail, int has_tail) {
   __shared__ double sm[256];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int lane4 = threadIdx.x >> 6;  // 0..3
@@ -28,9 +28,12 @@ __global__ void reduce_partials_kernel(const T* __restrict__ partial, double* __
   __syncthreads();
   if (lane4 == 0 && col < RC)
     out[(long)sidx * RC + col] = sm[threadIdx.x] + sm[threadIdx.x + 64] + sm[threadIdx.x + 128] + sm[threadIdx.x + 192];
+  // SyncBN: the rank's element count rides behind the sums, so ONE all-reduce yields global sums and count
+  if (has_tail && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) out[RC] = tail;
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count_host,
+                                   const double* __restrict__ count_dev, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ rmean,
                                    float* __restrict__ rvar, float momentum, float eps, int update,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
@@ -38,6 +41,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double m, v;
+  const double count = count_dev ? *count_dev : count_host;
   if (sums) {
     m = sums[c] / count;
     v = sums[C + c] / count - m * m;
@@ -185,10 +189,12 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 __global__ void bn_bwd_apply_kernel(const float4* __restrict__ dz, const float4* __restrict__ z,
                                     const float4* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                    const double* __restrict__ sums, double inv_count, float4* __restrict__ dy, int C,
+                                    const double* __restrict__ sums, double inv_count_host,
+                                    const double* __restrict__ count_dev, float4* __restrict__ dy, int C,
                                     long total4, int relu, const float* __restrict__ scale,
                                     const float* __restrict__ shift, float* __restrict__ colpart) {
   const int Q = C >> 2;
+  const double inv_count = count_dev ? 1.0 / *count_dev : inv_count_host;
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // colpart: this thread's channel quad is fixed (256 % Q == 0)
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const int c = 4 * (int)(i % Q);
@@ -271,36 +277,39 @@ extern "C" int dram_reduce_partials_stages(int nparts) {
 }
 
 extern "C" int dram_reduce_partials(const float* partial, double* sums, double* scratch, int nparts, int R, int C,
-                                    dram_stream_t stream) {
+                                    double tail, int has_tail, dram_stream_t stream) {
   if (!partial || !sums || nparts < 1 || R < 1 || C < 1) return DRAM_ERR_BAD_ARG;
   const int RC = R * C;
   const int S = dram_reduce_partials_stages(nparts);
   hipStream_t st = (hipStream_t)stream;
+  DramProf prof(DRAM_FAM_BN, 0, 0.0, 4.0 * (double)nparts * RC + 8.0 * RC, st);
   if (S == 1) {
     hipLaunchKernelGGL((reduce_partials_kernel<float>), dim3((RC + 63) / 64, 1), dim3(256), 0, st, partial, sums,
-                       nparts, RC);
+                       nparts, RC, tail, has_tail);
   } else {
     if (!scratch) return DRAM_ERR_WORKSPACE;
     hipLaunchKernelGGL((reduce_partials_kernel<float>), dim3((RC + 63) / 64, S), dim3(256), 0, st, partial, scratch,
-                       nparts, RC);
+                       nparts, RC, 0.0, 0);
     DRAM_LAUNCH_CHECK();
     hipLaunchKernelGGL((reduce_partials_kernel<double>), dim3((RC + 63) / 64, 1), dim3(256), 0, st,
-                       (const double*)scratch, sums, S, RC);
+                       (const double*)scratch, sums, S, RC, tail, has_tail);
   }
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
 
-extern "C" int dram_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+extern "C" int dram_bn_finalize(const double* sums, double count, const double* count_dev, const float* gamma,
+                                const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps,
                                 int update_running, float* mean, float* invstd, float* scale, float* shift, int C,
                                 dram_stream_t stream) {
   if (!gamma || !beta || !mean || !invstd || !scale || !shift || C < 1) return DRAM_ERR_BAD_ARG;
   if (!sums && (!running_mean || !running_var)) return DRAM_ERR_BAD_ARG;
-  if (sums && count <= 0.0) return DRAM_ERR_BAD_ARG;
+  if (sums && !count_dev && count <= 0.0) return DRAM_ERR_BAD_ARG;
   if (update_running && (!running_mean || !running_var)) return DRAM_ERR_BAD_ARG;
+  DramProf prof(DRAM_FAM_BN, 1, 0.0, 4.0 * 10.0 * C, (hipStream_t)stream);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count,
-                     gamma, beta, running_mean, running_var, momentum, eps, update_running, mean, invstd, scale,
+                     count_dev, gamma, beta, running_mean, running_var, momentum, eps, update_running, mean, invstd, scale,
                      shift, C);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
@@ -313,6 +322,9 @@ extern "C" int dram_bn_apply(const float* y, const float* scale, const float* sh
   const long total4 = (long)B * D * H * W * (C >> 2);
   hipStream_t s = (hipStream_t)stream;
   const int grid = ew_grid(total4);
+  // y read, z written, residual read (identity: full size; shortcut A: 1/rs^3 of Cr/C of it)
+  const double res_frac = !residual ? 0.0 : ((double)Cr / C) / ((double)rs * rs * rs);
+  DramProf prof(DRAM_FAM_BN, 2, 0.0, 16.0 * (double)total4 * (2.0 + res_frac), s);
   if (!residual) {
     hipLaunchKernelGGL((bn_apply_kernel<0>), dim3(grid), dim3(256), 0, s, (const float4*)y, scale, shift, nullptr, 0,
                        1, (float4*)z, D, H, W, C, total4, relu);
@@ -343,6 +355,7 @@ extern "C" int dram_bn_bwd_reduce(const float* dz, const float* z, const float* 
   if (relu && !z && !(scale && shift)) return DRAM_ERR_BAD_ARG;
   const int rpb = rows_per_block(rows);
   const int nparts = (int)((rows + rpb - 1) / rpb);
+  DramProf prof(DRAM_FAM_BN, 3, 0.0, 4.0 * (double)rows * C * (relu && z ? 3.0 : 2.0), (hipStream_t)stream);
   hipLaunchKernelGGL((colreduce_kernel<1>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, z, y, mean, invstd,
                      partial, (long)rows, C, rpb, relu, scale, shift);
   DRAM_LAUNCH_CHECK();
@@ -353,6 +366,7 @@ extern "C" int dram_colsum(const float* a, float* partial, long long rows, int C
   if (!a || !partial || rows < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
   const int rpb = rows_per_block(rows);
   const int nparts = (int)((rows + rpb - 1) / rpb);
+  DramProf prof(DRAM_FAM_BN, 4, 0.0, 4.0 * (double)rows * C, (hipStream_t)stream);
   hipLaunchKernelGGL((colreduce_kernel<0>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, a, nullptr, nullptr,
                      nullptr, nullptr, partial, (long)rows, C, rpb, 0);
   DRAM_LAUNCH_CHECK();
@@ -369,16 +383,18 @@ extern "C" int dram_bn_bwd_apply_nparts(long long rows, int C) {
 
 extern "C" int dram_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* mean,
                                  const float* invstd, const float* gamma, const float* scale, const float* shift,
-                                 const double* sums, double count, float* dy, float* colsum_partial, long long rows,
-                                 int C, int relu, dram_stream_t stream) {
-  if (!dz || !y || !mean || !invstd || !gamma || !sums || !dy || rows < 1 || C < 4 || (C & 3) || count <= 0.0)
+                                 const double* sums, double count, const double* count_dev, float* dy,
+                                 float* colsum_partial, long long rows, int C, int relu, dram_stream_t stream) {
+  if (!dz || !y || !mean || !invstd || !gamma || !sums || !dy || rows < 1 || C < 4 || (C & 3) ||
+      (!count_dev && count <= 0.0))
     return DRAM_ERR_BAD_ARG;
   if (relu && !z && !(scale && shift)) return DRAM_ERR_BAD_ARG;
   if (colsum_partial && dram_bn_bwd_apply_nparts(rows, C) < 1) return DRAM_ERR_UNSUPPORTED;
   const long total4 = (long)rows * (C >> 2);
+  DramProf prof(DRAM_FAM_BN, 5, 0.0, 16.0 * (double)total4 * (relu && z ? 4.0 : 3.0), (hipStream_t)stream);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream,
-                     (const float4*)dz, (const float4*)z, (const float4*)y, mean, invstd, gamma, sums, 1.0 / count,
-                     (float4*)dy, C, total4, relu, scale, shift, colsum_partial);
+                     (const float4*)dz, (const float4*)z, (const float4*)y, mean, invstd, gamma, sums,
+                     count_dev ? 0.0 : 1.0 / count, count_dev, (float4*)dy, C, total4, relu, scale, shift, colsum_partial);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
@@ -386,6 +402,7 @@ extern "C" int dram_bn_bwd_apply(const float* dz, const float* z, const float* y
 extern "C" int dram_add(const float* a, const float* b, float* out, long long n, dram_stream_t stream) {
   if (!a || !b || !out || n < 1) return DRAM_ERR_BAD_ARG;
   const long n4 = ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0) ? n / 4 : 0;
+  DramProf prof(DRAM_FAM_BN, 6, 0.0, 12.0 * (double)n, (hipStream_t)stream);
   hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n4 > 0 ? n4 : (n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)a, (const float4*)b, (float4*)out, n4, a, b, out, (long)n);
   DRAM_LAUNCH_CHECK();

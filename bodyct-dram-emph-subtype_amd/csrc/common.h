@@ -13,6 +13,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     if (_e != hipSuccess) return (int)_e;           \
   } while (0)
 
+// Kernel timeline (profile.hip): `DramProf p(family, variant, executed MFMA flops, algorithmic HBM bytes,
+// stream);` in front of a launch brackets it with two events when recording is on (one bool test when off).
+extern bool g_dram_prof_on;
+void dram_prof_begin(int family, int variant, double mfma_flops, double hbm_bytes, double alg_flops, hipStream_t s);
+void dram_prof_end(hipStream_t s);
+struct DramProf {
+  const bool on;
+  hipStream_t s;
+  // alg_flops: direct-convolution FLOPs the launch stands for (default: what it executes)
+  DramProf(int family, int variant, double mfma_flops, double hbm_bytes, hipStream_t st, double alg_flops = -1.0)
+      : on(g_dram_prof_on), s(st) {
+    if (on) dram_prof_begin(family, variant, mfma_flops, hbm_bytes, alg_flops < 0.0 ? mfma_flops : alg_flops, st);
+  }
+  ~DramProf() {
+    if (on) dram_prof_end(s);
+  }
+  DramProf(const DramProf&) = delete;
+};
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // XCD-aware bijective remap of the linear workgroup id (8 XCDs, round-robin

@@ -845,10 +845,23 @@ int lds_pad_for_balance(int BN, int nblk) {
   return need > stat ? need - stat : 0;
 }
 
+// timeline tags: executed = algorithmic 2*M*N*K (the strided data gradient touches 1/stride^3 of the taps per
+// voxel); bytes: gathered tensor + written tensor (+ add, gate) + packed weights, once each
+inline double igemm_flops(const IGemmGeom& g, int mode) {
+  const double st3 = mode == 2 ? (double)g.stride * g.stride * g.stride : 1.0;
+  return 2.0 * g.B * g.Do * g.Ho * g.Wo * (double)g.No * g.Ci * g.taps / st3;
+}
+inline double igemm_bytes(const IGemmGeom& g, const float* add, const float* gate) {
+  return 4.0 * ((double)g.B * g.Di * g.Hi * g.Wi * g.Ci +
+                (double)g.B * g.Do * g.Ho * g.Wo * g.No * (1.0 + (add ? 1 : 0) + (gate ? 1 : 0)) +
+                (double)g.taps * g.No * g.Ci);
+}
+
 template <int MODE>
 int launch(int BN, const float* in, const float* wp, const float* bias, float* out, float* stats,
            const float* add, const float* gate, IGemmGeom& g, hipStream_t s) {
   fill_tiles(g, BN);
+  DramProf prof(DRAM_FAM_CONV_IGEMM, 1000 * MODE + BN, igemm_flops(g, MODE), igemm_bytes(g, add, gate), s);
   dim3 grid(g.nblk), block(256);
   const int pad = lds_pad_for_balance(BN, g.nblk);
   const int ver = igemm_version();   // 0 = auto: LDS-DMA kernel for BN <= 64, register-staged for BN = 128
@@ -888,6 +901,7 @@ int launch3(const V3Plan& p, const float* in, const float* wp, const float* bias
             const float* add, const float* gate, IGemmGeom& g, hipStream_t s) {
   fill_tiles(g, p.bn, p.tz3);
   dim3 grid(g.nblk), block(512);
+  DramProf prof(DRAM_FAM_CONV_IGEMM, 3000 + 1000 * MODE + p.bn, igemm_flops(g, MODE), igemm_bytes(g, add, gate), s);
 #define IG3(NJ_, TZ_) \
   hipLaunchKernelGGL((conv_igemm3_kernel<NJ_, MODE, TZ_>), grid, block, 0, s, in, wp, bias, out, stats, add, gate, g)
   if (p.tz3 == 8 && p.bn == 64) IG3(2, 8);
@@ -989,6 +1003,7 @@ extern "C" int dram_pack_conv_weight(const float* w, float* wf, float* wb, int C
   if (!w || (!wf && !wb) || Cout < 1 || Cin < 1 || taps < 1) return DRAM_ERR_BAD_ARG;
   const long n = (long)Cout * Cin * taps;
   const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  DramProf prof(DRAM_FAM_WEIGHT_PACK, 0, 0.0, 4.0 * (double)n * (1.0 + (wf ? 1 : 0) + (wb ? 1 : 0)), (hipStream_t)stream);
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wf, wb, Cout, Cin, taps);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;

@@ -459,6 +459,10 @@ extern "C" int dram_conv3d_bwd_weight(const float* x, const float* dy, float* dw
       if (!workspace || workspace_bytes < need2) return DRAM_ERR_WORKSPACE;
       hipStream_t s2 = (hipStream_t)stream;
       const int pairs = g2.ci_tiles * (d->Cout / 32);
+      // one timeline record for kernel + slab reduce: 2*M*N*K executed; x, dy read once, dw written once
+      DramProf prof(DRAM_FAM_CONV_WGRAD, 2, 2.0 * d->B * d->Do * d->Ho * d->Wo * (double)d->Cout * d->Cin * 27.0,
+                    4.0 * ((double)d->B * d->D * d->H * d->W * d->Cin + (double)d->B * d->Do * d->Ho * d->Wo * d->Cout +
+                           27.0 * d->Cout * d->Cin), s2);
       hipLaunchKernelGGL(conv_wgrad2_kernel, dim3(pairs * g2.nslab), dim3(512), 0, s2, x, dy, (float*)workspace, g2);
       DRAM_LAUNCH_CHECK();
       const long per2 = (long)27 * d->Cout * d->Cin;
@@ -476,6 +480,10 @@ extern "C" int dram_conv3d_bwd_weight(const float* x, const float* dy, float* dw
   float* slab = (float*)workspace;
   dim3 grid(p.nblk);
   const bool narrow = (p.cow == 1);
+  DramProf prof(DRAM_FAM_CONV_WGRAD, 10 + p.variant,
+                2.0 * d->B * d->Do * d->Ho * d->Wo * (double)d->Cout * d->Cin * d->k * d->k * d->k,
+                4.0 * ((double)d->B * d->D * d->H * d->W * d->Cin + (double)d->B * d->Do * d->Ho * d->Wo * d->Cout +
+                       (double)d->k * d->k * d->k * d->Cout * d->Cin), s);
 #define WG_LAUNCH(S_, D_, K3_)                                                                              \
   do {                                                                                                      \
     if (narrow)                                                                                             \

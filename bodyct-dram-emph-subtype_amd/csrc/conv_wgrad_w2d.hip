@@ -291,6 +291,10 @@ extern "C" int dram_wgrad_w2d(const float* x, const float* dy, float* dw, const 
   if (!workspace || workspace_bytes < need) return DRAM_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int pairs = g.ci_tiles * (d->Cout / 32);
+  // kernel + slab reduce in one record; executed: 48 products per 2x2 in-plane tile and channel pair = 12 / voxel
+  const double vox = (double)d->B * d->D * d->H * d->W;
+  DramProf prof(DRAM_FAM_WGRAD_W2D, 0, 2.0 * vox * d->Cout * d->Cin * 12.0,
+                4.0 * (vox * (d->Cin + d->Cout) + 27.0 * d->Cout * d->Cin), s, 2.0 * vox * d->Cout * d->Cin * 27.0);
   hipLaunchKernelGGL(conv_wgrad_w2d_kernel, dim3(pairs * g.nslab), dim3(512), 0, s, x, dy, (float*)workspace, g);
   DRAM_LAUNCH_CHECK();
   const long n = (long)d->Cout * d->Cin;

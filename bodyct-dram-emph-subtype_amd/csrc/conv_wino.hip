@@ -1368,6 +1368,10 @@ int grid_for(long waves) {
 template <int MODE>
 int launch_wino_in(const float* src, float* dst, const WinoGeom& g, const int C, const int math, hipStream_t s) {
   const long units = (long)g.Tpad * (C / 64);
+  // algorithmic bytes: the activation read once + the Winograd-domain image written once
+  const double in_elems = (double)g.B * g.D * g.H * g.W * C;
+  DramProf prof(DRAM_FAM_WINO_IN, MODE * 1000 + g.nz * 100 + g.ny * 10 + g.nx, 0.0,
+                4.0 * (in_elems + (double)g.npts * g.Tpad * C), s);
   static const int half = getenv("DRAM_WINO_HALF") ? atoi(getenv("DRAM_WINO_HALF")) : 1;   // A/B switch (tools)
   if (half && g.nz == 4 && g.ny == 4 && g.nx == 4) {
     if (math) hipLaunchKernelGGL((wino_in444_kernel<MODE, true>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C);
@@ -1406,6 +1410,10 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
   if (const char* e = getenv("DRAM_NN_NJ")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && N % (64 * v) == 0) nj = v; }
   const int n_tiles = N / (64 * nj);
   const int nblk = g.npts * m_tiles * n_tiles;
+  // executed: 2*M*N*K per point; algorithmic bytes: A, U read once, Y written once
+  DramProf prof(DRAM_FAM_WINO_GEMM_NN, nj, 2.0 * g.npts * (double)g.Tpad * N * K,
+                4.0 * g.npts * ((double)g.Tpad * (K + N) + (double)N * K), s,
+                g.npts > 1 ? 2.0 * g.B * g.D * g.H * g.W * (double)N * K * 27.0 : -1.0);
   if (math) {      // split-bf16 operand images (Winograd pipeline only; no fused epilogue there)
 #define WNB(NJ_, NT_)                                                                                                  \
   hipLaunchKernelGGL((wino_gemm_nn_bf16_kernel<NJ_, NT_>), dim3(nblk), dim3(512), 0, s, A, U, Y, g.Tpad, N, K, m_tiles, \
@@ -1441,6 +1449,9 @@ int run_conv(const float* in, const float* U, const float* bias, const float* ad
   const int rc = run_nn(V, U, Mh, g, N, K, s, GemmEpilogue{nullptr, nullptr, nullptr, nullptr}, math);
   if (rc != DRAM_OK) return rc;
   const int ntb = (g.T + WINO_TPB - 1) / WINO_TPB;
+  const double out_elems = (double)g.B * g.D * g.H * g.W * N;
+  DramProf prof(DRAM_FAM_WINO_OUT, g.nz * 100 + g.ny * 10 + g.nx, 0.0,
+                4.0 * ((double)g.npts * g.Tpad * N + out_elems * (1 + (add ? 1 : 0) + (gate ? 1 : 0))), s);
 #define W_OUT(NZ_, NY_, NX_)                                                                                              \
   hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_, NX_>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add, gate, out, stats, \
                      g, N)
@@ -1526,6 +1537,9 @@ extern "C" int dram_conv1x1_bwd_weight(const float* x, const float* dy, float* d
   hipStream_t s = (hipStream_t)stream;
   float* slab = p.nsplit > 1 ? (float*)workspace : dw;      // one split: the GEMM writes dw[co][ci] directly
   const int nblk = p.nsplit * p.m_tiles * p.n_tiles;
+  {
+  DramProf prof(DRAM_FAM_WINO_GEMM_TN, p.bm * 1000 + p.bn, 2.0 * (double)g.Tpad * d->Cout * d->Cin,
+                4.0 * ((double)g.Tpad * (d->Cout + d->Cin) + (double)p.nsplit * d->Cout * d->Cin), s);
 #define C1TN(WM_, MI_, NJ_)                                                                                         \
   hipLaunchKernelGGL((wino_gemm_tn_kernel<WM_, MI_, NJ_>), dim3(nblk), dim3(512), 0, s, dy, x, slab, g.Tpad, d->Cout, \
                      d->Cin, p.m_tiles, p.n_tiles, p.nsplit, p.kper, nblk, 1)
@@ -1539,9 +1553,11 @@ extern "C" int dram_conv1x1_bwd_weight(const float* x, const float* dy, float* d
   else return DRAM_ERR_UNSUPPORTED;
 #undef C1TN
   DRAM_LAUNCH_CHECK();
+  }
   if (p.nsplit > 1) {
     const long n = (long)d->Cout * d->Cin;
     const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    DramProf prof(DRAM_FAM_WINO_WGRAD_OUT, 0, 0.0, 4.0 * (double)n * (p.nsplit + 1), s);
     hipLaunchKernelGGL(slab_sum_kernel, dim3(grid), dim3(256), 0, s, slab, dw, n, p.nsplit);
     DRAM_LAUNCH_CHECK();
   }
@@ -1685,6 +1701,8 @@ extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, const
   const WinoGeom gf = make_geom(d, 0), gb = make_geom(d, 1);      // uf: forward tiling, ub: data-gradient tiling
   const bool same = gf.nz == gb.nz && gf.ny == gb.ny && gf.nx == gb.nx;
   float *pf = uf, *pb = same ? ub : nullptr;
+  DramProf prof(DRAM_FAM_WEIGHT_PACK, 1, 0.0,
+                4.0 * (double)n * (27.0 + (uf ? gf.npts : 0) + (ub ? gb.npts : 0)), (hipStream_t)stream);
 #define W_WT(NZ_, NY_, NX_)                                                                                            \
   hipLaunchKernelGGL((wino_weight_kernel<NZ_, NY_, NX_>), grid, dim3(256), 0, (hipStream_t)stream, w, pf, pb, d->Cout, \
                      d->Cin, math_mode() ? 1 : 0)
@@ -1764,6 +1782,10 @@ extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache,
   }
   { const int rc1 = launch_wino_in<1>(dy, Dh, g, d->Cout, math, s); if (rc1 != DRAM_OK) return rc1; }
   const int nblk = g.npts * p.nsplit * p.m_tiles * p.n_tiles;
+  {
+  DramProf prof(DRAM_FAM_WINO_GEMM_TN, p.bm * 1000 + p.bn, 2.0 * g.npts * (double)g.Tpad * d->Cout * d->Cin,
+                4.0 * g.npts * ((double)g.Tpad * (d->Cout + d->Cin) + (double)p.nsplit * d->Cout * d->Cin), s,
+                2.0 * g.B * g.D * g.H * g.W * (double)d->Cout * d->Cin * 27.0);
 #define WTN(WM_, MI_, NJ_)                                                                                             \
   do {                                                                                                                 \
     if (math == 1)                                                                                                     \
@@ -1786,7 +1808,9 @@ extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache,
   else return DRAM_ERR_UNSUPPORTED;
 #undef WTN
   DRAM_LAUNCH_CHECK();
+  }
   const long n = (long)d->Cout * d->Cin;
+  DramProf prof(DRAM_FAM_WINO_WGRAD_OUT, 1, 0.0, 4.0 * (double)n * ((double)g.npts * p.nsplit + 27.0), s);
 #define W_WGO(NZ_, NY_, NX_)                                                                                         \
   hipLaunchKernelGGL((wino_wgrad_out_kernel<NZ_, NY_, NX_>), dim3((unsigned)((n + 63) / 64)), dim3(512), 0, s, slab, dw, \
                      d->Cout, d->Cin, p.nsplit)

@@ -702,6 +702,13 @@ int run_w2d(const float* in, const float* u2, const float* bias, const float* ad
   const int BN = N % 64 == 0 ? 64 : 32;
   int variant = 1;
   const W2dGeom g = make_w2d(d, K, N, BN, &variant);
+  // executed: 16 in-plane Winograd points x 3 z-taps = 48 MFMA products per 2x2 output tile and channel pair
+  // (a direct conv issues 108) on the padded tile grid; bytes: input, output (+ add, gate) once, weights once
+  const double vox_pad = (double)g.B * g.tiles_per_b * (variant == 1 ? W2_TZ16 : V2_TZ) * 64.0;
+  const double vox = (double)g.B * g.D * g.H * g.W;
+  DramProf prof(DRAM_FAM_CONV_WINO2D, variant * 100 + BN, 2.0 * vox_pad * K * N * 12.0,
+                4.0 * (vox * (K + N * (1.0 + (add ? 1 : 0) + (gate ? 1 : 0))) + 48.0 * K * N), s,
+                2.0 * vox * K * N * 27.0);
   if (variant == 1) {
     if (BN == 64)
       hipLaunchKernelGGL((conv_wino2d_kernel<2>), dim3(g.nblk), dim3(512), 0, s, in, u2, bias, out, stats, add, gate, g);
@@ -737,6 +744,8 @@ extern "C" int dram_wino2d_num_stat_rows(const DramConvDesc* d) {
 extern "C" int dram_wino2d_pack_weight(const float* w, float* uf, float* ub, int Cout, int Cin, dram_stream_t stream) {
   if (!w || (!uf && !ub) || Cout < 1 || Cin < 1) return DRAM_ERR_BAD_ARG;
   const long n = (long)Cout * Cin;
+  DramProf prof(DRAM_FAM_WEIGHT_PACK, 2, 0.0, 4.0 * (double)n * (27.0 + (uf ? 48 : 0) + (ub ? 48 : 0)),
+                (hipStream_t)stream);
   hipLaunchKernelGGL(wino2d_weight_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream, w,
                      uf, ub, Cout, Cin);
   DRAM_LAUNCH_CHECK();

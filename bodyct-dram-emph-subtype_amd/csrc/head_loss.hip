@@ -288,6 +288,7 @@ extern "C" int dram_head_fwd(const float* x, const float* w, const float* bias, 
   const NearGeom ng = make_near(lungs ? Dl : 1, lungs ? Hl : 1, lungs ? Wl : 1, D, H, W);
   dim3 grid(nblk, B), block(256);
   hipStream_t s = (hipStream_t)stream;
+  DramProf prof(DRAM_FAM_HEAD_LOSS, 0, 0.0, 4.0 * (double)B * vps * (32.0 + NO + (lungs ? 0.125 : 0.0)), s);
   if (NO <= 2)
     hipLaunchKernelGGL((head_fwd_kernel<2>), grid, block, 0, s, x, w, bias, lungs, ng, dense, partial, D, H, W, NO, sigmoid, nblk);
   else if (NO <= 9)
@@ -310,6 +311,8 @@ extern "C" int dram_head_bwd(const float* x, const float* w, const float* dense,
   const NearGeom ng = make_near(lungs ? Dl : 1, lungs ? Hl : 1, lungs ? Wl : 1, D, H, W);
   dim3 grid(nblk, B), block(256);
   hipStream_t s = (hipStream_t)stream;
+  DramProf prof(DRAM_FAM_HEAD_LOSS, 1, 0.0,
+                4.0 * (double)B * vps * (64.0 + (dense ? NO : 0) + (gdense ? NO : 0) + (lungs ? 0.125 : 0.0)), s);
   if (NO <= 2)
     hipLaunchKernelGGL((head_bwd_kernel<2>), grid, block, 0, s, x, w, dense, gdense, gpool, lungs, ng, dx, wpartial, D, H, W, NO, sigmoid, nblk);
   else if (NO <= 9)
@@ -332,6 +335,7 @@ extern "C" int dram_segloss_fwd(const float* cle, const float* pse, const float*
       Wl < 1)
     return DRAM_ERR_BAD_ARG;
   const long total = (long)B * D * H * W;
+  DramProf prof(DRAM_FAM_HEAD_LOSS, 2, 0.0, 4.0 * (double)total * 2.25, (hipStream_t)stream);   // cle, pse + 1/8 of 2 masks
   hipLaunchKernelGGL(segloss_fwd_kernel, dim3(dram_segloss_nblk(total)), dim3(256), 0, (hipStream_t)stream, cle, pse,
                      lungs, ems, binary, make_near(Dl, Hl, Wl, D, H, W), partial, B, D, H, W);
   DRAM_LAUNCH_CHECK();
@@ -345,6 +349,7 @@ extern "C" int dram_segloss_bwd(const float* cle, const float* pse, const float*
       Dl < 1 || Hl < 1 || Wl < 1)
     return DRAM_ERR_BAD_ARG;
   const long total = (long)B * D * H * W;
+  DramProf prof(DRAM_FAM_HEAD_LOSS, 3, 0.0, 4.0 * (double)total * 4.25, (hipStream_t)stream);
   hipLaunchKernelGGL(segloss_bwd_kernel, dim3(dram_segloss_nblk(total)), dim3(256), 0, (hipStream_t)stream, cle, pse,
                      lungs, ems, binary, make_near(Dl, Hl, Wl, D, H, W), coef, gcle, gpse, B, D, H, W);
   DRAM_LAUNCH_CHECK();

@@ -90,6 +90,8 @@ extern "C" int dram_adam_multi(const DramTensorRef* table, const DramChunkRef* c
                                float beta1, float beta2, float eps, float weight_decay, float bias_corr1,
                                float bias_corr2, float grad_scale, dram_stream_t stream) {
   if (!table || !chunks || nchunks < 1 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return DRAM_ERR_BAD_ARG;
+  // 28 B per parameter (r p,g,m,v; w p,m,v); the chunk count bounds the parameter count from above
+  DramProf prof(DRAM_FAM_OPTIM, 0, 0.0, 28.0 * (double)nchunks * 16384.0, (hipStream_t)stream);
   hipLaunchKernelGGL(adam_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, chunks, lr, beta1,
                      beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale);
   DRAM_LAUNCH_CHECK();
@@ -100,6 +102,7 @@ extern "C" int dram_sgd_multi(const DramTensorRef* table, const DramChunkRef* ch
                               float momentum, float weight_decay, int first_step, float grad_scale,
                               dram_stream_t stream) {
   if (!table || !chunks || nchunks < 1) return DRAM_ERR_BAD_ARG;
+  DramProf prof(DRAM_FAM_OPTIM, 1, 0.0, (momentum != 0.f ? 20.0 : 12.0) * (double)nchunks * 16384.0, (hipStream_t)stream);
   hipLaunchKernelGGL(sgd_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, chunks, lr, momentum,
                      weight_decay, first_step, grad_scale);
   DRAM_LAUNCH_CHECK();
@@ -108,3 +111,7 @@ extern "C" int dram_sgd_multi(const DramTensorRef* table, const DramChunkRef* ch
 
 extern "C" int dram_version(void) { return DRAM_ABI_VERSION; }
 extern "C" const char* dram_build_info(void) { return "libdram_hip gfx950 fp32-mfma"; }
+#ifndef DRAM_ABI_HASH
+#error "build through _build.py (it passes -DDRAM_ABI_HASH=<sha1 of include/dram_hip.h>)"
+#endif
+extern "C" const char* dram_abi_hash(void) { return DRAM_ABI_HASH; }

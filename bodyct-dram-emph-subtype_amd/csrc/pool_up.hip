@@ -356,6 +356,7 @@ extern "C" int dram_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int B
   if (!x || !y || !argmax || B < 1 || D < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
   const int Do = (D + 2 - 3) / 2 + 1, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long total4 = (long)B * Do * Ho * Wo * (C >> 2);
+  DramProf prof(DRAM_FAM_POOL_UP, 0, 0.0, 4.0 * (double)B * D * H * W * C + 5.0 * 4.0 * total4, (hipStream_t)stream);
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, D, H,
                      W, C, Do, Ho, Wo, total4);
   DRAM_LAUNCH_CHECK();
@@ -368,6 +369,8 @@ extern "C" int dram_maxpool_bwd(const float* dy, const uint8_t* argmax, const fl
   if (add && (add_stride < C || (add_stride & 3) || ((uintptr_t)add & 15))) return DRAM_ERR_BAD_ARG;
   const int Do = (D + 2 - 3) / 2 + 1, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long total4 = (long)B * D * H * W * (C >> 2);
+  DramProf prof(DRAM_FAM_POOL_UP, 1, 0.0,
+                4.0 * 4.0 * total4 * (1.0 + (add ? 1 : 0)) + 5.0 * (double)B * Do * Ho * Wo * C, (hipStream_t)stream);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, argmax, add,
                      add_stride, dx, D, H, W, C, Do, Ho, Wo, total4);
   DRAM_LAUNCH_CHECK();
@@ -382,6 +385,8 @@ extern "C" int dram_upcat_fwd(const float* src, const float* skip, float* cat, i
   const int oz = (Dk - Do + 1) / 2, oy = (Hk - Ho + 1) / 2, ox = (Wk - Wo + 1) / 2;  // ceil((b-a)/2)
   const long total4 = (long)B * Do * Ho * Wo * ((Cu + Ck) >> 2);
   const long tiles = (long)B * ((Do + 7) / 8) * ((Ho + 7) / 8) * ((Wo + 7) / 8);
+  DramProf prof(DRAM_FAM_POOL_UP, 2, 0.0,
+                4.0 * ((double)B * Ds * Hs * Ws * Cu + (double)B * Do * Ho * Wo * Ck + 4.0 * total4), (hipStream_t)stream);
   if (Cu % 64 == 0 && tiles >= 512 && tiles < (1L << 31) && !getenv("DRAM_UPCAT_UNTILED")) {
     hipLaunchKernelGGL(upcat_fwd_tiled_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, src, skip, cat, Ds,
                        Hs, Ws, Cu, Dk, Hk, Wk, Ck, oz, oy, ox, ac_scale(Ds, Do), ac_scale(Hs, Ho), ac_scale(Ws, Wo),
@@ -405,12 +410,14 @@ extern "C" int dram_upcat_bwd(const float* dcat, float* dsrc, float* dskip, int 
   hipStream_t s = (hipStream_t)stream;
   if (dsrc) {
     const long total4 = (long)B * Ds * Hs * Ws * (Cu >> 2);
+    DramProf prof(DRAM_FAM_POOL_UP, 3, 0.0, 4.0 * ((double)B * Do * Ho * Wo * Cu + 4.0 * total4), s);
     hipLaunchKernelGGL(upcat_bwd_src_kernel, dim3(ew_grid(total4)), dim3(256), 0, s, dcat, dsrc, Ds, Hs, Ws, Cu,
                        Cu + Ck, ac_scale(Ds, Do), ac_scale(Hs, Ho), ac_scale(Ws, Wo), total4);
     DRAM_LAUNCH_CHECK();
   }
   if (dskip) {
     const long total4 = (long)B * Dk * Hk * Wk * (Ck >> 2);
+    DramProf prof(DRAM_FAM_POOL_UP, 4, 0.0, 4.0 * ((double)B * Do * Ho * Wo * Ck + 4.0 * total4), s);
     hipLaunchKernelGGL(upcat_bwd_skip_kernel, dim3(ew_grid(total4)), dim3(256), 0, s, dcat, dskip, Do, Ho, Wo, Cu, Dk,
                        Hk, Wk, Ck, oz, oy, ox, total4);
     DRAM_LAUNCH_CHECK();
@@ -429,6 +436,7 @@ extern "C" int dram_upproject(const float* dense, const float* ess, float* out, 
     return DRAM_ERR_BAD_ARG;
   const long vps = (long)Do * Ho * Wo;
   const int nblk = dram_upproject_nblk(vps);
+  DramProf prof(DRAM_FAM_POOL_UP, 5, 0.0, 4.0 * ((double)B * D * H * W + 2.0 * B * (double)vps), (hipStream_t)stream);
   hipLaunchKernelGGL(upproject_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, dense, ess, out, partial, D, H,
                      W, Do, Ho, Wo, ac_scale(D, Do), ac_scale(H, Ho), ac_scale(W, Wo), vps, nblk);
   DRAM_LAUNCH_CHECK();

@@ -89,6 +89,7 @@ extern "C" int dram_window_stats_nblk(long long n) {
 extern "C" int dram_window_stats(const float* scan, float* partial, long long n, float lo, float hi,
                                  dram_stream_t stream) {
   if (!scan || !partial || n < 2 || !(hi > lo)) return DRAM_ERR_BAD_ARG;
+  DramProf prof(DRAM_FAM_PREP, 0, 0.0, 4.0 * (double)n, (hipStream_t)stream);
   hipLaunchKernelGGL(window_stats_kernel, dim3(dram_window_stats_nblk(n)), dim3(256), 0, (hipStream_t)stream, scan,
                      partial, (long)n, lo, hi);
   DRAM_LAUNCH_CHECK();
@@ -101,6 +102,7 @@ extern "C" int dram_prep_image(const float* scan, const int* zidx, const float* 
     return DRAM_ERR_BAD_ARG;
   const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
   const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  DramProf prof(DRAM_FAM_PREP, 1, 0.0, 4.0 * ((double)Do * H * W + (double)Do * Ho * Wo), (hipStream_t)stream);
   hipLaunchKernelGGL(prep_image_kernel, dim3(grid_for((long)Do * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, scan,
                      zidx, mean_invstd, out, H, W, Do, Ho, Wo, sy, sx, lo, hi);
   DRAM_LAUNCH_CHECK();
@@ -110,6 +112,7 @@ extern "C" int dram_prep_image(const float* scan, const int* zidx, const float* 
 extern "C" int dram_prep_mask(const float* mask, const int* zidx, float* out, int D, int H, int W, int Do, int Ho,
                               int Wo, dram_stream_t stream) {
   if (!mask || !zidx || !out || D < 1 || H < 1 || W < 1 || Do < 1 || Ho < 1 || Wo < 1) return DRAM_ERR_BAD_ARG;
+  DramProf prof(DRAM_FAM_PREP, 2, 0.0, 4.0 * 2.0 * (double)Do * Ho * Wo, (hipStream_t)stream);
   hipLaunchKernelGGL(prep_mask_kernel, dim3(grid_for((long)Do * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, mask,
                      zidx, out, H, W, Do, Ho, Wo, (float)H / (float)Ho, (float)W / (float)Wo);
   DRAM_LAUNCH_CHECK();

@@ -298,6 +298,9 @@ extern "C" int dram_stem_fwd(const float* x, const float* w, float* y, float* st
   g.nz = (g.Do + 3) / 4; g.ny = (g.Ho + 7) / 8; g.nx = (g.Wo + 7) / 8;
   g.tiles_per_b = g.nz * g.ny * g.nx;
   g.nblk = B * g.tiles_per_b;
+  const double vo = (double)B * g.Do * g.Ho * g.Wo;
+  DramProf prof(DRAM_FAM_STEM, 0, 2.0 * vo * 64.0 * 343.0, 4.0 * ((double)B * D * H * W + vo * 64.0 + 64.0 * 343.0),
+                (hipStream_t)stream);
   hipLaunchKernelGGL(stem_fwd_kernel, dim3(g.nblk), dim3(256), 0, (hipStream_t)stream, x, w, y, stats_partial, g);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
@@ -320,6 +323,8 @@ extern "C" int dram_stem_bwd_weight(const float* x, const float* dy, float* dw, 
   const int nblk = stem_wgrad_blocks(g.total);
   if (!workspace || workspace_bytes < (size_t)nblk * 64 * NTAP * sizeof(float)) return DRAM_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
+  const double vo = (double)B * g.Do * g.Ho * g.Wo;
+  DramProf prof(DRAM_FAM_STEM, 1, 2.0 * vo * 64.0 * 343.0, 4.0 * ((double)B * D * H * W + vo * 64.0 + 64.0 * 343.0), s);
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, s, x, dy, (float*)workspace, g);
   DRAM_LAUNCH_CHECK();
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * NTAP + 255) / 256), dim3(256), 0, s,

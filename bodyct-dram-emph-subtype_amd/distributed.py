@@ -3,117 +3,204 @@
 Stands in for what the reference gets from Lightning's ``DDPStrategy`` +
 ``sync_batchnorm=True`` (reference train.py:70,100-104):
 
-  C1  gradient mean over ranks     -> bucketed, *asynchronous* all-reduce launched from
-                                      inside the engine's backward as soon as a layer's
-                                      gradients exist, overlapped with the rest of backward
-  C2  SyncBN forward statistics    -> one all-reduce of [sum, sum^2] (2C doubles)
-  C3  SyncBN backward sums         -> one all-reduce of [sum g, sum g*xhat] (2C doubles)
+  C1  gradient mean over ranks     -> the weight-gradient kernels write straight into ONE flat
+                                      arena (a view per parameter, parameter order); contiguous
+                                      ranges of it are all-reduced *asynchronously* from inside the
+                                      engine's backward as soon as >= bucket_bytes of it are final,
+                                      overlapped with the rest of backward.  No concatenation copy.
+  C2  SyncBN forward statistics    -> one in-place all-reduce of [sum, sum^2, count] (2C+1 doubles);
+                                      the global count stays on the device (ranks may hold different
+                                      batch sizes, as under torch SyncBatchNorm)
+  C3  SyncBN backward sums         -> one in-place all-reduce of [sum g, sum g*xhat] (2C doubles),
+                                      launched asynchronously; the engine runs the PREVIOUS unit's
+                                      weight-gradient kernel while it is in flight
   C4  per-step buffer broadcast    -> dropped: SyncBN keeps running stats identical
   C5  initial parameter broadcast  -> broadcast_parameters()
 
-``torch.distributed`` with backend ``nccl`` IS RCCL on ROCm; the same code runs on
-``gloo`` (CPU or device tensors) for tests.  The engine's fused conv-BN units are invisible
-to ``SyncBatchNorm.convert_sync_batchnorm``, hence this module.
+Collectives per train step: 2 x (number of BN layers) statistic all-reduces (22/38/54 layers for
+ResNet-18/34/50: 44/76/108, each <= 32 KB, latency-bound; the backward half is hidden behind a
+weight-gradient kernel) + ceil(parameter bytes / bucket_bytes) + 1 gradient all-reduces (R18: 5 + 1).
+
+``torch.distributed`` with backend ``nccl`` IS RCCL on ROCm; the same code runs on ``gloo`` (CPU or
+device tensors) for tests.  ``force=True`` (or DRAM_DIST_FORCE=1) keeps every collective in place at
+world_size 1, which is how the RCCL code path is exercised on a one-GPU box.  The engine's fused
+conv-BN units are invisible to ``SyncBatchNorm.convert_sync_batchnorm``, hence
+this module.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+import os
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
 Tensor = torch.Tensor
+SMALL_NUMEL = 4096      # parameters below this (BN affine, biases, 1x1x1 heads) travel in one extra small bucket
+
+
+class _Done:
+    def wait(self):
+        return True
 
 
 class DistContext:
     def __init__(self, process_group=None, sync_bn: bool = True, bucket_bytes: int = 32 << 20,
-                 average: bool = True):
+                 average: bool = True, force: Optional[bool] = None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
+        if force is None:
+            force = os.environ.get("DRAM_DIST_FORCE", "0") == "1"
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
+        self.active = self.world > 1 or bool(force)
         self.sync_bn = sync_bn
         self.bucket_bytes = bucket_bytes
         self.average = average
         self._backend = dist.get_backend(process_group)
-        self._pending: List[str] = []
-        self._pending_bytes = 0
-        self._inflight = []   # (work, flat, names, shapes)
+        self._slots: Dict[str, Tuple[int, int, Tuple[int, ...]]] = {}    # big params: name -> (index, offset, shape)
+        self._order: List[Tuple[str, int, int]] = []                     # (name, offset, numel) in parameter order
+        self._total = 0
+        self.stats = dict(bn_allreduce=0, grad_allreduce=0)              # collectives issued since construction
+        self.last_arena = None                                           # (ptr, bytes) of the last finished step's arena
+        self._reset()
+
+    # ---------------------------------------------------------------- layout
+    def bind(self, named_params):
+        """Lay the large parameters out in one flat gradient arena, in parameter order (backward
+        produces them in roughly the reverse order, so finished ranges grow from the end)."""
+        self._slots, self._order, off = {}, [], 0
+        for name, p in named_params:
+            if p.numel() >= SMALL_NUMEL:
+                self._slots[name] = (len(self._order), off, tuple(p.shape))
+                self._order.append((name, off, p.numel()))
+                off += (p.numel() + 63) // 64 * 64        # 256-byte aligned views
+        self._total = off
+
+    def _reset(self):
+        self._arena: Optional[Tensor] = None
+        self._ready: List[bool] = []
+        self._hi = 0                  # slots [_hi, end) are already being reduced
+        self._small: List[str] = []
+        self._inflight: List[tuple] = []
         self._done = set()
 
-    # ---------------------------------------------------------------- SyncBN
-    def sync_bn_stats(self, sums: Tensor, count: float):
-        """sums [2,C] float64 local -> (global sums, global count)."""
-        if not self.sync_bn or self.world == 1:
-            return sums, count
-        out = sums.clone()
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.pg)
-        # every rank contributes the same per-rank count (same local batch shape), so the
-        # global count is known on the host without a device->host sync
-        return out, count * self.world
+    def begin_backward(self, device):
+        """Start of every engine.backward: forget whatever an interrupted step left behind (a caught
+        OOM must not make the next step skip or wait on stale work) and take a FRESH arena -- the
+        previous one may still back p.grad (gradient accumulation without zero_grad)."""
+        self._reset()
+        if self._total:
+            self._arena = torch.empty((self._total,), device=device, dtype=torch.float32)
+        self._ready = [False] * len(self._order)
+        self._hi = len(self._order)
 
-    def all_reduce_sum(self, t: Tensor) -> Tensor:
-        if not self.sync_bn or self.world == 1:
-            return t
-        out = t.clone()
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.pg)
-        return out
+    def grad_out(self, name: str) -> Optional[Tensor]:
+        """The arena view the weight-gradient kernel of `name` should write (None: not an arena parameter)."""
+        s = self._slots.get(name)
+        if s is None or self._arena is None:
+            return None
+        _, off, shape = s
+        n = 1
+        for d in shape:
+            n *= d
+        return self._arena[off:off + n].view(shape)
+
+    # ---------------------------------------------------------------- collectives
+    def _all_reduce(self, t: Tensor, avg: bool, async_op: bool):
+        if avg and self._backend == "nccl":
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.pg, async_op=async_op), True
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op), False
+
+    def all_reduce_stats(self, flat: Tensor):
+        """In-place SUM of a float64 statistics buffer over ranks (forward: the consumer needs it now)."""
+        if not (self.sync_bn and self.active):
+            return
+        self.stats["bn_allreduce"] += 1
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def all_reduce_stats_async(self, flat: Tensor):
+        """Same, asynchronous: returns a handle whose wait() orders the current stream (RCCL) or the
+        host (gloo) after the reduction.  The caller launches independent kernels in between."""
+        if not (self.sync_bn and self.active):
+            return _Done()
+        self.stats["bn_allreduce"] += 1
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     # ---------------------------------------------------------------- gradients
     def grads_ready(self, grads: Dict[str, Tensor], names: List[str]):
         """Called by the engine's backward when `names` have their final local gradients."""
-        if self.world == 1:
+        if not self.active:
             return
         for n in names:
             if n in self._done or n not in grads:
                 continue
             self._done.add(n)
-            self._pending.append(n)
-            self._pending_bytes += grads[n].numel() * grads[n].element_size()
-        if self._pending_bytes >= self.bucket_bytes:
-            self._launch(grads)
+            s = self._slots.get(n)
+            if s is None or self._arena is None:
+                self._small.append(n)
+                continue
+            view = self.grad_out(n)
+            if grads[n].data_ptr() != view.data_ptr():          # produced elsewhere: bring it into the arena
+                view.copy_(grads[n])
+                grads[n] = view
+            self._ready[s[0]] = True
+        lo = self._hi
+        while lo > 0 and self._ready[lo - 1]:
+            lo -= 1
+        if lo < self._hi:
+            a = self._order[lo][1]
+            b = self._order[self._hi - 1][1] + self._order[self._hi - 1][2]
+            if (b - a) * 4 >= self.bucket_bytes or lo == 0:
+                self._launch_range(lo)
 
-    def _launch(self, grads: Dict[str, Tensor]):
-        if not self._pending:
-            return
-        names = self._pending
-        self._pending, self._pending_bytes = [], 0
-        flat = torch.cat([grads[n].reshape(-1) for n in names])
-        if self.average and self._backend == "nccl":
-            work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
-            scaled = True
-        else:
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            scaled = False
-        self._inflight.append((work, flat, names, [grads[n].shape for n in names], scaled))
+    def _launch_range(self, lo: int):
+        a = self._order[lo][1]
+        b = self._order[self._hi - 1][1] + self._order[self._hi - 1][2]
+        seg = self._arena[a:b]
+        work, scaled = self._all_reduce(seg, self.average, True)
+        self.stats["grad_allreduce"] += 1
+        self._inflight.append((work, seg, scaled))
+        self._hi = lo
 
     def finish(self, grads: Dict[str, Tensor]):
-        """Flush, wait for every bucket, and re-point grads at the reduced buffers."""
-        if self.world == 1:
+        """Flush what is left, wait for every bucket; the small parameters go in one extra bucket."""
+        if not self.active:
             return
-        self._launch(grads)
-        for work, flat, names, shapes, scaled in self._inflight:
+        if self._hi > 0:
+            # parameters that never reported (frozen ones) leave undefined arena bytes nobody reads
+            self._launch_range(0)
+        small = [n for n in self._small if n in grads]
+        flat = None
+        if small:
+            flat = torch.cat([grads[n].reshape(-1) for n in small])
+            work, scaled = self._all_reduce(flat, self.average, True)
+            self.stats["grad_allreduce"] += 1
+            self._inflight.append((work, flat, scaled))
+        for work, seg, scaled in self._inflight:
             work.wait()
             if self.average and not scaled:
-                flat.div_(self.world)
+                seg.div_(self.world)
+        if small:
             off = 0
-            for n, shp in zip(names, shapes):
-                k = 1
-                for s in shp:
-                    k *= s
-                grads[n] = flat[off:off + k].view(shp)
+            for n in small:
+                k = grads[n].numel()
+                grads[n] = flat[off:off + k].view(grads[n].shape)
                 off += k
-        self._inflight = []
-        self._done = set()
+        arena = self._arena
+        self._reset()
+        self.last_arena = (arena.data_ptr(), arena.numel() * 4) if arena is not None else None
 
 
 def attach(module, process_group=None, sync_bn: bool = True, bucket_bytes: int = 32 << 20,
-           broadcast: bool = True) -> DistContext:
+           broadcast: bool = True, force: Optional[bool] = None) -> DistContext:
     """Make `module` (a ResNetSeg* drop-in) data-parallel: the equivalent of wrapping the
-    reference network in DDP + SyncBatchNorm (train.py:100-104)."""
-    ctx = DistContext(process_group, sync_bn, bucket_bytes)
-    module._dist = ctx if ctx.world > 1 else None
+    reference network in DDP + SyncBatchNorm (train.py:100-104).  Do NOT also wrap it in
+    DistributedDataParallel / convert_sync_batchnorm."""
+    ctx = DistContext(process_group, sync_bn, bucket_bytes, force=force)
+    ctx.bind(list(module.named_parameters()))
+    module._dist = ctx if ctx.active else None
     if broadcast and ctx.world > 1:
         broadcast_parameters(module, process_group)
     return ctx

@@ -43,6 +43,7 @@ class _State:
         self.dist = dist
         self.grads: Dict[str, Tensor] = {}
         self.nbt: List[Tensor] = []
+        self.deferred = None          # (ctx, dy) of the unit whose weight gradient is still to be launched
 
 
 class Engine:
@@ -59,13 +60,19 @@ class Engine:
     def _bn_fwd(self, st: _State, y: Tensor, sp: Optional[Tensor], bnp: str, residual, rs, relu=True):
         P = st.P
         count = float(y.numel() // y.shape[-1])
+        count_dev = None
         if st.training:
-            sums = ops.reduce_partials(sp)
-            if st.dist is not None:
-                sums, count = st.dist.sync_bn_stats(sums, count)
+            if st.dist is not None and st.dist.sync_bn:
+                # SyncBN (train.py:101): [sum, sum^2, count] summed over ranks in ONE in-place all-reduce;
+                # the global count never leaves the device
+                flat, sums = ops.reduce_partials(sp, tail=count)
+                st.dist.all_reduce_stats(flat)
+                count_dev = flat[-1:]
+            else:
+                sums = ops.reduce_partials(sp)
             mean, invstd, scale, shift = ops.bn_finalize(sums, count, P[bnp + ".weight"], P[bnp + ".bias"],
                                                          P[bnp + ".running_mean"], P[bnp + ".running_var"],
-                                                         BN_MOMENTUM, BN_EPS, True)
+                                                         BN_MOMENTUM, BN_EPS, True, count_dev)
             st.nbt.append(P[bnp + ".num_batches_tracked"])      # incremented together at the end of forward
         else:
             mean, invstd, scale, shift = ops.bn_finalize(None, 1.0, P[bnp + ".weight"], P[bnp + ".bias"],
@@ -73,7 +80,7 @@ class Engine:
                                                          BN_MOMENTUM, BN_EPS, False)
         z = ops.bn_apply(y, scale, shift, residual, rs, relu)
         # without a residual the backward pass re-derives the ReLU mask from y (scale, shift) instead of reading z
-        return z, mean, invstd, count, (None if residual is not None else (scale, shift))
+        return z, mean, invstd, (count, count_dev), (None if residual is not None else (scale, shift))
 
     def _bn_bwd(self, st: _State, c: dict, dz: Tensor) -> Tensor:
         bnp = c["bn"]
@@ -85,17 +92,21 @@ class Engine:
         sf = sums.float()                                  # one conversion; the two gradients are its rows
         st.grads[bnp + ".weight"] = sf[1]
         st.grads[bnp + ".bias"] = sf[0]
-        if st.dist is not None:
-            sums = st.dist.all_reduce_sum(sums)
+        count, count_dev = c["count"]
+        if st.dist is not None and st.dist.sync_bn:
+            # C3: the sums travel while the previous unit's weight-gradient kernel runs
+            work = st.dist.all_reduce_stats_async(sums)
+            self._flush_wgrad(st)
+            work.wait()
         if c.get("b"):    # the convolution in front has a bias: its gradient = column sums of dy, taken on the way
             dy, colpart = ops.bn_bwd_apply(dz, zmask, c["y"], c["mean"], c["invstd"], st.P[bnp + ".weight"], sums,
-                                           c["count"], True, sc, sh, want_colsum=True)
+                                           count, True, sc, sh, want_colsum=True, count_dev=count_dev)
             if colpart is None:
                 colpart = ops.colsum(dy)
             st.grads[c["b"]] = ops.reduce_partials(colpart)[0].float()
             return dy
-        return ops.bn_bwd_apply(dz, zmask, c["y"], c["mean"], c["invstd"], st.P[bnp + ".weight"], sums, c["count"],
-                                True, sc, sh)
+        return ops.bn_bwd_apply(dz, zmask, c["y"], c["mean"], c["invstd"], st.P[bnp + ".weight"], sums, count,
+                                True, sc, sh, count_dev=count_dev)
 
     # ------------------------------------------------------------------ conv + BN unit
     def _conv_bn_fwd(self, st: _State, x: Tensor, wname: str, bname: Optional[str], bnp: str, k: int, stride: int,
@@ -114,17 +125,28 @@ class Engine:
 
     def _conv_bn_bwd(self, st: _State, c: dict, dz: Tensor, need_dx=True, add=None, gate=None):
         dy = self._bn_bwd(st, c, dz)
-        st.grads[c["w"]] = ops.conv3d_bwd_weight(c["x"], dy, c["g"], v_cache=c.get("v"))
-        c["v"] = None                                   # release the cached Winograd-domain input
-        self._grad_ready(st, c)
+        if st.dist is not None:
+            # data parallel: this unit's weight gradient is launched inside the NEXT unit's statistic
+            # all-reduce (see _bn_bwd), hiding that latency-bound collective behind a long kernel
+            st.deferred = (c, dy)
+        else:
+            self._wgrad(st, c, dy)
         if not need_dx:
             return None
         return ops.conv3d_bwd_data(dy, c["wb"], c["g"], add, gate)
 
-    def _grad_ready(self, st: _State, c: dict):
+    def _wgrad(self, st: _State, c: dict, dy: Tensor):
+        out = st.dist.grad_out(c["w"]) if st.dist is not None else None
+        st.grads[c["w"]] = ops.conv3d_bwd_weight(c["x"], dy, c["g"], out=out, v_cache=c.get("v"))
+        c["v"] = None                                   # release the cached Winograd-domain input
         if st.dist is not None:
             names = [c["w"], c["bn"] + ".weight", c["bn"] + ".bias"] + ([c["b"]] if c["b"] else [])
             st.dist.grads_ready(st.grads, names)
+
+    def _flush_wgrad(self, st: _State):
+        if st.deferred is not None:
+            (c, dy), st.deferred = st.deferred, None
+            self._wgrad(st, c, dy)
 
     # ------------------------------------------------------------------ residual blocks
     def _block_fwd(self, st, x, p, planes, stride, dil, has_ds):
@@ -178,7 +200,16 @@ class Engine:
     def forward(self, P: Dict[str, Tensor], x: Tensor, lungs: Optional[Tensor], training: bool, need_grad: bool,
                 dist=None):
         """x [B,1,D,H,W] (NCDHW == NDHW for C=1), lungs None or [B,1,D,H,W] float.
-        Returns (dense_list, outs_list, saved-or-None)."""
+        Returns (dense_list, outs_list, saved-or-None).  Every kernel is launched on x's device (its
+        current stream); operands on any other device are rejected before launch."""
+        with ops.launch_scope(x.device):
+            return self._forward(P, x, lungs, training, need_grad, dist)
+
+    def backward(self, saved: dict, g_dense: List[Optional[Tensor]], g_outs: List[Optional[Tensor]]):
+        with ops.launch_scope(saved["dense"].device):
+            return self._backward(saved, g_dense, g_outs)
+
+    def _forward(self, P, x, lungs, training, need_grad, dist):
         if need_grad and not training:
             raise NotImplementedError("gradients through eval-mode BatchNorm are not part of the hot path")
         st = _State(P, training, need_grad, dist)
@@ -230,8 +261,10 @@ class Engine:
             torch._foreach_add_(st.nbt, 1)               # one launch for all num_batches_tracked counters
         return dense_list, outs, saved
 
-    def backward(self, saved: dict, g_dense: List[Optional[Tensor]], g_outs: List[Optional[Tensor]]):
+    def _backward(self, saved, g_dense, g_outs):
         st: _State = saved["st"]
+        if st.dist is not None:
+            st.dist.begin_backward(saved["dense"].device)
         n0, n1 = saved["n0"], saved["n1"]
         NO = n0 + n1
         dense = saved["dense"]
@@ -281,13 +314,37 @@ class Engine:
                 idx -= 1
                 extra = dskip_x1 if (li == 1 and bi == 0) else None
                 d = self._block_bwd(st, blocks[idx], d, extra_add=extra)
+        self._flush_wgrad(st)
         # d = gradient w.r.t. the max-pooled stem output
         dxs = ops.maxpool_bwd(d, saved["amax"], saved["xs_shape"], dskip_stem)
         c0 = dict(z=saved["xs"], y=saved["y0"], mean=saved["mean0"], invstd=saved["invstd0"], count=saved["count0"],
                   bn="bn1", ss=saved["ss0"])
         dy0 = self._bn_bwd(st, c0, dxs)
-        st.grads["conv1.weight"] = ops.stem_bwd_weight(saved["x4"], dy0)
+        st.grads["conv1.weight"] = ops.stem_bwd_weight(saved["x4"], dy0,
+                                                       out=st.dist.grad_out("conv1.weight") if st.dist else None)
         if st.dist is not None:
             st.dist.grads_ready(st.grads, ["conv1.weight", "bn1.weight", "bn1.bias"])
             st.dist.finish(st.grads)
         return st.grads
+
+
+def forward_decisions(saved: dict) -> Dict[str, Tensor]:
+    """The piecewise-linear decisions one training forward took, from its saved state: for every
+    ReLU the on/off mask (bool, NCDHW, keyed by the state_dict prefix of the BatchNorm in front of it)
+    and under 'maxpool' the window tap each max-pool output took (uint8 (kz*3+ky)*3+kx, NCDHW).
+    Inspection / verification API: lets a checker evaluate a reference backward on exactly the linear
+    piece this forward ran on (tests/test_network_gpu.py), so a ReLU input within rounding of zero
+    cannot hide -- or fake -- a gradient error."""
+    def mask(z):
+        return (z > 0).permute(0, 4, 1, 2, 3).contiguous()
+
+    out = {"bn1": mask(saved["xs"]), "maxpool": saved["amax"].permute(0, 4, 1, 2, 3).contiguous()}
+    units = []
+    for blk in saved["blocks"]:
+        units.extend(blk[:-1])
+    for cu in (saved["cu1"], saved["cu2"]):
+        units.extend(cu[:2])
+    units.append(saved["cu3"])
+    for c in units:
+        out[c["bn"]] = mask(c["z"])
+    return out

@@ -9,7 +9,9 @@ Activations are NDHWC float32: ``[B, D, H, W, C]``.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import threading
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -25,7 +27,37 @@ def _L():
     return _lib.load()
 
 
+_TLS = threading.local()        # forward runs on the caller's thread, backward on autograd's device thread
+
+
+@contextlib.contextmanager
+def launch_scope(device):
+    """Pin the launch device for a run of kernels: makes `device` torch's current device (so the
+    stream handed to the library belongs to the GPU the operand pointers live on), caches the stream
+    handle, and lets `_req` reject operands that live on any other GPU *before* a kernel is launched
+    with foreign pointers (a page fault / GPU reset instead of a Python error)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("libdram_hip has no CPU path")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    prev = getattr(_TLS, "scope", None)
+    with torch.cuda.device(idx):
+        _TLS.scope = (idx, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        try:
+            yield
+        finally:
+            _TLS.scope = prev
+
+
+def _launch_device() -> int:
+    sc = getattr(_TLS, "scope", None)
+    return sc[0] if sc is not None else torch.cuda.current_device()
+
+
 def _stream():
+    sc = getattr(_TLS, "scope", None)
+    if sc is not None:
+        return sc[1]
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -41,6 +73,9 @@ def _chk(rc: int, name: str):
 def _req(t: Tensor, name: str, dtype=torch.float32, shape=None):
     if not isinstance(t, Tensor) or not t.is_cuda:
         raise RuntimeError(f"{name}: expected a device tensor (libdram_hip has no CPU path)")
+    if t.device.index != _launch_device():
+        raise RuntimeError(f"{name}: lives on cuda:{t.device.index} but kernels launch on cuda:{_launch_device()} "
+                           "(all operands of a call must be on the current device)")
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():
@@ -50,9 +85,50 @@ def _req(t: Tensor, name: str, dtype=torch.float32, shape=None):
     return t
 
 
+class KernelTimeline:
+    """The library's own kernel timeline (dram_profile_*): every kernel launch bracketed by two
+    hipEvents on its launch stream, tagged with family / executed MFMA FLOPs / direct-convolution FLOPs
+    / algorithmic HBM bytes.  bench.py's roofline table is built from it."""
+
+    def __init__(self, max_records: int = 1 << 16):
+        self.max_records = int(max_records)
+
+    def start(self):
+        _chk(_L().dram_profile_start(self.max_records), "dram_profile_start")
+
+    def stop(self):
+        _chk(_L().dram_profile_stop(), "dram_profile_stop")
+
+    def families(self):
+        """{family name: dict(bound, launches, ms, mfma_flops, alg_flops, hbm_bytes, variants{variant: [launches, ms]})}
+        (synchronises the device)"""
+        L = _L()
+        buf = (_lib.DramProfRecord * self.max_records)()
+        n = L.dram_profile_read(buf, self.max_records)
+        if n < 0:
+            raise RuntimeError(f"dram_profile_read failed with code {n}")
+        out = {}
+        for i in range(n):
+            r = buf[i]
+            name = L.dram_profile_family_name(r.family).decode()
+            d = out.setdefault(name, dict(bound="mfma" if L.dram_profile_family_is_mfma(r.family) else "hbm",
+                                          launches=0, ms=0.0, mfma_flops=0.0, alg_flops=0.0, hbm_bytes=0.0,
+                                          variants={}))
+            d["launches"] += 1
+            d["ms"] += r.ms
+            d["mfma_flops"] += r.mfma_flops
+            d["alg_flops"] += r.alg_flops
+            d["hbm_bytes"] += r.hbm_bytes
+            v = d["variants"].setdefault(int(r.variant), [0, 0.0])
+            v[0] += 1
+            v[1] += r.ms
+        self.dropped = int(L.dram_profile_dropped())
+        return out
+
+
 class KernelProfiler:
-    """HIP-event timing of kernel families on the launch stream (bench.py's roofline leg).
-    Records (family, algorithmic flops, start, end) per launch; summary() after a sync."""
+    """HIP-event timing of whole convolution calls on torch's current stream (bench.py --detail: the
+    per-layer table).  Records (family, algorithmic flops, start, end) per call; summary() after a sync."""
 
     def __init__(self):
         self.records = []
@@ -392,21 +468,32 @@ def stem_bwd_weight(x: Tensor, dy: Tensor, out: Optional[Tensor] = None) -> Tens
 
 
 # --------------------------------------------------------------------------- batch norm
-def reduce_partials(partial: Tensor) -> Tensor:
-    """[P,R,C] float32 -> [R,C] float64."""
+def reduce_partials(partial: Tensor, tail: Optional[float] = None):
+    """[P,R,C] float32 -> [R,C] float64.  With `tail` (SyncBN: the rank's element count) returns
+    (flat [R*C+1] float64 whose last element is tail -- the buffer to all-reduce --, its [R,C] view)."""
     _req(partial, "partial")
     Pn, R, C = partial.shape
     stages = _L().dram_reduce_partials_stages(Pn)
-    buf = torch.empty((stages + 1 if stages > 1 else 1, R, C), device=partial.device, dtype=torch.float64)
-    sums = buf[0]
-    scratch = buf[1:] if stages > 1 else None
-    _chk(_L().dram_reduce_partials(_p(partial), _p(sums), _p(scratch), Pn, R, C, _stream()), "dram_reduce_partials")
-    return sums
+    n = R * C + (1 if tail is not None else 0)
+    buf = torch.empty((n + (stages * R * C if stages > 1 else 0),), device=partial.device, dtype=torch.float64)
+    flat = buf[:n]
+    scratch = buf[n:] if stages > 1 else None
+    _chk(_L().dram_reduce_partials(_p(partial), _p(flat), _p(scratch), Pn, R, C,
+                                   float(tail) if tail is not None else 0.0, int(tail is not None), _stream()),
+         "dram_reduce_partials")
+    if tail is not None:
+        return flat, flat[:R * C].view(R, C)
+    return flat.view(R, C)
 
 
 def bn_finalize(sums: Optional[Tensor], count: float, gamma: Tensor, beta: Tensor, running_mean: Tensor,
-                running_var: Tensor, momentum: float, eps: float, update_running: bool):
+                running_var: Tensor, momentum: float, eps: float, update_running: bool,
+                count_dev: Optional[Tensor] = None):
+    """count_dev: optional 1-element float64 device tensor (the all-reduced global count) read by the
+    kernel instead of `count`."""
     C = gamma.numel()
+    if count_dev is not None:
+        _req(count_dev, "count_dev", dtype=torch.float64, shape=(1,))
     _req(gamma, "gamma", shape=(C,))
     _req(beta, "beta", shape=(C,))
     _req(running_mean, "running_mean", shape=(C,))
@@ -415,7 +502,7 @@ def bn_finalize(sums: Optional[Tensor], count: float, gamma: Tensor, beta: Tenso
         _req(sums, "sums", dtype=torch.float64, shape=(2, C))
     out = torch.empty((4, C), device=gamma.device, dtype=torch.float32)
     mean, invstd, scale, shift = out[0], out[1], out[2], out[3]
-    _chk(_L().dram_bn_finalize(_p(sums), float(count), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+    _chk(_L().dram_bn_finalize(_p(sums), float(count), _p(count_dev), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
                                float(momentum), float(eps), int(update_running), _p(mean), _p(invstd), _p(scale),
                                _p(shift), C, _stream()), "dram_bn_finalize")
     return mean, invstd, scale, shift
@@ -478,9 +565,11 @@ def bn_bwd_reduce(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, invs
 
 def bn_bwd_apply(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, sums: Tensor,
                  count: float, relu: bool, scale: Optional[Tensor] = None, shift: Optional[Tensor] = None,
-                 want_colsum: bool = False):
+                 want_colsum: bool = False, count_dev: Optional[Tensor] = None):
     """-> dy, or (dy, partial [P,1,C] column sums of dy) with want_colsum (None when C is unsupported there)."""
     C = y.shape[-1]
+    if count_dev is not None:
+        _req(count_dev, "count_dev", dtype=torch.float64, shape=(1,))
     _req(dz, "dz", shape=y.shape)
     _mask_args(z, y, scale, shift, relu)
     colpart = None
@@ -492,7 +581,7 @@ def bn_bwd_apply(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, invst
     _req(gamma, "gamma", shape=(C,))
     dy = torch.empty_like(y)
     _chk(_L().dram_bn_bwd_apply(_p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(scale), _p(shift), _p(sums),
-                                float(count), _p(dy), _p(colpart), _rows(y), C, int(relu), _stream()),
+                                float(count), _p(count_dev), _p(dy), _p(colpart), _rows(y), C, int(relu), _stream()),
          "dram_bn_bwd_apply")
     return (dy, colpart) if want_colsum else dy
 

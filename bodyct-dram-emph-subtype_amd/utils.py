@@ -6,7 +6,7 @@ requiring hydra/omegaconf (absent from this image): the yaml is read with PyYAML
 ``med3d.*`` target is bound to THIS package's drop-in ``med3d`` module.  If hydra is
 installed and this directory is on ``sys.path`` (so that ``import med3d`` finds the
 drop-in), the reference's own ``get_model_by_name`` works unchanged.
-``load_state_dict_greedy`` follows reference utils.py:226-249.
+``load_state_dict_greedy`` keeps the semantics of reference utils.py:226-249 (own implementation).
 """
 from __future__ import annotations
 
@@ -44,18 +44,17 @@ def get_model_by_name(name: str, conf_dir: str = None):
 
 
 def load_state_dict_greedy(model: torch.nn.Module, state_dict_to_load: Dict):
-    """Shape-checked, key-by-key partial load (strict=False), reference utils.py:226-249."""
-    model_state_dict = model.state_dict()
-    for key, weight in state_dict_to_load.items():
-        if key in model_state_dict:
-            if model_state_dict[key].shape == weight.shape:
-                logger.info(f"[load_state_dict_greedy]:correctly loading:{key}")
-                model_state_dict[key] = weight
-            else:
-                logger.warning(f"[load_state_dict_greedy]:shape mismatch:{key}")
-        else:
-            logger.warning(f"[load_state_dict_greedy]:unexpected entry:{key}")
-    for key in model_state_dict.keys():
-        if key not in state_dict_to_load.keys():
-            logger.warning(f"[load_state_dict_greedy]:missing entry:{key}")
-    model.load_state_dict(model_state_dict, strict=False)
+    """Partial, shape-checked load with the semantics of reference utils.py:226-249: an entry is taken
+    when the model has a tensor of that name AND shape; everything else (unknown names, shape
+    mismatches, names the checkpoint lacks) is skipped and reported, never an error.  Returns the
+    three skipped groups so callers / tests can inspect what happened."""
+    have = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    usable = {k: v for k, v in state_dict_to_load.items() if have.get(k) == tuple(v.shape)}
+    mismatched = sorted(k for k in state_dict_to_load if k in have and k not in usable)
+    unexpected = sorted(k for k in state_dict_to_load if k not in have)
+    missing = sorted(k for k in have if k not in state_dict_to_load)
+    model.load_state_dict(usable, strict=False)
+    report = logger.warning if (mismatched or unexpected or missing) else logger.info
+    report("[load_state_dict_greedy] loaded %d/%d tensors; shape mismatch: %s; unexpected: %s; missing: %s",
+           len(usable), len(have), mismatched or "-", unexpected or "-", missing or "-")
+    return dict(mismatched=mismatched, unexpected=unexpected, missing=missing)

@@ -35,10 +35,63 @@ typedef void* dram_stream_t; /* hipStream_t */
 #define DRAM_ERR_UNSUPPORTED (-2)
 #define DRAM_ERR_WORKSPACE (-3)
 
-#define DRAM_ABI_VERSION 1
+#define DRAM_ABI_VERSION 2
 int dram_version(void);
 /* static string: "gfx950" build tag */
 const char* dram_build_info(void);
+/* sha1 (first 16 hex digits) of the dram_hip.h this library was compiled against; the host binding
+ * compares it with the header it reads its signatures from and refuses a mismatching library. */
+const char* dram_abi_hash(void);
+
+/* ------------------------------------------------------------------------- */
+/* Kernel timeline (measurement only; off by default, no cost when off).
+ * Between dram_profile_start and dram_profile_stop every kernel launch of the library is bracketed by
+ * two hipEvents recorded on the stream it is launched on, tagged with its kernel family, the MFMA
+ * FLOPs it EXECUTES (products really issued -- a Winograd kernel issues fewer than the direct
+ * convolution it replaces) and the ALGORITHMIC HBM bytes it has to move (each operand read once,
+ * each result written once).  bench.py builds its roofline table from these records; rocprofv3
+ * --kernel-trace --stats of the same command must agree (profiles/).
+ *   dram_profile_start(max_records): allocate the event pool, clear the log, switch recording on.
+ *   dram_profile_stop(): recording off (the log stays readable).
+ *   dram_profile_read(out, max): waits for the recorded events (the ONE entry point of the library
+ *     that synchronises), fills out[i].ms, returns the number of records (<= max).
+ * Launches beyond max_records are not recorded (dram_profile_dropped() counts them). */
+enum {
+  DRAM_FAM_CONV_WINO2D = 0, /* fused in-plane Winograd conv, fwd + dgrad          (mfma) */
+  DRAM_FAM_WINO_IN,         /* 3-D Winograd input / gradient tile transforms      (hbm)  */
+  DRAM_FAM_WINO_GEMM_NN,    /* Winograd-domain GEMMs fwd + dgrad, 1x1x1 GEMMs     (mfma) */
+  DRAM_FAM_WINO_OUT,        /* 3-D Winograd output transforms (+ epilogues)       (hbm)  */
+  DRAM_FAM_WINO_GEMM_TN,    /* Winograd-domain weight-gradient GEMMs              (mfma) */
+  DRAM_FAM_WINO_WGRAD_OUT,  /* slab sum + G^T dU G                                (hbm)  */
+  DRAM_FAM_WEIGHT_PACK,     /* weight repacking / weight transforms               (hbm)  */
+  DRAM_FAM_WGRAD_W2D,       /* in-plane Winograd weight gradient (+ reduce)       (mfma) */
+  DRAM_FAM_CONV_IGEMM,      /* direct implicit-GEMM conv, fwd + dgrad             (mfma) */
+  DRAM_FAM_CONV_WGRAD,      /* direct weight gradient (+ reduce)                  (mfma) */
+  DRAM_FAM_STEM,            /* 7x7x7 stem conv fwd + wgrad                        (mfma) */
+  DRAM_FAM_BN,              /* BN apply / backward / statistics folds / add       (hbm)  */
+  DRAM_FAM_POOL_UP,         /* max-pool, upsample+concat, up-projection           (hbm)  */
+  DRAM_FAM_HEAD_LOSS,       /* heads, dRAM losses                                 (hbm)  */
+  DRAM_FAM_OPTIM,           /* fused Adam / SGD                                   (hbm)  */
+  DRAM_FAM_PREP,            /* input transforms                                   (hbm)  */
+  DRAM_FAM_COUNT
+};
+typedef struct DramProfRecord {
+  int32_t family;      /* DRAM_FAM_* */
+  int32_t variant;     /* kernel variant within the family (template instance id; informational) */
+  double mfma_flops;   /* executed MFMA FLOPs of this launch (0 for non-matrix kernels) */
+  double alg_flops;    /* direct-convolution FLOPs (2*M*N*K) the launch stands for; for the 3-D Winograd
+                          pipeline they are booked on the GEMM launch; 0 elsewhere */
+  double hbm_bytes;    /* algorithmic HBM bytes of this launch */
+  float ms;            /* hipEventElapsedTime(start, end) */
+  float pad_;
+} DramProfRecord;
+const char* dram_profile_family_name(int family);
+/* 1 when the family's roof is the matrix pipe, 0 when it is HBM bandwidth */
+int dram_profile_family_is_mfma(int family);
+int dram_profile_start(int max_records);
+int dram_profile_stop(void);
+int dram_profile_dropped(void);
+int dram_profile_read(DramProfRecord* out, int max_records);
 
 /* ------------------------------------------------------------------------- */
 /* Convolution geometry (isotropic stride / padding / dilation, cubic kernel). */
@@ -197,16 +250,21 @@ int dram_stem_bwd_weight(const float* x, const float* dy, float* dw, int B, int 
  *   Used for the BN statistics, BN-backward sums and bias gradients.  In DDP the
  *   caller all-reduces `sums` (SyncBatchNorm, train.py:101) before finalising.
  *   Two-stage for many partials: scratch = dram_reduce_partials_stages(nparts)*R*C doubles
- *   (may be NULL when stages == 1).  Fixed summation order (deterministic). */
+ *   (may be NULL when stages == 1).  Fixed summation order (deterministic).
+ *   has_tail != 0: also writes sums[R*C] = tail (the caller's buffer then has R*C+1 doubles): the
+ *   rank's element count rides behind the sums so that ONE all-reduce gives global sums AND the
+ *   global count (ranks may hold different batch sizes -- torch SyncBatchNorm semantics). */
 int dram_reduce_partials_stages(int nparts);
 int dram_reduce_partials(const float* partial, double* sums, double* scratch, int nparts, int R, int C,
-                         dram_stream_t stream);
+                         double tail, int has_tail, dram_stream_t stream);
 
 /* training: mean/var from sums[2][C] over `count` elements per channel;
  * eval (sums == NULL): running stats.  Writes mean, invstd, scale = gamma*invstd,
  * shift = beta - mean*scale; when update_running != 0 also
  * running = (1-momentum)*running + momentum*{mean, unbiased var}. */
-int dram_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+/* count_dev (device pointer, may be NULL): when given the element count is read from device memory
+ * (the all-reduced tail of dram_reduce_partials) and `count` is ignored -- no host round trip. */
+int dram_bn_finalize(const double* sums, double count, const double* count_dev, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps,
                      int update_running, float* mean, float* invstd, float* scale, float* shift,
                      int C, dram_stream_t stream);
@@ -231,12 +289,12 @@ int dram_bn_bwd_reduce(const float* dz, const float* z, const float* y, const fl
 /* phase 2: dy = gamma*invstd*(g - sums[0]/count - xhat*sums[1]/count).
  * colsum_partial: NULL, or [dram_bn_bwd_apply_nparts(rows, C)][C] -- per-workgroup column sums of dy (the
  * bias gradient of the convolution in front, med3d.py:67/:76/:226, without a pass of its own); nparts < 1
- * => unsupported for this C (C / 4 must divide 256), use dram_colsum. */
+ * => unsupported for this C (C / 4 must divide 256), use dram_colsum.  count_dev: as in dram_bn_finalize. */
 int dram_bn_bwd_apply_nparts(long long rows, int C);
 int dram_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* mean,
                       const float* invstd, const float* gamma, const float* scale, const float* shift,
-                      const double* sums, double count, float* dy, float* colsum_partial, long long rows,
-                      int C, int relu, dram_stream_t stream);
+                      const double* sums, double count, const double* count_dev, float* dy,
+                      float* colsum_partial, long long rows, int C, int relu, dram_stream_t stream);
 /* partial[p][0][c] = sum_rows a[row][c]  (conv-bias gradient) */
 int dram_colsum(const float* a, float* partial, long long rows, int C, dram_stream_t stream);
 

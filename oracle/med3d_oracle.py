@@ -106,38 +106,81 @@ def upsample2_trilinear(x: Tensor) -> Tensor:
 
 
 # ---------------------------------------------------------------------------
+# pinned decisions (test device: removes ReLU / max-pool tie-flips from gradient comparisons)
+# ---------------------------------------------------------------------------
+def relu(x: Tensor, pins: Optional[Dict[str, Tensor]] = None, key: str = "") -> Tensor:
+    """nn.ReLU.  With ``pins`` the on/off decision of every element is FORCED to ``pins[key]``
+    (bool, same shape) instead of being re-derived from ``x > 0``: the piecewise-linear network is
+    evaluated on the linear piece another implementation chose, so an input within rounding of zero
+    cannot land on different sides in the two implementations and the gradient comparison measures
+    arithmetic error only.  ``key`` is the state_dict prefix of the BatchNorm in front of the ReLU."""
+    if pins is None:
+        return F.relu(x)
+    if pins.get("__record__"):          # recording run: plain ReLU, decisions written into `pins`
+        pins[key] = x.detach() > 0
+        return F.relu(x)
+    return x * pins[key].to(x.dtype)
+
+
+def max_pool3(x: Tensor, pins: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """nn.MaxPool3d(3, 2, 1) (med3d.py:206,275).  With ``pins`` the window element taken is
+    ``pins['maxpool']`` (tap index (kz*3+ky)*3+kx into the window starting at 2*o-1, the same
+    encoding ATen's scan order induces) instead of the arg-max."""
+    if pins is None:
+        return F.max_pool3d(x, 3, 2, 1)
+    if pins.get("__record__"):
+        out, idx = F.max_pool3d(x, 3, 2, 1, return_indices=True)
+        D, H, W = x.shape[-3:]
+        zo, yo, xo = torch.meshgrid(*[torch.arange(n) for n in out.shape[-3:]], indexing="ij")
+        kz, ky, kx = idx // (H * W) - (2 * zo - 1), (idx // W) % H - (2 * yo - 1), idx % W - (2 * xo - 1)
+        pins["maxpool"] = ((kz * 3 + ky) * 3 + kx).to(torch.uint8)
+        return out
+    am = pins["maxpool"]
+    Do, Ho, Wo = am.shape[-3:]
+    xp = F.pad(x, (1, 1, 1, 1, 1, 1))
+    out = 0.0
+    for kz in range(3):
+        for ky in range(3):
+            for kx in range(3):
+                tap = (kz * 3 + ky) * 3 + kx
+                sl = xp[:, :, kz:kz + 2 * Do:2, ky:ky + 2 * Ho:2, kx:kx + 2 * Wo:2]
+                out = out + sl * (am == tap).to(x.dtype)
+    return out
+
+
+# ---------------------------------------------------------------------------
 # blocks
 # ---------------------------------------------------------------------------
-def basic_block(x, sd, p, planes, stride, dil, has_ds, train, ns):
+def basic_block(x, sd, p, planes, stride, dil, has_ds, train, ns, pins=None):
     """BasicBlock.forward (med3d.py:129-144)."""
     out = F.conv3d(x, sd[p + ".conv1.weight"], None, stride, dil, dil)
-    out = F.relu(batch_norm(out, sd, p + ".bn1", train, ns))
+    out = relu(batch_norm(out, sd, p + ".bn1", train, ns), pins, p + ".bn1")
     out = F.conv3d(out, sd[p + ".conv2.weight"], None, 1, dil, dil)
     out = batch_norm(out, sd, p + ".bn2", train, ns)
     res = shortcut_a(x, planes, stride) if has_ds else x
-    return F.relu(out + res)
+    return relu(out + res, pins, p + ".bn2")
 
 
-def bottleneck(x, sd, p, planes, stride, dil, has_ds, train, ns):
+def bottleneck(x, sd, p, planes, stride, dil, has_ds, train, ns, pins=None):
     """Bottleneck.forward (med3d.py:164-184)."""
     out = F.conv3d(x, sd[p + ".conv1.weight"])
-    out = F.relu(batch_norm(out, sd, p + ".bn1", train, ns))
+    out = relu(batch_norm(out, sd, p + ".bn1", train, ns), pins, p + ".bn1")
     out = F.conv3d(out, sd[p + ".conv2.weight"], None, stride, dil, dil)
-    out = F.relu(batch_norm(out, sd, p + ".bn2", train, ns))
+    out = relu(batch_norm(out, sd, p + ".bn2", train, ns), pins, p + ".bn2")
     out = F.conv3d(out, sd[p + ".conv3.weight"])
     out = batch_norm(out, sd, p + ".bn3", train, ns)
     res = shortcut_a(x, planes * 4, stride) if has_ds else x
-    return F.relu(out + res)
+    return relu(out + res, pins, p + ".bn3")
 
 
-def up_block(inputs, cats, sd, p, nconv, train, ns):
+def up_block(inputs, cats, sd, p, nconv, train, ns, pins=None):
     """UpsampleConvBlock5d.forward (med3d.py:85-89): up2 -> crop_concat (upsampled
     channels FIRST) -> nconv x (conv3+bias -> BN -> ReLU)."""
     x = crop_concat(upsample2_trilinear(inputs), cats)
     for i in range(nconv):
         q = f"{p}.conv_blocks.{i}"
         x = F.conv3d(x, sd[q + ".0.weight"], sd[q + ".0.bias"], 1, 1)
-        x = F.relu(batch_norm(x, sd, q + ".1", train, ns))
+        x = relu(batch_norm(x, sd, q + ".1", train, ns), pins, q + ".1")
     return x
 
 
@@ -146,12 +189,13 @@ def up_block(inputs, cats, sd, p, nconv, train, ns):
 # ---------------------------------------------------------------------------
 def forward(sd: Dict[str, Tensor], x: Tensor, lungs: Optional[Tensor], arch: str,
             train: bool = True, new_stats: Optional[Dict[str, Tensor]] = None,
-            taps: Optional[Dict[str, Tensor]] = None):
+            taps: Optional[Dict[str, Tensor]] = None, pins: Optional[Dict[str, Tensor]] = None):
     """ResNetSegCls.forward (med3d.py:270-285) / ResNetSegReg.forward (:369-388).
 
     ``sd``: state_dict-keyed tensors (reference key names).  Returns
     (dense_outs, outs) exactly like the reference.  ``taps`` (optional dict)
-    receives named intermediate activations for layer-level tests.
+    receives named intermediate activations for layer-level tests.  ``pins`` (optional) forces
+    every ReLU / max-pool decision (see ``relu`` / ``max_pool3``).
     """
     net, head = split_arch(arch)
     kind, layers = ARCHS[net]
@@ -161,8 +205,8 @@ def forward(sd: Dict[str, Tensor], x: Tensor, lungs: Optional[Tensor], arch: str
     ns = new_stats
 
     x = F.conv3d(x, sd["conv1.weight"], None, 2, 3)                     # :272 / :371
-    x = F.relu(batch_norm(x, sd, "bn1", train, ns))                     # :273-274
-    xp = F.max_pool3d(x, 3, 2, 1)                                       # :275
+    x = relu(batch_norm(x, sd, "bn1", train, ns), pins, "bn1")          # :273-274
+    xp = max_pool3(x, pins)                                             # :275
     feats = []
     h = xp
     inplanes = 64
@@ -170,14 +214,14 @@ def forward(sd: Dict[str, Tensor], x: Tensor, lungs: Optional[Tensor], arch: str
         for bi in range(nblk):
             s = stride if bi == 0 else 1
             has_ds = bi == 0 and (stride != 1 or inplanes != planes * e)  # :244
-            h = blk(h, sd, f"layer{li + 1}.{bi}", planes, s, dil, has_ds, train, ns)
+            h = blk(h, sd, f"layer{li + 1}.{bi}", planes, s, dil, has_ds, train, ns, pins)
             inplanes = planes * e
         feats.append(h)
     x1, x4 = feats[0], feats[3]
-    xup1 = up_block(x4, x1, sd, "us1", 2, train, ns)                    # :280 / :379
-    xup2 = up_block(xup1, x, sd, "us2", 2, train, ns)                   # :281 / :380 (skip = post-ReLU stem)
+    xup1 = up_block(x4, x1, sd, "us1", 2, train, ns, pins)              # :280 / :379
+    xup2 = up_block(xup1, x, sd, "us2", 2, train, ns, pins)             # :281 / :380 (skip = post-ReLU stem)
     xup3 = F.conv3d(xup2, sd["us3.0.weight"], sd["us3.0.bias"], 1, 1)   # :282 / :381
-    xup3 = F.relu(batch_norm(xup3, sd, "us3.1", train, ns))
+    xup3 = relu(batch_norm(xup3, sd, "us3.1", train, ns), pins, "us3.1")
     if taps is not None:
         taps.update(stem=x, xp=xp, x1=feats[0], x2=feats[1], x3=feats[2], x4=x4,
                     xup1=xup1, xup2=xup2, xup3=xup3)

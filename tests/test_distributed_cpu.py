@@ -21,28 +21,57 @@ def _worker(rank, world, port, q):
     try:
         from bodyct_dram_emph_subtype_amd.distributed import DistContext, broadcast_parameters
         torch.manual_seed(100 + rank)
-        ctx = DistContext(bucket_bytes=4096)
-        # --- SyncBN statistics: global mean/var from per-rank [sum, sum^2]
-        x = torch.randn(5, 8, dtype=torch.float64)            # local "activations" [rows, C]
-        sums = torch.stack([x.sum(0), (x * x).sum(0)])
-        gs, cnt = ctx.sync_bn_stats(sums, 5.0)
-        allx = [torch.zeros_like(x) for _ in range(world)]
-        dist.all_gather(allx, x)
+        ctx = DistContext(bucket_bytes=40000)
+        # --- SyncBN statistics: global mean/var from per-rank [sum, sum^2, count]; ranks hold DIFFERENT counts
+        rows = 5 + 2 * rank
+        x = torch.randn(rows, 8, dtype=torch.float64)            # local "activations" [rows, C]
+        flat = torch.cat([x.sum(0), (x * x).sum(0), torch.tensor([float(rows)], dtype=torch.float64)])
+        ctx.all_reduce_stats(flat)                                # in place
+        gs, cnt = flat[:16].view(2, 8), float(flat[16])
+        allx = [torch.zeros(5 + 2 * r, 8, dtype=torch.float64) for r in range(world)]
+        dist.all_gather_object(allx, x)
         full = torch.cat(allx)
-        ok = cnt == 10.0 and torch.allclose(gs[0] / cnt, full.mean(0)) and \
+        ok = cnt == float(full.shape[0]) and torch.allclose(gs[0] / cnt, full.mean(0)) and \
             torch.allclose(gs[1] / cnt - (gs[0] / cnt) ** 2, full.var(0, unbiased=False))
-        ok = ok and torch.equal(sums, torch.stack([x.sum(0), (x * x).sum(0)]))   # input untouched
-        # --- bucketed async gradient mean (several buckets, names arriving in groups)
-        grads = {f"p{i}": torch.randn(300 + 17 * i) for i in range(7)}
-        local = {k: v.clone() for k, v in grads.items()}
-        ctx.grads_ready(grads, ["p6", "p5"])
-        ctx.grads_ready(grads, ["p4", "p3", "p2"])
-        ctx.grads_ready(grads, ["p1", "p0", "p0"])           # duplicate names are ignored
+        w = ctx.all_reduce_stats_async(flat[:16])                 # the backward form: asynchronous, then wait()
+        w.wait()
+        ok = ok and torch.allclose(flat[0:8] / world, full.sum(0))
+        # --- gradient arena: large parameters are written in place (views in parameter order), finished
+        #     ranges are all-reduced asynchronously from the end; small ones travel in one extra bucket
+        params = [(f"p{i}", torch.empty(5000 + 64 * i) if i != 3 else torch.empty(17)) for i in range(7)]
+        ctx.bind(params)
+        n0 = dict(ctx.stats)
+        ctx.begin_backward("cpu")
+        grads, local = {}, {}
+        for name, p in params:
+            out = ctx.grad_out(name)
+            assert (out is None) == (p.numel() < 4096)
+            g = torch.randn(p.shape)
+            local[name] = g.clone()
+            if out is not None and name != "p2":
+                out.copy_(g)                                      # "the wgrad kernel wrote the arena view"
+                grads[name] = out
+            else:
+                grads[name] = g                                   # produced elsewhere: copied in by grads_ready
+        ctx.grads_ready(grads, ["p6", "p5"])                      # 2 x 20 KB >= bucket: launched here
+        launched_early = ctx.stats["grad_allreduce"] - n0["grad_allreduce"]
+        ctx.grads_ready(grads, ["p4", "p3", "p1"])                # p2 missing: range [p4] only is contiguous-final
+        ctx.grads_ready(grads, ["p2", "p0", "p0"])                # duplicate names are ignored
         ctx.finish(grads)
+        ok = ok and launched_early == 1 and ctx.stats["grad_allreduce"] - n0["grad_allreduce"] <= 4
+        lo, nbytes = ctx.last_arena
         for k in local:
             g_all = [torch.zeros_like(local[k]) for _ in range(world)]
             dist.all_gather(g_all, local[k])
             ok = ok and torch.allclose(grads[k], sum(g_all) / world, atol=1e-6)
+            if local[k].numel() >= 4096:
+                ok = ok and lo <= grads[k].data_ptr() < lo + nbytes    # the averaged gradient IS the arena view
+        # an interrupted step must not leak state into the next one
+        ctx.begin_backward("cpu")
+        ctx.grads_ready({"p6": ctx.grad_out("p6")}, ["p6"])
+        ctx.begin_backward("cpu")
+        ok = ok and not ctx._done and not ctx._inflight and ctx._hi == len(ctx._order)
+        ctx.finish({})
         # --- parameter broadcast
         lin = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
         broadcast_parameters(lin)

@@ -14,52 +14,67 @@ import torch.multiprocessing as mp
 from conftest import ROOT, rel_l2
 
 pytestmark = pytest.mark.gpu
-FACTORY, SHAPE = "resnet18segreg", (1, 1, 16, 32, 32)
+SHAPE = (1, 1, 16, 32, 32)
 
 
 def _inputs(rank):
+    """rank 1 holds TWO volumes, rank 0 one: SyncBN must weight by the all-reduced counts."""
     g = torch.Generator().manual_seed(500 + rank)
-    x = torch.randn(*SHAPE, generator=g)
-    lungs = (torch.rand(*SHAPE, generator=g) > 0.3).float()
+    shape = (1 + rank,) + SHAPE[1:]
+    x = torch.randn(*shape, generator=g)
+    lungs = (torch.rand(*shape, generator=g) > 0.3).float()
     return x, lungs
 
 
 def _loss(rank, dense, outs):
+    if outs[0].dim() == 2:      # cls head: logits [B,6], [B,3]
+        return (1.0 + rank) * outs[0][:, 1].sum() - 0.5 * outs[1][:, 2].sum() + 0.1 * (dense[0][:, 0] * dense[1][:, 1]).mean()
     return (1.0 + rank) * outs[0].sum() - 0.5 * outs[1].sum() + 0.1 * (dense[0] * dense[1]).mean()
 
 
-def _worker(rank, world, port, outdir):
+def _build(factory):
+    from bodyct_dram_emph_subtype_amd import med3d
+    kw = dict(n_classes=[6, 3]) if factory.endswith("cls") else {}
+    return getattr(med3d, factory)(**kw)
+
+
+def _worker(rank, world, port, outdir, factory):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from bodyct_dram_emph_subtype_amd import med3d, distributed as ddist
+        from bodyct_dram_emph_subtype_amd import distributed as ddist
         torch.manual_seed(21 + rank)            # different init per rank: attach() must broadcast rank 0's
-        m = med3d.resnet18segreg().to("cuda:0").train()
-        ddist.attach(m, bucket_bytes=8 << 20)
+        m = _build(factory).to("cuda:0").train()
+        ctx = ddist.attach(m, bucket_bytes=8 << 20)
         x, lungs = _inputs(rank)
         dense, outs = m(x.cuda(), lungs.cuda())
         _loss(rank, dense, outs).backward()
         torch.cuda.synchronize()
+        # the large weight gradients autograd hands to p.grad ARE the arena views the kernels wrote and RCCL
+        # reduced in place (no concatenation, no copy-out)
+        lo, nb = ctx.last_arena
+        in_arena = [lo <= p.grad.data_ptr() < lo + nb for n, p in m.named_parameters() if p.numel() >= ddist.SMALL_NUMEL]
         grads = {n: p.grad.cpu() for n, p in m.named_parameters()}
         stats = {k: v.cpu() for k, v in m.state_dict().items() if "running" in k}
         # results go through a file: passing torch tensors through mp.Queue hands over fds that
         # die with the worker process
-        torch.save((rank, grads, stats, [float(o.detach()) for o in outs]), os.path.join(outdir, f"rank{rank}.pt"))
+        torch.save((rank, grads, stats, [o.detach().cpu() for o in outs], all(in_arena), dict(ctx.stats)),
+                   os.path.join(outdir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_engine_matches_ddp_syncbn_emulation():
+@pytest.mark.parametrize("factory", ["resnet18segreg", "resnet50segcls"])
+def test_two_rank_engine_matches_ddp_syncbn_emulation(factory):
     from oracle import med3d_oracle as orc
-    from bodyct_dram_emph_subtype_amd import med3d
     import tempfile
     ctx = mp.get_context("spawn")
-    port = 33500 + (os.getpid() % 2000)
+    port = 33500 + (os.getpid() % 2000) + (7 if factory.endswith("cls") else 0)
     with tempfile.TemporaryDirectory() as outdir:
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, outdir)) for r in range(2)]
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, outdir, factory)) for r in range(2)]
         for p in procs:
             p.start()
         for p in procs:
@@ -67,11 +82,14 @@ def test_two_rank_engine_matches_ddp_syncbn_emulation():
             assert p.exitcode == 0, f"rank process failed with {p.exitcode}"
         res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(2)]
     torch.manual_seed(21)                        # rank 0's initial weights
-    sd = {k: v.clone() for k, v in med3d.resnet18segreg().state_dict().items()}
+    sd = {k: v.clone() for k, v in _build(factory).state_dict().items()}
     xs, ls = zip(*[_inputs(r) for r in range(2)])
-    ref, _ = orc.ddp_emulated_grads(sd, list(xs), list(ls), FACTORY, _loss)
+    ref, _ = orc.ddp_emulated_grads(sd, list(xs), list(ls), factory, _loss)
     ns = {}
-    d, o = orc.forward(sd, torch.cat(xs), torch.cat(ls), FACTORY, train=True, new_stats=ns)
+    d, o = orc.forward(sd, torch.cat(xs), torch.cat(ls), factory, train=True, new_stats=ns)
+    assert res[0][4] and res[1][4], "weight gradients were copied out of the arena"
+    nbn = sum(1 for k in sd if k.endswith("running_mean"))
+    assert res[0][5]["bn_allreduce"] == 2 * nbn, res[0][5]      # one statistic all-reduce per BN layer per direction
     g0, g1 = res[0][1], res[1][1]
     for n in ref:
         assert torch.equal(g0[n], g1[n]), f"ranks disagree on {n}"          # averaged gradients are identical
@@ -84,6 +102,60 @@ def test_two_rank_engine_matches_ddp_syncbn_emulation():
     for k in ("bn1.running_mean", "layer4.1.bn2.running_var", "us3.1.running_var"):
         assert torch.equal(res[0][2][k], res[1][2][k])
         assert np.allclose(res[0][2][k].numpy(), ns[k].numpy(), rtol=1e-3, atol=1e-5), k
-    # per-rank regression scores = the global-batch forward, sliced
+    # per-rank scores = the global-batch forward, sliced (rank 0: sample 0, rank 1: samples 1-2)
+    off = 0
     for r in range(2):
-        assert abs(res[r][3][0] - float(o[0][r])) < 1e-3 and abs(res[r][3][1] - float(o[1][r])) < 1e-3
+        b = 1 + r
+        for i in range(2):
+            ref_o = o[i][off:off + b].detach()
+            assert float((res[r][3][i] - ref_o).abs().max()) < 1e-3 * max(1.0, float(ref_o.abs().max()))
+        off += b
+
+
+def _nccl_world1(port, outdir):
+    """One rank, backend nccl (= RCCL), collectives forced on: ReduceOp.AVG + async_op on arena ranges, float64
+    statistic all-reduces (in-place, sync and async) and their stream ordering run for real on the one GPU
+    of the test box; the result must equal the plain single-GPU step bit for bit (a 1-rank mean is the
+    identity)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from bodyct_dram_emph_subtype_amd import distributed as ddist
+        out = {}
+        for forced in (False, True):
+            torch.manual_seed(4)
+            m = _build("resnet18segreg").to("cuda:0").train()
+            ctx = ddist.attach(m, bucket_bytes=8 << 20, force=forced)
+            assert (m._dist is not None) == forced
+            x, lungs = _inputs(1)
+            for _ in range(2):                       # two steps: the arena / state is rebuilt every backward
+                m.zero_grad(set_to_none=True)
+                dense, outs = m(x.cuda(), lungs.cuda())
+                _loss(0, dense, outs).backward()
+            torch.cuda.synchronize()
+            out[forced] = ({n: p.grad.cpu() for n, p in m.named_parameters()},
+                           {k: v.cpu() for k, v in m.state_dict().items() if "running" in k}, dict(ctx.stats))
+        torch.save(out, os.path.join(outdir, "w1.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world1_forced_collectives_equal_plain_step():
+    import tempfile
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as outdir:
+        p = ctx.Process(target=_nccl_world1, args=(35500 + (os.getpid() % 2000), outdir))
+        p.start()
+        p.join(300)
+        assert p.exitcode == 0, f"nccl world-1 process failed with {p.exitcode}"
+        out = torch.load(os.path.join(outdir, "w1.pt"))
+    (g0, s0, st0), (g1, s1, st1) = out[False], out[True]
+    assert st0["bn_allreduce"] == 0 and st1["bn_allreduce"] == 2 * 2 * 22 and st1["grad_allreduce"] >= 2 * 2
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k

@@ -22,7 +22,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
     assert declared <= exported, declared - exported
     lib = _lib.load()                       # dlopen works without a GPU; no compute call is made
-    assert lib.dram_version() == 1
+    assert lib.dram_version() == _lib.ABI_VERSION
+    assert lib.dram_abi_hash().decode() == _build.abi_hash()
     assert b"gfx950" in lib.dram_build_info()
     # pure host-side entry points (no kernel launch)
     d = _lib.DramConvDesc(2, 16, 32, 32, 64, 16, 32, 32, 128, 3, 1, 4, 4)

@@ -4,19 +4,21 @@
 Tolerances
   * class logits, regression scores, dRAM volumes, loss, BN running stats: max-relative
     <= 1e-3 against the reference's golden values (BASELINE.json north_star, fp32).
-  * gradients: train-mode BN over tiny batches makes the fp32 gradient itself chaotic -- the
-    CPU fp32 oracle is 6e-6 .. 3e-3 away from the same oracle evaluated in fp64, depending on
-    the case (tools/grad_diag.py).  The bar is therefore accuracy-relative: per tensor,
-    err(HIP, fp64) <= 4 * err(CPU fp32, fp64) + 1e-4 + FLIP (relative L2), i.e. the HIP path is
-    as accurate as the reference's own arithmetic; plus gradient norms within 3e-2 of the golden.
-    FLIP: a ReLU input within fp32 rounding of zero can land on either side (measured with
-    tools/mask_diag.py on net_4: ONE of 65,536 decisions in xup3 differs, HIP 6.9e-6 vs 0.0);
-    one flip moves every upstream weight gradient by O(1/sqrt(voxels per channel)): ~1-2e-2 at
-    the 16x32x32 golden sizes (2,048 voxels), so FLIP = 3e-2 there and 5e-3 at 64x128x128.
+  * gradients, DECISION-PINNED: the network is piecewise linear in its ReLU / max-pool decisions and a
+    ReLU input within fp32 rounding of zero can land on either side in two implementations (one such
+    flip moves every upstream gradient by O(1/sqrt(voxels))), which used to force a 3e-2 allowance
+    that could also hide a real halo bug.  Instead the HIP forward exports the decisions it took
+    (engine.forward_decisions: every ReLU mask + the max-pool taps) and the oracle backward is
+    evaluated in fp64 on exactly that linear piece (oracle.forward(pins=...)).  What is left is
+    summation-order rounding only: per-tensor relative L2 <= GRAD_TOL = 1e-4 for every parameter of
+    every golden network, on the library's plan and with the Winograd paths forced.
+    (Gradient norms are additionally compared with the reference's golden values at 3e-2: that
+    number contains the reference's own fp32 decisions and is a sanity bound, not the parity bar.)
   * decoder conv biases sit in front of a BatchNorm: their true gradient is 0, both sides
-    compute rounding noise (SURVEY.md §7 parity traps) -> only |g| is bounded, and parameters
-    after Adam steps (which turn that noise and every near-zero gradient into +-lr moves) are
-    compared at 1e-2 relative L2.
+    compute rounding noise (SURVEY.md §7 parity traps) -> only |g| is bounded.
+  * parameters after two Adam steps: Adam turns every near-zero gradient component into a +-lr move,
+    so the sign noise of those components dominates: relative L2 <= 8e-2 (a smoke bound; the exact
+    optimizer arithmetic is held to 2e-5 against torch.optim in test_fused_adam_and_sgd_match_torch).
 """
 import glob
 import os
@@ -33,7 +35,7 @@ DEV = "cuda:0"
 NET_FILES = sorted(glob.glob(os.path.join(GOLDEN, "net_*.npz")))
 OUT_TOL = 1e-3
 NORM_TOL = 3e-2
-FLIP_TINY, FLIP_MID = 3e-2, 5e-3
+GRAD_TOL = 1e-4          # decision-pinned gradients vs the fp64 oracle, per tensor, relative L2
 
 
 def is_noise_param(name):
@@ -46,6 +48,12 @@ def build(factory, seed):
     torch.manual_seed(seed)
     kw = dict(n_classes=[6, 3]) if factory.endswith("cls") else {}
     return getattr(med3d, factory)(**kw)
+
+
+def pinned_decisions(out):
+    """ReLU masks + max-pool taps of the forward that produced `out` (before its backward frees them)."""
+    from bodyct_dram_emph_subtype_amd.engine import forward_decisions
+    return {k: v.cpu() for k, v in forward_decisions(out.grad_fn.saved_state).items()}
 
 
 def assert_close_rel(a, b, tol, what):
@@ -82,14 +90,14 @@ def test_train_step_matches_reference_golden(path, algo, monkeypatch):
     opt = FusedAdam(m.parameters(), lr=float(g["lr"]))
     names = [n for n, _ in m.named_parameters()]
 
-    # CPU oracle on the same weights in fp32 and fp64 (the accuracy yardstick for gradients)
-    def oracle_grads(dtype):
-        lv = {k: (v.clone().to(dtype).requires_grad_(True) if k in names
-                  else (v.clone().to(dtype) if v.is_floating_point() else v.clone())) for k, v in sd0.items()}
-        od, oo = orc.forward(lv, x.to(dtype), None if lungs is None else lungs.to(dtype), factory, train=True)
-        golden_loss(factory, od, oo, [t.cpu().to(dtype) for t in hw]).backward()
-        return {n: lv[n].grad.double() for n in names}
-    g32, g64 = oracle_grads(torch.float32), oracle_grads(torch.float64)
+    def oracle_grads_pinned(pins):
+        """fp64 oracle backward on the linear piece the HIP forward ran on"""
+        dt = torch.float64
+        lv = {k: (v.clone().to(dt).requires_grad_(True) if k in names
+                  else (v.clone().to(dt) if v.is_floating_point() else v.clone())) for k, v in sd0.items()}
+        od, oo = orc.forward(lv, x.to(dt), None if lungs is None else lungs.to(dt), factory, train=True, pins=pins)
+        golden_loss(factory, od, oo, [t.cpu().to(dt) for t in hw]).backward()
+        return {n: lv[n].grad for n in names}
 
     # eval-mode forward on the initial weights (running stats 0/1), must not touch the buffers
     m.eval()
@@ -104,6 +112,8 @@ def test_train_step_matches_reference_golden(path, algo, monkeypatch):
     for step in range(int(g["meta"][2])):
         opt.zero_grad()
         dense, outs = m(xd, ld)
+        if step == 0:
+            g64 = oracle_grads_pinned(pinned_decisions(dense[0]))
         loss = golden_loss(factory, dense, outs, hw)
         loss.backward()
         if step == 0:
@@ -120,10 +130,10 @@ def test_train_step_matches_reference_golden(path, algo, monkeypatch):
                     assert float(gh.norm()) < 1e-4 and float(g["gnorm"][i]) < 1e-4, n
                     continue
                 assert abs(float(gh.norm()) / float(g["gnorm"][i]) - 1.0) < NORM_TOL, (n, float(gh.norm()))
-                e_hip, e_cpu = rel_l2(gh, g64[n]), rel_l2(g32[n], g64[n])
-                assert e_hip <= 4.0 * e_cpu + 1e-4 + FLIP_TINY, f"{n}: hip-vs-fp64 {e_hip:.2e}, cpu32-vs-fp64 {e_cpu:.2e}"
+                e_hip = rel_l2(gh, g64[n])
+                assert e_hip <= GRAD_TOL, f"{n}: hip vs decision-pinned fp64 oracle {e_hip:.2e}"
                 worst = max(worst, (e_hip, n))
-            print(f"[{factory}] worst gradient error vs fp64 oracle: {worst}")
+            print(f"[{factory}] worst gradient error vs decision-pinned fp64 oracle: {worst}")
             sd = m.state_dict()
             for k in g.files:
                 if k.startswith("stat:"):
@@ -200,13 +210,16 @@ def _synthetic(B, dims, seed):
     return x, lung[None, None].expand(B, 1, D, H, W).contiguous()
 
 
-def test_mid_size_train_step_vs_oracle():
-    """resnet18segreg, 1x64x128x128 (BASELINE configs[0] volume): full dRAM train loss through the
-    fused loss kernels; outputs 1e-3 vs the fp32 oracle, gradients accuracy-relative vs fp64."""
+@pytest.mark.parametrize("factory", ["resnet18segreg", "resnet50segreg"])
+def test_mid_size_train_step_vs_oracle(factory):
+    """1x64x128x128 (BASELINE configs[0] volume), full dRAM train loss through the fused loss kernels, on the
+    library's OWN plan: S2 = 8x16x16 = 2,048 voxels, so for ResNet-50 the 1x1x1 convolutions run as plain
+    GEMMs (plan 3) and the 2304->64 decoder convolution runs the Winograd pipeline unforced.  Outputs 1e-3 vs
+    the fp32 oracle; every gradient <= GRAD_TOL vs the decision-pinned fp64 oracle."""
     from bodyct_dram_emph_subtype_amd import med3d, models
-    factory, dims = "resnet18segreg", (64, 128, 128)
+    dims = (64, 128, 128)
     torch.manual_seed(5)
-    m = med3d.resnet18segreg()
+    m = getattr(med3d, factory)()
     sd0 = {k: v.clone() for k, v in m.state_dict().items()}
     names = [n for n, _ in m.named_parameters()]
     x, lungs = _synthetic(1, dims, 11)
@@ -214,17 +227,20 @@ def test_mid_size_train_step_vs_oracle():
     cle, pse = torch.tensor([3]), torch.tensor([1])
     cw, pw = torch.tensor([0.3]), torch.tensor([0.6])
 
-    def oracle(dtype):
+    def oracle(dtype, pins=None):
         lv = {k: (v.clone().to(dtype).requires_grad_(True) if k in names
                   else (v.clone().to(dtype) if v.is_floating_point() else v.clone())) for k, v in sd0.items()}
-        d, o = orc.forward(lv, x.to(dtype), lungs.to(dtype), factory, train=True)
+        d, o = orc.forward(lv, x.to(dtype), lungs.to(dtype), factory, train=True, pins=pins)
         loss, parts = orc.reg_train_loss(d, o, lungs.to(dtype), ems.to(dtype), cle, pse, cw.to(dtype), pw.to(dtype))
         loss.backward()
         return [t.detach() for t in d], [t.detach() for t in o], loss.detach(), parts, {n: lv[n].grad.double() for n in names}
-    d32, o32, l32, parts32, g32 = oracle(torch.float32)
-    _, _, _, _, g64 = oracle(torch.float64)
+    with torch.no_grad():
+        lv = dict(sd0)
+        d32, o32 = orc.forward(lv, x, lungs, factory, train=True)
+        l32, parts32 = orc.reg_train_loss(d32, o32, lungs, ems, cle, pse, cw, pw)
     md = m.to(DEV).train()
     dd, od = md(x.to(DEV), lungs.to(DEV))
+    pins = pinned_decisions(dd[0])
     loss, parts = models.reg_train_loss(dd, od, lungs.to(DEV), ems.to(DEV), cle.to(DEV), pse.to(DEV), cw.to(DEV),
                                         pw.to(DEV))
     loss.backward()
@@ -235,11 +251,15 @@ def test_mid_size_train_step_vs_oracle():
     for k in parts32:
         assert abs(float(parts[k]) - float(parts32[k])) < OUT_TOL * max(1.0, abs(float(parts32[k]))), k
     assert abs(float(loss) - float(l32)) < OUT_TOL * max(1.0, abs(float(l32)))
+    _, _, _, _, g64 = oracle(torch.float64, pins)
+    worst = (0.0, "")
     for n, p in md.named_parameters():
         if is_noise_param(n):
             continue
-        e_hip, e_cpu = rel_l2(p.grad.double().cpu(), g64[n]), rel_l2(g32[n], g64[n])
-        assert e_hip <= 4.0 * e_cpu + 1e-4 + FLIP_MID, f"{n}: hip-vs-fp64 {e_hip:.2e}, cpu32-vs-fp64 {e_cpu:.2e}"
+        e = rel_l2(p.grad.double().cpu(), g64[n])
+        assert e <= GRAD_TOL, f"{n}: hip vs decision-pinned fp64 oracle {e:.2e}"
+        worst = max(worst, (e, n))
+    print(f"[{factory} 1x64x128x128] worst gradient error vs decision-pinned fp64 oracle: {worst}")
 
 
 @pytest.mark.slow
@@ -261,3 +281,60 @@ def test_full_size_forward_config1_vs_oracle():
         assert_close_rel(a.cpu(), b, OUT_TOL, "class logits")
     assert_close_rel(d1[0].cpu(), d_ref[0], OUT_TOL, "dense cle map")
     assert torch.equal(o1[0], o2[0]) and torch.equal(d1[1], d2[1])      # no atomics anywhere: reproducible
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("config", [1, 2])
+def test_full_size_train_step_vs_oracle(config):
+    """One FULL-SIZE train step of BASELINE configs[1] (resnet18segcls, class-weighted CE) and configs[2]'s
+    network and loss (resnet18segreg, dRAM loss; fp32 here) at 2x1x128x256x256 -- the shapes bench.py times,
+    so the kernels compared are the ones the plan picks at full size (4x4x4 Winograd tilings with >= 512
+    tiles, the two-workgroup in-plane Winograd variant, the slab-split TN GEMMs): loss and pooled outputs at
+    1e-3, and the weight gradients of conv1, layer1.0.conv1, layer2.0.conv1 (strided), layer3.1.conv2,
+    layer4.1.conv2, us1.0, us2.0, us2.1, us3, fcs against the fp32 CPU oracle at <= 5e-3 relative L2."""
+    from bodyct_dram_emph_subtype_amd import med3d, models
+    factory = {1: "resnet18segcls", 2: "resnet18segreg"}[config]
+    torch.manual_seed(0)
+    kw = dict(n_classes=[6, 3]) if factory.endswith("cls") else {}
+    m = getattr(med3d, factory)(**kw)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    names = [n for n, _ in m.named_parameters()]
+    x, lungs = _synthetic(2, (128, 256, 256), 1234)
+    ems = ((x < -1.0).float() * lungs)
+    cle, pse = torch.tensor([4, 1]), torch.tensor([0, 2])
+
+    def loss_of(mod, d, o, dev):
+        t = lambda v: v.to(dev)
+        if config == 1:
+            return mod.cls_train_loss(o, t(cle), t(pse), t(torch.full((6,), 1 / 6)), t(torch.full((3,), 1 / 3)))[0]
+        return mod.reg_train_loss(d, o, t(lungs), t(ems), t(cle), t(pse), t(torch.tensor([0.3, 0.2])),
+                                  t(torch.tensor([0.6, 0.1])))[0]
+
+    md = m.to(DEV).train()
+    dd, od = md(x.to(DEV), lungs.to(DEV))
+    loss = loss_of(models, dd, od, DEV)
+    loss.backward()
+    torch.cuda.synchronize()
+    got = {n: p.grad.cpu() for n, p in md.named_parameters()}
+    outs_hip = [o.detach().cpu() for o in od]
+    loss_hip = float(loss)
+    del md, dd, od, loss
+    torch.cuda.empty_cache()
+
+    lv = {k: (v.requires_grad_(True) if k in names else v) for k, v in sd0.items()}
+    d, o = orc.forward(lv, x, lungs, factory, train=True)
+    l_ref = loss_of(orc, d, o, "cpu")
+    l_ref.backward()
+    for a, b in zip(outs_hip, o):
+        assert_close_rel(a, b.detach(), OUT_TOL, "pooled output")
+    assert abs(loss_hip - float(l_ref)) < OUT_TOL * max(1.0, abs(float(l_ref)))
+    sampled = ["conv1.weight", "layer1.0.conv1.weight", "layer2.0.conv1.weight", "layer3.1.conv2.weight",
+               "layer4.1.conv2.weight", "us1.conv_blocks.0.0.weight", "us2.conv_blocks.0.0.weight",
+               "us2.conv_blocks.1.0.weight", "us3.0.weight", "fcs.0.weight", "fcs.1.weight", "layer4.1.bn2.weight",
+               "bn1.bias"]
+    worst = (0.0, "")
+    for n in sampled:
+        e = rel_l2(got[n], lv[n].grad)
+        worst = max(worst, (e, n))
+        assert e <= 5e-3, f"{n}: full-size gradient vs fp32 oracle {e:.2e}"
+    print(f"[config {config} full size] loss {loss_hip:.6f} vs {float(l_ref):.6f}; worst sampled gradient {worst}")

@@ -169,3 +169,42 @@ def test_oracle_input_transforms_match_reference():
     assert img.shape == tuple(z["image_out"].shape)
     assert torch.equal(img, torch.from_numpy(z["image_out"]))
     assert msk.dtype == torch.bool and torch.equal(msk, torch.from_numpy(z["mask_out"]))
+
+
+@pytest.mark.parametrize("factory,shape", [("resnet18segreg", (2, 1, 16, 16, 24)), ("resnet50segcls", (1, 1, 16, 16, 16))])
+def test_pinned_decisions_reproduce_the_unpinned_oracle(factory, shape):
+    """oracle.forward(pins=...) -- every ReLU / max-pool decision forced -- is the device the GPU gradient
+    tests use to take tie-flips out of the comparison.  Pinned to the decisions the (golden-checked) plain
+    forward itself takes, it must give the same outputs and the same gradients; pinned to a perturbed
+    decision it must follow the pin (the forced piece, not x > 0)."""
+    from bodyct_dram_emph_subtype_amd import med3d
+    torch.manual_seed(2)
+    kw = dict(n_classes=[6, 3]) if factory.endswith("cls") else {}
+    m = getattr(med3d, factory)(**kw)
+    names = [n for n, _ in m.named_parameters()]
+    sd = {k: v.clone().double() if v.is_floating_point() else v.clone() for k, v in m.state_dict().items()}
+    x, lungs = make_inputs(7, shape)
+    x, lungs = x.double(), lungs.double()
+
+    def run(pins):
+        lv = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+        d, o = orc.forward(lv, x, lungs, factory, train=True, pins=pins)
+        loss = sum((t * t).sum() for t in o) + 0.1 * (d[0] * d[0]).mean()
+        loss.backward()
+        return [t.detach() for t in d + o], {n: lv[n].grad for n in names}
+
+    rec = {"__record__": True}
+    out0, g0 = run(rec)
+    rec.pop("__record__")
+    nbn = sum(1 for k in sd if k.endswith("running_mean"))
+    assert len(rec) == nbn + 1 and rec["maxpool"].dtype == torch.uint8 and int(rec["maxpool"].max()) <= 26
+    out_plain, g_plain = run(None)
+    out1, g1 = run(rec)
+    for a, b, c in zip(out0, out1, out_plain):
+        assert torch.equal(a, c) and torch.allclose(a, b, rtol=1e-12, atol=1e-14)
+    for n in names:
+        assert torch.allclose(g1[n], g_plain[n], rtol=1e-9, atol=1e-14), n
+    flipped = dict(rec)
+    flipped["us3.1"] = ~rec["us3.1"]
+    out2, _ = run(flipped)
+    assert not torch.allclose(out2[0], out0[0], rtol=1e-3)

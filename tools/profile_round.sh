@@ -3,13 +3,15 @@
 # passes (FETCH_SIZE / WRITE_SIZE in separate runs) behind profiles/rNN_*.  Output: gpurun_out/prof/.
 #   gpurun --timeout 1200 -- 'bash tools/profile_round.sh'
 # (delete the local gpurun_out/prof first: gpurun merges, it does not mirror)
-# then locally:  python tools/summarize_profile.py gpurun_out/prof profiles r01
+# then locally:  python tools/summarize_profile.py gpurun_out/prof profiles r02
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof
 rm -rf $O && mkdir -p $O
 cd $R
-python bench.py --steps 5 --warmup 2 --detail $O/bench_config1_per_layer.txt > $O/bench_config1.json.log 2>$O/bench_config1.err
+python bench.py --steps 20 --warmup 5 > $O/bench_config1.json.log 2>$O/bench_config1.err
+python bench.py --steps 5 --warmup 2 --no-cpu-baseline --detail $O/bench_config1_per_layer.txt > $O/bench_config1_detail.json.log 2>/dev/null
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --timeline off > $O/bench_config1_no_timeline.json.log 2>/dev/null
 for c in 0 2 3; do python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config$c.json.log 2>/dev/null; done
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config1_under_rocprofv3.json.log 2>/dev/null

@@ -11,20 +11,24 @@ import sys
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
 
-FAMILIES = [("conv_wino2d_kernel", "conv_wino2d"), ("wino_gemm_nn", "wino_gemm_nn"), ("wino_gemm_tn", "wino_gemm_tn"),
-            ("wino_in_kernel", "wino_transforms"), ("wino_in444", "wino_transforms"), ("wino_out_kernel", "wino_transforms"),
-            ("wino_wgrad_out", "wino_transforms"), ("wino_weight", "weight_pack"), ("wino2d_weight", "weight_pack"),
-            ("pack_weight", "weight_pack"), ("conv_igemm", "conv_igemm"), ("conv_wgrad", "conv_wgrad"),
-            ("wgrad_reduce", "conv_wgrad"), ("stem_", "stem"), ("bn_", "bn/elementwise"), ("colreduce", "bn/elementwise"),
-            ("reduce_partials", "bn/elementwise"), ("upcat", "bn/elementwise"), ("maxpool", "bn/elementwise"),
-            ("add_kernel", "bn/elementwise")]
+# kernel name fragment -> family, the library's own taxonomy (include/dram_hip.h DRAM_FAM_*, the names in
+# bench.py's roofline.families); first match wins
+FAMILIES = [("conv_wino2d", "conv_wino2d"), ("wino_in", "wino_in"), ("wino_out_kernel", "wino_out"),
+            ("wino_gemm_nn", "wino_gemm_nn"), ("wino_gemm_tn", "wino_gemm_tn"), ("wino_wgrad_out", "wino_wgrad_out"),
+            ("slab_sum", "wino_wgrad_out"), ("wino_weight", "weight_pack"), ("wino2d_weight", "weight_pack"),
+            ("pack_weight", "weight_pack"), ("conv_wgrad_w2d", "conv_wgrad_w2d"), ("wgrad_w2d_reduce", "conv_wgrad_w2d"),
+            ("conv_igemm", "conv_igemm"), ("conv_wgrad", "conv_wgrad"), ("wgrad_reduce", "conv_wgrad"),
+            ("stem_", "stem"), ("bn_", "bn_elementwise"), ("colreduce", "bn_elementwise"),
+            ("reduce_partials", "bn_elementwise"), ("add_kernel", "bn_elementwise"), ("maxpool", "pool_up"),
+            ("upcat", "pool_up"), ("upproject", "pool_up"), ("head_", "head_loss"), ("segloss", "head_loss"),
+            ("adam_multi", "optim"), ("sgd_multi", "optim"), ("window_stats", "prep"), ("prep_", "prep")]
 
 
 def family(name):
     for key, fam in FAMILIES:
         if key in name:
             return fam
-    return "other"
+    return "torch_glue"
 
 
 def short(name):
@@ -39,6 +43,7 @@ stats = max(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")), key
 shutil.copy(stats, os.path.join(dst, f"{tag}_rocprofv3_kernel_stats_bench_config1.csv"))
 rows = list(csv.DictReader(open(stats)))
 steps = 7.0   # 2 warm-up + 5 timed
+PMC_STEPS = 4.0   # the PMC passes run --steps 3 --warmup 1
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 fam = collections.defaultdict(lambda: [0.0, 0])
 with open(os.path.join(dst, f"{tag}_rocprofv3_summary.txt"), "w") as out:
@@ -61,9 +66,13 @@ with open(os.path.join(dst, f"{tag}_rocprofv3_summary.txt"), "w") as out:
         line = [l for l in open(os.path.join(src, "bench_config1.json.log")) if l.startswith("{")][-1]
         j = json.loads(line)
         rf = j["roofline"]
-        out.write(f"# bench.py (same build, no profiler): {j['value']:.2f} volumes/s, {j['ms_per_step']:.2f} ms/step; "
-                  f"roofline kernel {rf['kernel']}: avg launch {rf['avg_launch_ms'] * 1e3:.1f} us, "
-                  f"{rf['achieved']:.1f} TFLOP/s algorithmic = {rf['frac']:.3f} of {rf['peak']}\n")
+        out.write(f"# bench.py (same build, no rocprofv3): {j['value']:.2f} volumes/s, {j['ms_per_step']:.2f} ms/step; "
+                  f"roofline family {rf['family']}: avg launch {rf['avg_launch_ms'] * 1e3:.1f} us, "
+                  f"{rf['achieved']:.1f} {rf['unit']} = {rf['frac']:.3f} of {rf['peak']}\n")
+        out.write("# bench.py kernel timeline (hipEvent pairs), per family: ms/step, launches/step, avg us, bound, frac\n")
+        for k, r in sorted(rf["families"].items(), key=lambda kv: -kv[1]["ms_per_step"]):
+            out.write(f"#   {k:16s} {r['ms_per_step']:8.3f} {r['launches_per_step']:7.1f} {r['avg_launch_ms'] * 1e3:9.1f}  "
+                      f"{r['bound']:4s} {r['frac']:.3f}\n")
     except Exception as e:  # noqa: BLE001
         out.write(f"# (bench line not parsed: {e})\n")
 
@@ -88,6 +97,12 @@ for fm in sorted(set(fetch) | set(write)):
     rd = fetch[fm].get("FETCH_SIZE", 0.0) * 1024.0 * 2.0 / n
     wr = write[fm].get("WRITE_SIZE", 0.0) * 1024.0 / n
     traffic[fm] = {"launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "total": rd + wr}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bodyct_dram_emph_subtype_amd import _build  # noqa: E402
+traffic["_step_total_bytes"] = sum(v["launches"] * v["total"] for v in traffic.values()) / PMC_STEPS
+traffic["source_hash"] = _build.source_hash()     # bench.py ignores this file when the kernel sources differ
+traffic["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 3 --warmup 1, config 1; "
+                    "FETCH_SIZE x 2 on gfx950 (128-B requests counted as 64 B); per-launch averages per family")
 json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1)
 
 sq, ls = pmc("pmc_sq")
