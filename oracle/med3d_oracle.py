@@ -406,18 +406,25 @@ def sgd_step(p: Tensor, g: Tensor, buf: Optional[Tensor], lr: float, momentum: f
 # ---------------------------------------------------------------------------
 # N-rank DDP + SyncBN emulation
 # ---------------------------------------------------------------------------
-def ddp_emulated_grads(sd, xs: List[Tensor], lungs: List[Optional[Tensor]], arch: str, loss_fn):
+def ddp_emulated_grads(sd, xs: List[Tensor], lungs: List[Optional[Tensor]], arch: str, loss_fn,
+                       pins: Optional[Dict[str, Tensor]] = None, dtype=None):
     """Gradients an N-rank DDP+SyncBatchNorm run produces (train.py:70,100-103):
     BN statistics over the concatenated batch, loss = mean over ranks of the loss
     computed from rank r's slice only.  ``loss_fn(rank, dense_slice, outs_slice)``.
+    ``pins``: forced ReLU / max-pool decisions of the concatenated batch (see ``relu``);
+    ``dtype``: evaluate in this precision (default: the state dict's).
     """
     N = len(xs)
     sizes = [t.shape[0] for t in xs]
     x = torch.cat(xs, 0)
     lg = None if lungs[0] is None else torch.cat(lungs, 0)
+    if dtype is not None:
+        sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+        x = x.to(dtype)
+        lg = None if lg is None else lg.to(dtype)
     leaves = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v)
               for k, v in sd.items()}
-    dense, outs = forward(leaves, x, lg, arch, train=True)
+    dense, outs = forward(leaves, x, lg, arch, train=True, pins=pins)
     total = 0.0
     off = 0
     for r, b in enumerate(sizes):

@@ -11,7 +11,8 @@ Tolerances
     (engine.forward_decisions: every ReLU mask + the max-pool taps) and the oracle backward is
     evaluated in fp64 on exactly that linear piece (oracle.forward(pins=...)).  What is left is
     summation-order rounding only: per-tensor relative L2 <= GRAD_TOL = 1e-4 for every parameter of
-    every golden network, on the library's plan and with the Winograd paths forced.
+    every golden network, on the library's plan and with the Winograd paths forced (where the CPU fp32
+    oracle itself is further than that from fp64 on the same pinned piece: 3x its distance, at most 5e-4).
     (Gradient norms are additionally compared with the reference's golden values at 3e-2: that
     number contains the reference's own fp32 decisions and is a sanity bound, not the parity bar.)
   * decoder conv biases sit in front of a BatchNorm: their true gradient is 0, both sides
@@ -48,6 +49,13 @@ def build(factory, seed):
     torch.manual_seed(seed)
     kw = dict(n_classes=[6, 3]) if factory.endswith("cls") else {}
     return getattr(med3d, factory)(**kw)
+
+
+def grad_tol(e_cpu32):
+    """GRAD_TOL, or -- where the reference's own fp32 arithmetic is further than that from fp64 on the same
+    pinned piece (54 BN layers over 16-voxel statistics in the ResNet-50 fixtures) -- 3x that distance,
+    never more than 5e-4."""
+    return min(max(GRAD_TOL, 3.0 * e_cpu32), 5e-4)
 
 
 def pinned_decisions(out):
@@ -90,9 +98,9 @@ def test_train_step_matches_reference_golden(path, algo, monkeypatch):
     opt = FusedAdam(m.parameters(), lr=float(g["lr"]))
     names = [n for n, _ in m.named_parameters()]
 
-    def oracle_grads_pinned(pins):
-        """fp64 oracle backward on the linear piece the HIP forward ran on"""
-        dt = torch.float64
+    def oracle_grads_pinned(pins, dt=torch.float64):
+        """oracle backward (fp64: the yardstick; fp32: the reference arithmetic's own rounding) on the linear
+        piece the HIP forward ran on"""
         lv = {k: (v.clone().to(dt).requires_grad_(True) if k in names
                   else (v.clone().to(dt) if v.is_floating_point() else v.clone())) for k, v in sd0.items()}
         od, oo = orc.forward(lv, x.to(dt), None if lungs is None else lungs.to(dt), factory, train=True, pins=pins)
@@ -113,7 +121,8 @@ def test_train_step_matches_reference_golden(path, algo, monkeypatch):
         opt.zero_grad()
         dense, outs = m(xd, ld)
         if step == 0:
-            g64 = oracle_grads_pinned(pinned_decisions(dense[0]))
+            pins = pinned_decisions(dense[0])
+            g64, g32 = oracle_grads_pinned(pins), oracle_grads_pinned(pins, torch.float32)
         loss = golden_loss(factory, dense, outs, hw)
         loss.backward()
         if step == 0:
@@ -130,10 +139,11 @@ def test_train_step_matches_reference_golden(path, algo, monkeypatch):
                     assert float(gh.norm()) < 1e-4 and float(g["gnorm"][i]) < 1e-4, n
                     continue
                 assert abs(float(gh.norm()) / float(g["gnorm"][i]) - 1.0) < NORM_TOL, (n, float(gh.norm()))
-                e_hip = rel_l2(gh, g64[n])
-                assert e_hip <= GRAD_TOL, f"{n}: hip vs decision-pinned fp64 oracle {e_hip:.2e}"
-                worst = max(worst, (e_hip, n))
-            print(f"[{factory}] worst gradient error vs decision-pinned fp64 oracle: {worst}")
+                e_hip, e_cpu = rel_l2(gh, g64[n]), rel_l2(g32[n], g64[n])
+                worst = max(worst, (e_hip, e_cpu, n))
+                assert e_hip <= grad_tol(e_cpu), f"{n}: hip vs decision-pinned fp64 oracle {e_hip:.2e} (CPU fp32: {e_cpu:.2e})"
+            print(f"[{factory}{' ' + algo if algo else ''}] worst gradient error vs decision-pinned fp64 oracle "
+                  f"(hip, cpu-fp32, tensor): {worst}")
             sd = m.state_dict()
             for k in g.files:
                 if k.startswith("stat:"):
@@ -210,12 +220,48 @@ def _synthetic(B, dims, seed):
     return x, lung[None, None].expand(B, 1, D, H, W).contiguous()
 
 
+def _oracle_backward(sd0, names, factory, x, lungs, pins, upstream, dtype):
+    """decision-pinned oracle forward, then backward of the GIVEN upstream gradients of (dense0, dense1, out0, out1)"""
+    lv = {k: (v.clone().to(dtype).requires_grad_(True) if k in names
+              else (v.clone().to(dtype) if v.is_floating_point() else v.clone())) for k, v in sd0.items()}
+    d, o = orc.forward(lv, x.to(dtype), None if lungs is None else lungs.to(dtype), factory, train=True, pins=pins)
+    torch.autograd.backward(d + o, [u.to(dtype) for u in upstream])
+    return {n: lv[n].grad.double() for n in names}
+
+
+def _dram_loss_checks(models, dd, od, lungs, ems, cle, pse, cw, pw):
+    """dRAM loss through the fused loss kernels: value + parts at 1e-3 against the fp32 oracle evaluated at the
+    SAME dense maps / scores; its gradient FIELDS (what the loss kernels hand to the network backward) against
+    fp64 at the same point.  At a random initialisation sigmoid(.) ~ 0.5 puts cle+pse on the clamp(., 0, 1) kink
+    of models.py:527 and BCE's 1/(1-p) (metrics.py:18-24, eps = 1e-6) makes the reference's own fp32 gradient
+    field ~1e-2 from fp64 there (tools/grad_pairs.py), so the per-voxel fields are compared where that term is
+    conditioned (|1 - (cle+pse)| > 1e-3): relative L2 <= 2e-4; the pooled-score gradients at 1e-5."""
+    loss, parts = models.reg_train_loss(dd, od, lungs.to(DEV), ems.to(DEV), cle.to(DEV), pse.to(DEV), cw.to(DEV), pw.to(DEV))
+    ups = [u.detach().cpu() for u in torch.autograd.grad(loss, dd + od, retain_graph=True)]
+    at = [t.detach().cpu() for t in dd + od]
+    l32, parts32 = orc.reg_train_loss(at[:2], at[2:], lungs, ems, cle, pse, cw, pw)
+    for k in parts32:
+        assert abs(float(parts[k]) - float(parts32[k])) < OUT_TOL * max(1.0, abs(float(parts32[k]))), k
+    assert abs(float(loss) - float(l32)) < OUT_TOL * max(1.0, abs(float(l32)))
+    leaf = [t.double().requires_grad_(True) for t in at]
+    orc.reg_train_loss(leaf[:2], leaf[2:], lungs.double(), ems.double(), cle, pse, cw.double(), pw.double())[0].backward()
+    ok = ((at[0] + at[1]).double() - 1.0).abs() > 1e-3
+    for i in (0, 1):
+        assert rel_l2(ups[i][ok], leaf[i].grad[ok]) <= 2e-4, f"dense-gradient field {i}"
+    for i in (2, 3):
+        assert rel_l2(ups[i], leaf[i].grad) <= 1e-5, f"score gradient {i}"
+    return loss, ups
+
+
 @pytest.mark.parametrize("factory", ["resnet18segreg", "resnet50segreg"])
 def test_mid_size_train_step_vs_oracle(factory):
     """1x64x128x128 (BASELINE configs[0] volume), full dRAM train loss through the fused loss kernels, on the
     library's OWN plan: S2 = 8x16x16 = 2,048 voxels, so for ResNet-50 the 1x1x1 convolutions run as plain
-    GEMMs (plan 3) and the 2304->64 decoder convolution runs the Winograd pipeline unforced.  Outputs 1e-3 vs
-    the fp32 oracle; every gradient <= GRAD_TOL vs the decision-pinned fp64 oracle."""
+    GEMMs (plan 3) and the 2304->64 decoder convolution runs the Winograd pipeline unforced.
+    Outputs 1e-3 vs the fp32 oracle; loss + its gradient fields (see _dram_loss_checks); then the network backward
+    of exactly those fields: HIP vs the decision-pinned fp64 oracle given the same upstream, every parameter
+    <= max(GRAD_TOL, 3 x the CPU fp32 oracle's own distance), at most 2e-3 (the outlier-dominated upstream field
+    makes the weight-gradient sums cancel: CPU fp32 itself sits 2e-5 (R18) / 3e-4 (R50) from fp64)."""
     from bodyct_dram_emph_subtype_amd import med3d, models
     dims = (64, 128, 128)
     torch.manual_seed(5)
@@ -226,72 +272,43 @@ def test_mid_size_train_step_vs_oracle(factory):
     ems = ((x < -1.0).float() * lungs)
     cle, pse = torch.tensor([3]), torch.tensor([1])
     cw, pw = torch.tensor([0.3]), torch.tensor([0.6])
-
-    def oracle(dtype, pins=None):
-        lv = {k: (v.clone().to(dtype).requires_grad_(True) if k in names
-                  else (v.clone().to(dtype) if v.is_floating_point() else v.clone())) for k, v in sd0.items()}
-        d, o = orc.forward(lv, x.to(dtype), lungs.to(dtype), factory, train=True, pins=pins)
-        loss, parts = orc.reg_train_loss(d, o, lungs.to(dtype), ems.to(dtype), cle, pse, cw.to(dtype), pw.to(dtype))
-        loss.backward()
-        return [t.detach() for t in d], [t.detach() for t in o], loss.detach(), parts, {n: lv[n].grad.double() for n in names}
     with torch.no_grad():
-        lv = dict(sd0)
-        d32, o32 = orc.forward(lv, x, lungs, factory, train=True)
-        l32, parts32 = orc.reg_train_loss(d32, o32, lungs, ems, cle, pse, cw, pw)
+        d32, o32 = orc.forward(dict(sd0), x, lungs, factory, train=True)
     md = m.to(DEV).train()
     dd, od = md(x.to(DEV), lungs.to(DEV))
     pins = pinned_decisions(dd[0])
-    loss, parts = models.reg_train_loss(dd, od, lungs.to(DEV), ems.to(DEV), cle.to(DEV), pse.to(DEV), cw.to(DEV),
-                                        pw.to(DEV))
-    loss.backward()
     for a, b in zip(od, o32):
         assert_close_rel(a.detach().cpu(), b, OUT_TOL, "regression score")
     for a, b in zip(dd, d32):
         assert_close_rel(a.detach().cpu(), b, OUT_TOL, "dRAM volume")
-    for k in parts32:
-        assert abs(float(parts[k]) - float(parts32[k])) < OUT_TOL * max(1.0, abs(float(parts32[k]))), k
-    assert abs(float(loss) - float(l32)) < OUT_TOL * max(1.0, abs(float(l32)))
-    _, _, _, _, g64 = oracle(torch.float64, pins)
-    worst = (0.0, "")
+    loss, ups = _dram_loss_checks(models, dd, od, lungs, ems, cle, pse, cw, pw)
+    loss.backward()
+    g64 = _oracle_backward(sd0, names, factory, x, lungs, pins, ups, torch.float64)
+    g32 = _oracle_backward(sd0, names, factory, x, lungs, pins, ups, torch.float32)
+    worst = (0.0, 0.0, "")
     for n, p in md.named_parameters():
         if is_noise_param(n):
             continue
-        e = rel_l2(p.grad.double().cpu(), g64[n])
-        assert e <= GRAD_TOL, f"{n}: hip vs decision-pinned fp64 oracle {e:.2e}"
-        worst = max(worst, (e, n))
-    print(f"[{factory} 1x64x128x128] worst gradient error vs decision-pinned fp64 oracle: {worst}")
-
-
-@pytest.mark.slow
-def test_full_size_forward_config1_vs_oracle():
-    """BASELINE configs[1] at full size (resnet18segcls, 2x1x128x256x256): class logits and the
-    dense maps against the CPU oracle forward; plus determinism (bitwise equal re-run)."""
-    from bodyct_dram_emph_subtype_amd import med3d
-    torch.manual_seed(0)
-    m = med3d.resnet18segcls(n_classes=[6, 3])
-    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
-    x, lungs = _synthetic(2, (128, 256, 256), 1234)
-    with torch.no_grad():
-        d_ref, o_ref = orc.forward(sd0, x, lungs, "resnet18segcls", train=True)
-    md = m.to(DEV).train()
-    with torch.no_grad():
-        d1, o1 = md(x.to(DEV), lungs.to(DEV))
-        d2, o2 = md(x.to(DEV), lungs.to(DEV))
-    for a, b in zip(o1, o_ref):
-        assert_close_rel(a.cpu(), b, OUT_TOL, "class logits")
-    assert_close_rel(d1[0].cpu(), d_ref[0], OUT_TOL, "dense cle map")
-    assert torch.equal(o1[0], o2[0]) and torch.equal(d1[1], d2[1])      # no atomics anywhere: reproducible
+        e, e_cpu = rel_l2(p.grad.double().cpu(), g64[n]), rel_l2(g32[n], g64[n])
+        worst = max(worst, (e, e_cpu, n))
+        assert e <= min(max(GRAD_TOL, 3.0 * e_cpu), 2e-3), f"{n}: hip {e:.2e} vs decision-pinned fp64 oracle (CPU fp32: {e_cpu:.2e})"
+    print(f"[{factory} 1x64x128x128, dRAM loss] worst gradient error vs decision-pinned fp64 oracle (hip, cpu-fp32, tensor): {worst}")
 
 
 @pytest.mark.slow
 @pytest.mark.parametrize("config", [1, 2])
 def test_full_size_train_step_vs_oracle(config):
-    """One FULL-SIZE train step of BASELINE configs[1] (resnet18segcls, class-weighted CE) and configs[2]'s
-    network and loss (resnet18segreg, dRAM loss; fp32 here) at 2x1x128x256x256 -- the shapes bench.py times,
-    so the kernels compared are the ones the plan picks at full size (4x4x4 Winograd tilings with >= 512
-    tiles, the two-workgroup in-plane Winograd variant, the slab-split TN GEMMs): loss and pooled outputs at
-    1e-3, and the weight gradients of conv1, layer1.0.conv1, layer2.0.conv1 (strided), layer3.1.conv2,
-    layer4.1.conv2, us1.0, us2.0, us2.1, us3, fcs against the fp32 CPU oracle at <= 5e-3 relative L2."""
+    """One FULL-SIZE train step of BASELINE configs[1] (resnet18segcls, class-weighted CE) and of configs[2]'s
+    network and loss (resnet18segreg, dRAM loss; fp32 storage here; batch 1) at [2|1]x1x128x256x256 -- the shapes
+    bench.py times, so the kernels compared are the ones the plan picks at full size (4x4x4 Winograd tilings with >= 512
+    tiles, the two-workgroup in-plane Winograd variant, the slab-split TN GEMMs, the tiled upsample+concat).
+    Yardstick: the fp64 oracle on the HIP forward's own ReLU / max-pool decisions.  (The fp32 CPU oracle is not
+    usable as one at this size: its weight-gradient sums over 10^6-10^7 voxels sit 1e-3 ... 1.4e-1 from fp64
+    -- us3.0.weight 14 % -- where the HIP path, with double-precision statistic folds and blocked fp32
+    accumulation, sits at 2-6e-5; tools/grad_pairs.py)
+    Pooled outputs, dense maps and loss at 1e-3; the upstream gradients of (dense, outs) the loss hands back are
+    propagated by both sides and EVERY parameter gradient must agree to 2e-4 relative L2; a second forward must
+    reproduce the first bit for bit (no atomics anywhere)."""
     from bodyct_dram_emph_subtype_amd import med3d, models
     factory = {1: "resnet18segcls", 2: "resnet18segreg"}[config]
     torch.manual_seed(0)
@@ -299,42 +316,51 @@ def test_full_size_train_step_vs_oracle(config):
     m = getattr(med3d, factory)(**kw)
     sd0 = {k: v.clone() for k, v in m.state_dict().items()}
     names = [n for n, _ in m.named_parameters()]
-    x, lungs = _synthetic(2, (128, 256, 256), 1234)
+    B = 2 if config == 1 else 1          # config 2 at batch 1: halves the fp64 oracle's time (GPU-test budget)
+    x, lungs = _synthetic(B, (128, 256, 256), 1234)
     ems = ((x < -1.0).float() * lungs)
-    cle, pse = torch.tensor([4, 1]), torch.tensor([0, 2])
-
-    def loss_of(mod, d, o, dev):
-        t = lambda v: v.to(dev)
-        if config == 1:
-            return mod.cls_train_loss(o, t(cle), t(pse), t(torch.full((6,), 1 / 6)), t(torch.full((3,), 1 / 3)))[0]
-        return mod.reg_train_loss(d, o, t(lungs), t(ems), t(cle), t(pse), t(torch.tensor([0.3, 0.2])),
-                                  t(torch.tensor([0.6, 0.1])))[0]
+    cle, pse = torch.tensor([4, 1])[:B], torch.tensor([0, 2])[:B]
 
     md = m.to(DEV).train()
+    with torch.no_grad():
+        d_first, o_first = md(x.to(DEV), lungs.to(DEV))
+    for k in [k for k in sd0 if "running" in k or "num_batches" in k]:      # undo the running-stat update of that run
+        md.state_dict()[k].copy_(sd0[k])
     dd, od = md(x.to(DEV), lungs.to(DEV))
-    loss = loss_of(models, dd, od, DEV)
+    assert torch.equal(o_first[0], od[0]) and torch.equal(d_first[1], dd[1])
+    del d_first, o_first
+    pins = pinned_decisions(dd[0])
+    outs_hip = [o.detach().cpu() for o in od]
+    dense_hip = [d.detach().cpu() for d in dd]
+    if config == 1:
+        cwt, pwt = torch.full((6,), 1 / 6), torch.full((3,), 1 / 3)
+        loss = models.cls_train_loss(od, cle.to(DEV), pse.to(DEV), cwt.to(DEV), pwt.to(DEV))[0]
+        ups = [None, None] + [u.detach().cpu() for u in torch.autograd.grad(loss, od, retain_graph=True)]
+        l_ref = orc.cls_train_loss(outs_hip, cle, pse, cwt, pwt)[0]
+        assert abs(float(loss) - float(l_ref)) < OUT_TOL * max(1.0, abs(float(l_ref)))
+    else:
+        loss, ups = _dram_loss_checks(models, dd, od, lungs, ems, cle, pse, torch.tensor([0.3, 0.2])[:B],
+                                      torch.tensor([0.6, 0.1])[:B])
     loss.backward()
     torch.cuda.synchronize()
-    got = {n: p.grad.cpu() for n, p in md.named_parameters()}
-    outs_hip = [o.detach().cpu() for o in od]
+    got = {n: p.grad.double().cpu() for n, p in md.named_parameters()}
     loss_hip = float(loss)
     del md, dd, od, loss
     torch.cuda.empty_cache()
 
-    lv = {k: (v.requires_grad_(True) if k in names else v) for k, v in sd0.items()}
-    d, o = orc.forward(lv, x, lungs, factory, train=True)
-    l_ref = loss_of(orc, d, o, "cpu")
-    l_ref.backward()
-    for a, b in zip(outs_hip, o):
-        assert_close_rel(a, b.detach(), OUT_TOL, "pooled output")
-    assert abs(loss_hip - float(l_ref)) < OUT_TOL * max(1.0, abs(float(l_ref)))
-    sampled = ["conv1.weight", "layer1.0.conv1.weight", "layer2.0.conv1.weight", "layer3.1.conv2.weight",
-               "layer4.1.conv2.weight", "us1.conv_blocks.0.0.weight", "us2.conv_blocks.0.0.weight",
-               "us2.conv_blocks.1.0.weight", "us3.0.weight", "fcs.0.weight", "fcs.1.weight", "layer4.1.bn2.weight",
-               "bn1.bias"]
+    dt = torch.float64
+    lv = {k: (v.to(dt).requires_grad_(True) if k in names else (v.to(dt) if v.is_floating_point() else v))
+          for k, v in sd0.items()}
+    d, o = orc.forward(lv, x.to(dt), lungs.to(dt), factory, train=True, pins=pins)
+    for a, b in zip(outs_hip + dense_hip, o + d):
+        assert_close_rel(a, b.detach(), OUT_TOL, "pooled output / dense map")
+    pairs = [(t, u.to(dt)) for t, u in zip(d + o, ups) if u is not None]
+    torch.autograd.backward([t for t, _ in pairs], [u for _, u in pairs])
     worst = (0.0, "")
-    for n in sampled:
+    for n in names:
+        if is_noise_param(n):
+            continue
         e = rel_l2(got[n], lv[n].grad)
         worst = max(worst, (e, n))
-        assert e <= 5e-3, f"{n}: full-size gradient vs fp32 oracle {e:.2e}"
-    print(f"[config {config} full size] loss {loss_hip:.6f} vs {float(l_ref):.6f}; worst sampled gradient {worst}")
+        assert e <= 2e-4, f"{n}: full-size gradient vs decision-pinned fp64 oracle {e:.2e}"
+    print(f"[config {config} full size] loss {loss_hip:.6f}; worst gradient vs decision-pinned fp64 oracle {worst}")
