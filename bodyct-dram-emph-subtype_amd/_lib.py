@@ -27,6 +27,11 @@ class DramTensorRef(ctypes.Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", ctypes.c_int64)]
 
 
+class DramAugment(ctypes.Structure):
+    _fields_ = [("flags", ctypes.c_int32), ("n_boxes", ctypes.c_int32), ("boxes", (ctypes.c_int32 * 6) * 10),
+                ("flip_axes", ctypes.c_int32), ("sigma", c_float), ("box_lo", c_float * 3), ("box_hi", c_float * 3)]
+
+
 class DramProfRecord(ctypes.Structure):
     _fields_ = [("family", ctypes.c_int32), ("variant", ctypes.c_int32), ("mfma_flops", c_double),
                 ("alg_flops", c_double), ("hbm_bytes", c_double), ("ms", c_float), ("pad_", c_float)]
@@ -108,12 +113,18 @@ SIGNATURES = {
     "dram_upproject_nblk": (I, [LL]),
     "dram_upproject": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "dram_adam_multi": (I, [P, P, I, F, F, F, F, F, F, F, F, P]),
+    "dram_adam_multi_dev": (I, [P, P, I, P, P]),
     "dram_sgd_multi": (I, [P, P, I, F, F, F, I, F, P]),
     "dram_window_stats_nblk": (I, [LL]),
     "dram_window_stats": (I, [P, P, LL, F, F, P]),
     "dram_prep_image": (I, [P, P, P, P, I, I, I, I, I, I, F, F, P]),
     "dram_prep_mask": (I, [P, P, P, I, I, I, I, I, I, P]),
     "dram_add": (I, [P, P, P, LL, P]),
+    "dram_resample_paste": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "dram_minmax_nblk": (I, [LL]),
+    "dram_minmax": (I, [P, P, LL, P]),
+    "dram_augment_image": (I, [P, P, P, P, I, I, I, P, P]),
+    "dram_augment_mask": (I, [P, P, I, I, I, P, P]),
 }
 
 OPT_CHUNK = 16384

@@ -7,10 +7,9 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void adam_multi_kernel(const DramTensorRef* __restrict__ table,
-                                                         const DramChunkRef* __restrict__ chunks, float lr, float b1,
-                                                         float b2, float eps, float wd, float bc1, float bc2,
-                                                         float gscale) {
+__device__ __forceinline__ void adam_chunk(const DramTensorRef* __restrict__ table,
+                                           const DramChunkRef* __restrict__ chunks, float lr, float b1, float b2,
+                                           float eps, float wd, float bc1, float bc2, float gscale) {
   const DramChunkRef ch = chunks[blockIdx.x];
   const DramTensorRef t = table[ch.tensor];
   const long n = t.n - ch.offset < DRAM_OPT_CHUNK ? t.n - ch.offset : DRAM_OPT_CHUNK;
@@ -63,6 +62,29 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const DramTensorRef* __
   }
 }
 
+__global__ __launch_bounds__(256) void adam_multi_kernel(const DramTensorRef* __restrict__ table,
+                                                         const DramChunkRef* __restrict__ chunks, float lr, float b1,
+                                                         float b2, float eps, float wd, float bc1, float bc2,
+                                                         float gscale) {
+  adam_chunk(table, chunks, lr, b1, b2, eps, wd, bc1, bc2, gscale);
+}
+
+// Graph-replayable form: every hyper-parameter AND the step count live in device memory, so a captured
+// hipGraph of the train step stays valid while lr decays (ExponentialLR) and the bias corrections change.
+// hyper = [lr, b1, b2, eps, wd, grad_scale, step]; step is advanced by adam_advance_kernel first.
+__global__ void adam_advance_kernel(float* __restrict__ hyper) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) hyper[6] += 1.f;
+}
+__global__ __launch_bounds__(256) void adam_multi_dev_kernel(const DramTensorRef* __restrict__ table,
+                                                             const DramChunkRef* __restrict__ chunks,
+                                                             const float* __restrict__ hyper) {
+  const float b1 = hyper[1], b2 = hyper[2];
+  const double t = (double)hyper[6];
+  // torch: bias_correction = 1 - beta ** step, evaluated in double on the host
+  const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2 = (float)(1.0 - pow((double)b2, t));
+  adam_chunk(table, chunks, hyper[0], b1, b2, hyper[3], hyper[4], bc1, bc2, hyper[5]);
+}
+
 __global__ __launch_bounds__(256) void sgd_multi_kernel(const DramTensorRef* __restrict__ table,
                                                         const DramChunkRef* __restrict__ chunks, float lr, float mom,
                                                         float wd, int first, float gscale) {
@@ -94,6 +116,18 @@ extern "C" int dram_adam_multi(const DramTensorRef* table, const DramChunkRef* c
   DramProf prof(DRAM_FAM_OPTIM, 0, 0.0, 28.0 * (double)nchunks * 16384.0, (hipStream_t)stream);
   hipLaunchKernelGGL(adam_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, chunks, lr, beta1,
                      beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_adam_multi_dev(const DramTensorRef* table, const DramChunkRef* chunks, int nchunks, float* hyper,
+                                   dram_stream_t stream) {
+  if (!table || !chunks || nchunks < 1 || !hyper) return DRAM_ERR_BAD_ARG;
+  DramProf prof(DRAM_FAM_OPTIM, 2, 0.0, 28.0 * (double)nchunks * 16384.0, (hipStream_t)stream);
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper);
+  DRAM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(adam_multi_dev_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, chunks,
+                     (const float*)hyper);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

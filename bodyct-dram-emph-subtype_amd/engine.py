@@ -114,7 +114,10 @@ class Engine:
         w = st.P[wname]
         B, D, H, W, Cin = x.shape
         g = ConvGeom(B, D, H, W, Cin, w.shape[0], k, stride, pad, dil)
-        wf, wb = ops.pack_conv_weight(w, True, st.need_grad, g)
+        if st.need_grad:
+            wf, wb = ops.pack_conv_weight(w, True, True, g)
+        else:                                           # inference: packed / transformed once per weight version
+            wf, wb = ops.packed_forward_weight(w, g), None
         y, sp, v = ops.conv3d_fwd_keep(x, wf, st.P[bname] if bname else None, g, st.training, st.need_grad)
         z, mean, invstd, count, ss = self._bn_fwd(st, y, sp, bnp, residual, rs)
         c = None

@@ -64,9 +64,15 @@ def _band_table(ratio_map, tightness=1.0):
 _CLE_BANDS, _PSE_BANDS = _band_table(CLE_RATIO_MAP), _band_table(PSE_RATIO_MAP)
 
 
+_BANDS_DEV: Dict[tuple, torch.Tensor] = {}
+
+
 def generate_regression_labels(cls_targets: torch.Tensor, which: str) -> torch.Tensor:
-    tab = _CLE_BANDS if which == "cle" else _PSE_BANDS
-    return tab.to(cls_targets.device)[cls_targets.long()]
+    key = (which, cls_targets.device)
+    tab = _BANDS_DEV.get(key)
+    if tab is None:      # one host->device copy per device (none per step: the step stays graph-capturable)
+        tab = _BANDS_DEV[key] = (_CLE_BANDS if which == "cle" else _PSE_BANDS).to(cls_targets.device)
+    return tab[cls_targets.long()]
 
 
 def interval_regression_loss(outs, reg_targets, weight_factors):
@@ -148,6 +154,19 @@ def cls_train_loss(cls_outs, cle_labels, pse_labels, cle_cw, pse_cw):
     return loss_cle + loss_pse, dict(loss_cle=loss_cle, loss_pse=loss_pse)
 
 
+def update_class_weights(weights: torch.Tensor, y_true: torch.Tensor, y_pred: torch.Tensor) -> torch.Tensor:
+    """models.py:367-377: w <- w * (1 - per-class accuracy), renormalised; the accuracy is diag / row sums of the
+    confusion matrix over the labels that occur (sklearn.metrics.confusion_matrix semantics)."""
+    labels = torch.unique(torch.cat([y_true, y_pred]))
+    if labels.numel() != weights.numel():
+        raise ValueError(f"class-weight update: {labels.numel()} classes occur, {weights.numel()} weights "
+                         "(the reference's element-wise product fails the same way)")
+    hit = (y_true[None, :] == labels[:, None])
+    acc = (hit & (y_pred[None, :] == labels[:, None])).sum(1).double() / hit.sum(1).double()
+    w = weights.double().to(acc.device) * (1.0 - acc)
+    return (w / w.sum()).to(weights.dtype).cpu()
+
+
 class _ScanModule(_Base):
     def __init__(self, args):
         self.args = args
@@ -171,6 +190,49 @@ class _ScanModule(_Base):
 
     def test_step(self, batch, batch_idx):
         return self.shared_step(batch, batch_idx, TEST_PHASE)
+
+    # ---- epoch end (models.py:287-317 / :603-633, :367-379) ------------------------------------------------
+    def training_epoch_end(self, step_outputs):
+        return self.shared_epoch_end(step_outputs, TRAIN_PHASE)
+
+    def validation_epoch_end(self, step_outputs):
+        return self.shared_epoch_end(step_outputs, VALID_PHASE)
+
+    def test_epoch_end(self, step_outputs):
+        return self.shared_epoch_end(step_outputs, TEST_PHASE)
+
+    def shared_epoch_end(self, step_outputs, phase):
+        """Concatenate the step outputs, all-gather them over the ranks (utils.cat_all_gather), take the
+        accuracies over everything gathered (models.py:300-301: BEFORE de-duplication), drop the samples the
+        distributed sampler repeated (first occurrence per index, :303-309) and, in the train phase, rescale the
+        per-class loss weights by (1 - per-class accuracy) (:367-379).  Plots / csv dumps are out of scope;
+        returns what they would have been fed."""
+        from .utils import cat_all_gather
+        with torch.no_grad():
+            cols = {k: cat_all_gather(torch.cat([o[k] for o in step_outputs]))
+                    for k in ("pred_cle_labels", "cle_labels", "pred_pse_labels", "pse_labels")}
+            indices = cat_all_gather(torch.cat([o["index"] for o in step_outputs]))
+            acc_cle = (cols["pred_cle_labels"] == cols["cle_labels"]).float().mean()
+            acc_pse = (cols["pred_pse_labels"] == cols["pse_labels"]).float().mean()
+            order = torch.argsort(indices, stable=True)          # np.unique(indices, return_index=True)
+            s = indices[order]
+            first = torch.ones_like(s, dtype=torch.bool)
+            first[1:] = s[1:] != s[:-1]
+            keep = order[first]
+            cols = {k: v[keep] for k, v in cols.items()}
+            if phase == TRAIN_PHASE:
+                for name in ("cle", "pse"):
+                    w = getattr(self, f"{name}_class_weights")
+                    seen = torch.unique(torch.cat([cols[f"{name}_labels"], cols[f"pred_{name}_labels"]])).numel()
+                    if seen == w.numel():
+                        setattr(self, f"{name}_class_weights",
+                                update_class_weights(w, cols[f"{name}_labels"], cols[f"pred_{name}_labels"]))
+                    else:       # the reference's element-wise product raises here (tiny epochs); keep the weights
+                        import logging
+                        logging.warning(f"{name}: only {seen} of {w.numel()} classes occurred this epoch; class weights kept")
+            self.log(f"epoch_{phase}_acc_cle", acc_cle, on_step=False, on_epoch=True)
+            self.log(f"epoch_{phase}_acc_pse", acc_pse, on_step=False, on_epoch=True)
+            return dict(indices=indices[keep], acc_cle=acc_cle, acc_pse=acc_pse, **cols)
 
     def configure_optimizers(self):
         """models.py:381-394 / :685-698: Adam(lr=args.lr) + ExponentialLR(gamma=0.95)."""

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import os
 import threading
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
@@ -261,10 +262,56 @@ def _workspace(nbytes: int, device) -> Tensor:
     return ws
 
 
+# environment switches the library's plan functions read (tests flip them between cases): part of the plan-cache key
+_PLAN_ENV = ("DRAM_CONV_ALGO", "DRAM_WINO_TILING", "DRAM_MATH", "DRAM_W2D_V", "DRAM_IGEMM_V", "DRAM_IGEMM_V3_FORCE",
+             "DRAM_WGRAD_V")
+
+
+class ConvPlan:
+    """Everything the host needs to know about one convolution geometry, asked from the library ONCE per
+    (geometry, plan-relevant environment): forward / weight-gradient algorithm, packed-weight leading
+    dimensions, statistic rows, workspace sizes, cached-transform size -- ~12 host calls into the library
+    (each of which re-derives tilings and reads the environment) instead of that many per launch."""
+    __slots__ = ("desc", "dref", "algo", "walgo", "taps_f", "taps_b", "stat_rows", "ws_fwd", "ws_bwd", "ws_wgrad",
+                 "v_elems", "ws_direct_wgrad")
+
+    def __init__(self, g: "ConvGeom"):
+        L = _L()
+        self.desc = g.desc()
+        self.dref = d = ctypes.byref(self.desc)
+        self.algo = int(L.dram_conv_algo(d))
+        self.walgo = int(L.dram_conv_wgrad_algo(d))
+        if self.algo == 1:
+            self.taps_f, self.taps_b = int(L.dram_wino_num_points(d)), int(L.dram_wino_num_points_bwd(d))
+        else:
+            self.taps_f = self.taps_b = 48 if self.algo == 2 else g.taps
+        self.stat_rows = int({0: L.dram_conv_num_mtiles, 1: L.dram_wino_num_stat_rows, 2: L.dram_wino2d_num_stat_rows,
+                              3: L.dram_conv1x1_num_stat_rows}[self.algo](d))
+        self.ws_fwd = int(L.dram_wino_workspace(d, 0)) if self.algo == 1 else 0
+        self.ws_bwd = int(L.dram_wino_workspace(d, 1)) if self.algo == 1 else 0
+        self.v_elems = int(L.dram_wino_v_elems(d)) if (self.algo == 1 or self.walgo == 1) else 0
+        self.ws_wgrad = {3: lambda: int(L.dram_conv1x1_bwd_weight_workspace(d)),
+                         2: lambda: int(L.dram_wgrad_w2d_workspace(d)),
+                         1: lambda: int(L.dram_wino_workspace(d, 2))}.get(self.walgo, lambda: 0)()
+        self.ws_direct_wgrad = int(L.dram_conv3d_bwd_weight_workspace(d)) if (self.walgo == 0 or self.ws_wgrad == 0) else 0
+
+
+_PLANS: Dict[tuple, ConvPlan] = {}
+
+
+def conv_plan(g: "ConvGeom") -> ConvPlan:
+    env = os.environ
+    key = (g,) + tuple(env.get(k) for k in _PLAN_ENV)
+    p = _PLANS.get(key)
+    if p is None:
+        p = _PLANS[key] = ConvPlan(g)
+    return p
+
+
 def conv_algo(g: "ConvGeom") -> int:
     """Library plan for this geometry (dram_conv_algo): 0 direct implicit GEMM, 1 Winograd
-    F(2x2x2,3x3x3) pipeline, 2 fused in-plane Winograd F(2x2,3x3) x direct-z."""
-    return int(_L().dram_conv_algo(ctypes.byref(g.desc())))
+    F(2x2x2,3x3x3) pipeline, 2 fused in-plane Winograd F(2x2,3x3) x direct-z, 3 1x1x1 GEMM."""
+    return conv_plan(g).algo
 
 
 def conv_use_wino(g: "ConvGeom") -> bool:
@@ -274,11 +321,8 @@ def conv_use_wino(g: "ConvGeom") -> bool:
 def packed_taps(g: "ConvGeom", bwd: bool = False) -> int:
     """Leading dimension of the packed weights the library's plan expects for g (forward operand wf, or
     with bwd=True the data-gradient operand wb: the Winograd pipeline may tile the two passes differently)."""
-    algo = conv_algo(g)
-    if algo == 1:
-        fn = _L().dram_wino_num_points_bwd if bwd else _L().dram_wino_num_points
-        return int(fn(ctypes.byref(g.desc())))
-    return 48 if algo == 2 else g.taps
+    p = conv_plan(g)
+    return p.taps_b if bwd else p.taps_f
 
 
 def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True, g: Optional["ConvGeom"] = None
@@ -288,19 +332,44 @@ def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True, g: Optional["ConvG
     _req(w, "w")
     Cout, Cin = w.shape[0], w.shape[1]
     taps = w.shape[2] * w.shape[3] * w.shape[4]
-    algo = conv_algo(g) if g is not None else 0
-    pt = packed_taps(g) if g is not None else taps
-    ptb = packed_taps(g, True) if g is not None else taps
+    plan = conv_plan(g) if g is not None else None
+    algo = plan.algo if plan else 0
+    pt = plan.taps_f if plan else taps
+    ptb = plan.taps_b if plan else taps
     wf = torch.empty((pt, Cout, Cin), device=w.device, dtype=torch.float32) if want_fwd else None
     wb = torch.empty((ptb, Cin, Cout), device=w.device, dtype=torch.float32) if want_bwd else None
     if algo == 1:
-        _chk(_L().dram_wino_pack_weight(_p(w), _p(wf), _p(wb), ctypes.byref(g.desc()), _stream()),
+        _chk(_L().dram_wino_pack_weight(_p(w), _p(wf), _p(wb), plan.dref, _stream()),
              "dram_wino_pack_weight")
     elif algo == 2:
         _chk(_L().dram_wino2d_pack_weight(_p(w), _p(wf), _p(wb), Cout, Cin, _stream()), "dram_wino2d_pack_weight")
     else:
         _chk(_L().dram_pack_conv_weight(_p(w), _p(wf), _p(wb), Cout, Cin, taps, _stream()), "dram_pack_conv_weight")
     return wf, wb
+
+
+# Packed forward weights of inference calls (no_grad): repacking / re-transforming every weight on every
+# forward is pure overhead when the weights did not change.  Key = storage address + torch version counter +
+# WEIGHT_EPOCH (bumped by the fused optimizers, whose kernels update parameters behind torch's back) + plan.
+WEIGHT_EPOCH = 0
+_PACKED: Dict[tuple, Tensor] = {}
+
+
+def weights_changed():
+    """Called by anything that rewrites parameters through raw pointers (FusedAdam / FusedSGD)."""
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+    _PACKED.clear()
+
+
+def packed_forward_weight(w: Tensor, g: "ConvGeom") -> Tensor:
+    key = (w.data_ptr(), w._version, WEIGHT_EPOCH, g) + tuple(os.environ.get(k) for k in _PLAN_ENV)
+    wf = _PACKED.get(key)
+    if wf is None:
+        if len(_PACKED) > 1024:
+            _PACKED.clear()
+        wf = _PACKED[key] = pack_conv_weight(w, True, False, g)[0]
+    return wf
 
 
 def conv3d_fwd(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, want_stats: bool):
@@ -312,42 +381,39 @@ def conv3d_fwd_keep(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, 
     """Forward conv; with keep=True on the Winograd path also returns the transformed input V
     (reused by conv3d_bwd_weight instead of transforming x again), else None."""
     _req(x, "x", shape=g.in_shape)
-    algo = conv_algo(g)
-    wino = algo == 1
-    _req(wf, "wf", shape=(packed_taps(g), g.Cout, g.Cin))
+    plan = conv_plan(g)
+    algo, d = plan.algo, plan.dref
+    _req(wf, "wf", shape=(plan.taps_f, g.Cout, g.Cin))
     if bias is not None:
         _req(bias, "bias", shape=(g.Cout,))
-    d = g.desc()
     y = torch.empty(g.out_shape, device=x.device, dtype=torch.float32)
     stats = None
     if want_stats:
-        nt = {0: _L().dram_conv_num_mtiles, 1: _L().dram_wino_num_stat_rows, 2: _L().dram_wino2d_num_stat_rows,
-              3: _L().dram_conv1x1_num_stat_rows}[algo](ctypes.byref(d))
-        if nt <= 0:
+        if plan.stat_rows <= 0:
             raise RuntimeError(f"dram_conv_num_mtiles rejected {g}")
-        stats = torch.empty((nt, 2, g.Cout), device=x.device, dtype=torch.float32)
-    if wino:
-        nbytes = _L().dram_wino_workspace(ctypes.byref(d), 0)
+        stats = torch.empty((plan.stat_rows, 2, g.Cout), device=x.device, dtype=torch.float32)
+    if algo == 1:
+        nbytes = plan.ws_fwd
         ws = _workspace(nbytes, x.device)
         v = None
         if keep:
-            v = torch.empty((_L().dram_wino_v_elems(ctypes.byref(d)),), device=x.device, dtype=torch.float32)
+            v = torch.empty((plan.v_elems,), device=x.device, dtype=torch.float32)
         with _span("conv_wino_kernels", g.flops, f"fwd {g}"):
-            _chk(_L().dram_wino_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), _p(v), ctypes.byref(d), _p(ws),
+            _chk(_L().dram_wino_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), _p(v), d, _p(ws),
                                            nbytes, _stream()), f"dram_wino_conv3d_fwd{g}")
         return y, stats, v
     if algo == 3:                                    # 1x1x1: plain GEMM, wf [1, Cout, Cin] is the weight itself
         with _span("conv1x1_gemm", g.flops, f"fwd {g}"):
-            _chk(_L().dram_conv1x1_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), ctypes.byref(d), _stream()),
+            _chk(_L().dram_conv1x1_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), d, _stream()),
                  f"dram_conv1x1_fwd{g}")
         return y, stats, None
     if algo == 2:
         with _span("conv_wino2d_kernel", g.flops, f"fwd {g}"):
-            _chk(_L().dram_wino2d_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), ctypes.byref(d), _stream()),
+            _chk(_L().dram_wino2d_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), d, _stream()),
                  f"dram_wino2d_conv3d_fwd{g}")
         return y, stats, None
     with _span("conv_igemm_kernel", g.flops, f"fwd {g}"):
-        _chk(_L().dram_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), ctypes.byref(d), _stream()),
+        _chk(_L().dram_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), d, _stream()),
              f"dram_conv3d_fwd{g}")
     return y, stats, None
 
@@ -355,34 +421,33 @@ def conv3d_fwd_keep(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, 
 def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] = None,
                     gate: Optional[Tensor] = None) -> Tensor:
     _req(dy, "dy", shape=g.out_shape)
-    algo = conv_algo(g)
-    wino = algo == 1
-    _req(wb, "wb", shape=(packed_taps(g, True), g.Cin, g.Cout))
+    plan = conv_plan(g)
+    algo, d = plan.algo, plan.dref
+    _req(wb, "wb", shape=(plan.taps_b, g.Cin, g.Cout))
     if add is not None:
         _req(add, "add", shape=g.in_shape)
     if gate is not None:
         _req(gate, "gate", shape=g.in_shape)
-    d = g.desc()
     dx = torch.empty(g.in_shape, device=dy.device, dtype=torch.float32)
-    if wino:
-        nbytes = _L().dram_wino_workspace(ctypes.byref(d), 1)
+    if algo == 1:
+        nbytes = plan.ws_bwd
         ws = _workspace(nbytes, dy.device)
         with _span("conv_wino_kernels", g.flops, f"dgrad {g}"):
-            _chk(_L().dram_wino_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d), _p(ws),
+            _chk(_L().dram_wino_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), d, _p(ws),
                                                 nbytes, _stream()), f"dram_wino_conv3d_bwd_data{g}")
         return dx
     if algo == 3:
         with _span("conv1x1_gemm", g.flops, f"dgrad {g}"):
-            _chk(_L().dram_conv1x1_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d), _stream()),
+            _chk(_L().dram_conv1x1_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), d, _stream()),
                  f"dram_conv1x1_bwd_data{g}")
         return dx
     if algo == 2:
         with _span("conv_wino2d_kernel", g.flops, f"dgrad {g}"):
-            _chk(_L().dram_wino2d_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d),
+            _chk(_L().dram_wino2d_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), d,
                                                   _stream()), f"dram_wino2d_conv3d_bwd_data{g}")
         return dx
     with _span("conv_igemm_kernel", g.flops, f"dgrad {g}"):
-        _chk(_L().dram_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), ctypes.byref(d), _stream()),
+        _chk(_L().dram_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), d, _stream()),
              f"dram_conv3d_bwd_data{g}")
     return dx
 
@@ -391,41 +456,41 @@ def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] 
                       v_cache: Optional[Tensor] = None) -> Tensor:
     _req(x, "x", shape=g.in_shape)
     _req(dy, "dy", shape=g.out_shape)
-    d = g.desc()
+    plan = conv_plan(g)
+    d, walgo = plan.dref, plan.walgo
     shape = (g.Cout, g.Cin, g.k, g.k, g.k)
     dw = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
     _req(dw, "dw", shape=shape)
-    walgo = _L().dram_conv_wgrad_algo(ctypes.byref(d))
     if walgo == 3:
-        nbytes = _L().dram_conv1x1_bwd_weight_workspace(ctypes.byref(d))
+        nbytes = plan.ws_wgrad
         ws = _workspace(max(nbytes, 4), x.device)
         with _span("conv1x1_gemm", g.flops, f"wgrad {g}"):
-            _chk(_L().dram_conv1x1_bwd_weight(_p(x), _p(dy), _p(dw), ctypes.byref(d), _p(ws), nbytes, _stream()),
+            _chk(_L().dram_conv1x1_bwd_weight(_p(x), _p(dy), _p(dw), d, _p(ws), nbytes, _stream()),
                  f"dram_conv1x1_bwd_weight{g}")
         return dw
     if walgo == 2:
-        nbytes = _L().dram_wgrad_w2d_workspace(ctypes.byref(d))
+        nbytes = plan.ws_wgrad
         ws = _workspace(nbytes, x.device)
         with _span("conv_wgrad_w2d_kernel+reduce", g.flops, f"wgrad {g}"):
-            _chk(_L().dram_wgrad_w2d(_p(x), _p(dy), _p(dw), ctypes.byref(d), _p(ws), nbytes, _stream()),
+            _chk(_L().dram_wgrad_w2d(_p(x), _p(dy), _p(dw), d, _p(ws), nbytes, _stream()),
                  f"dram_wgrad_w2d{g}")
         return dw
     if walgo == 1:
-        nbytes = _L().dram_wino_workspace(ctypes.byref(d), 2)
+        nbytes = plan.ws_wgrad
         if nbytes:                                   # 0: this geometry's weight gradient stays on the direct path
             ws = _workspace(nbytes, x.device)
             if v_cache is not None:
-                _req(v_cache, "v_cache", shape=(_L().dram_wino_v_elems(ctypes.byref(d)),))
+                _req(v_cache, "v_cache", shape=(plan.v_elems,))
             with _span("conv_wino_kernels", g.flops, f"wgrad {g}"):
-                _chk(_L().dram_wino_conv3d_bwd_weight(_p(x), _p(v_cache), _p(dy), _p(dw), ctypes.byref(d), _p(ws),
+                _chk(_L().dram_wino_conv3d_bwd_weight(_p(x), _p(v_cache), _p(dy), _p(dw), d, _p(ws),
                                                       nbytes, _stream()), f"dram_wino_conv3d_bwd_weight{g}")
             return dw
-    nbytes = _L().dram_conv3d_bwd_weight_workspace(ctypes.byref(d))
+    nbytes = plan.ws_direct_wgrad
     if nbytes == 0:
         raise RuntimeError(f"dram_conv3d_bwd_weight: unsupported geometry {g}")
-    ws = torch.empty(((nbytes + 3) // 4,), device=x.device, dtype=torch.float32)
+    ws = _workspace(nbytes, x.device)
     with _span("conv_wgrad_kernel+reduce", g.flops, f"wgrad {g}"):
-        _chk(_L().dram_conv3d_bwd_weight(_p(x), _p(dy), _p(dw), ctypes.byref(d), _p(ws), nbytes, _stream()),
+        _chk(_L().dram_conv3d_bwd_weight(_p(x), _p(dy), _p(dw), d, _p(ws), nbytes, _stream()),
              f"dram_conv3d_bwd_weight{g}")
     return dw
 
@@ -757,6 +822,12 @@ def segloss_bwd(cle: Tensor, pse: Tensor, lungs: Tensor, ems: Tensor, binary: Te
 def adam_multi(table: Tensor, chunks: Tensor, nchunks: int, lr, b1, b2, eps, wd, bc1, bc2, grad_scale):
     _chk(_L().dram_adam_multi(_p(table), _p(chunks), nchunks, lr, b1, b2, eps, wd, bc1, bc2, grad_scale, _stream()),
          "dram_adam_multi")
+
+
+def adam_multi_dev(table: Tensor, chunks: Tensor, nchunks: int, hyper: Tensor):
+    """hyper: float32[7] device tensor {lr, b1, b2, eps, wd, grad_scale, step} (graph-replayable form)."""
+    _req(hyper, "hyper", shape=(7,))
+    _chk(_L().dram_adam_multi_dev(_p(table), _p(chunks), nchunks, _p(hyper), _stream()), "dram_adam_multi_dev")
 
 
 def sgd_multi(table: Tensor, chunks: Tensor, nchunks: int, lr, momentum, wd, first_step, grad_scale):

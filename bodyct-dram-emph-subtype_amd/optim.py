@@ -92,6 +92,7 @@ class FusedAdam(_FusedBase):
                 t, c, n = self._tables(key, ptrs, plist[0].device)
                 ops.adam_multi(t, c, n, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
                                1.0 - b1 ** step, 1.0 - b2 ** step, float(self.grad_scale))
+        ops.weights_changed()        # the kernel wrote the parameters through raw pointers
         return loss
 
 
@@ -128,4 +129,5 @@ class FusedSGD(_FusedBase):
                 t, c, n = self._tables((gi, is_first, tuple(ptrs)), ptrs, plist[0].device)
                 ops.sgd_multi(t, c, n, float(group["lr"]), group["momentum"], group["weight_decay"], is_first,
                               float(self.grad_scale))
+        ops.weights_changed()
         return loss

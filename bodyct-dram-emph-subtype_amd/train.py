@@ -25,6 +25,7 @@ from pathlib import Path
 import torch
 
 from . import models
+from .transforms import TrainAugment
 from .utils import load_state_dict_greedy
 
 
@@ -51,6 +52,7 @@ def build_parser() -> ArgumentParser:
     p.add_argument("--log_every_n_steps", default=5, type=int)
     p.add_argument("--synthetic", default=1, type=int)
     p.add_argument("--seed", default=0, type=int)
+    p.add_argument("--augment", default=0, type=int, help="1: GPU-side train-time augmentations (models.py:66-74)")
     return p
 
 
@@ -80,6 +82,20 @@ class SyntheticSubtypeData:
                    "cls_label": torch.randint(0, 6, (self.B,), generator=gl).to(self.device),
                    "pse_label": torch.randint(0, 3, (self.B,), generator=gl).to(self.device),
                    "index": (torch.arange(self.B) + i * self.B).unsqueeze(-1).to(self.device)}
+
+
+def augment_batch(batch, augment):
+    """apply one parameter draw per sample to the image and its masks (the reference's dict transforms run per
+    sample in the DataLoader workers)"""
+    keys = [k for k in batch if k == "image" or k.endswith("_mask")]
+    cols = {k: [] for k in keys}
+    for b in range(batch["image"].shape[0]):
+        out = augment({k: batch[k][b] for k in keys})
+        for k in keys:
+            cols[k].append(out[k])
+    new = dict(batch)
+    new.update({k: torch.stack(v) for k, v in cols.items()})
+    return new
 
 
 # ------------------------------------------------------------------ checkpoints (Lightning-1.9 shape)
@@ -143,25 +159,54 @@ def run_training_job(argv=None):
         from . import distributed as ddist
         ddist.attach(module.model)                 # DDP + SyncBatchNorm semantics (train.py:100-104)
     data = SyntheticSubtypeData(args.num_samples, args.batch_size, args.target_size, rank, world, device, args.seed)
+    val_data = SyntheticSubtypeData(max(args.batch_size * world, args.num_samples // 4), args.batch_size, args.target_size,
+                                    rank, world, device, args.seed + 7)
+    augment = TrainAugment() if getattr(args, "augment", 0) else None        # models.py:66-74 (train mode only)
     global_step = 0
+    best = (float("inf"), None)
     for epoch in range(start_epoch, args.max_epochs):
         module.train()
-        running = 0.0
+        running, step_outputs, losses = 0.0, [], []
         for i, batch in enumerate(data.epoch(epoch)):
+            if augment is not None:
+                batch = augment_batch(batch, augment)
             optimizer.zero_grad(set_to_none=True)
             out = module.training_step(batch, i)
             out["loss"].backward()
             optimizer.step()
+            losses.append(out["loss"].detach())
+            step_outputs.append({k: v for k, v in out.items() if k != "loss"})
             global_step += 1
             if global_step % args.log_every_n_steps == 0:
                 running = float(out["loss"])
                 if rank == 0:
                     logging.info(f"epoch {epoch} step {global_step} train_loss {running:.5f} "
                                  f"lr {optimizer.param_groups[0]['lr']:.3e}")
+        # Lightning's fit loop: validation epoch, then the epoch-end hooks (gather + de-dup + class-weight update,
+        # models.py:287-317 / :367-379), then the scheduler and ModelCheckpoint
+        module.eval()
+        val_outputs = [module.validation_step(b, i) for i, b in enumerate(val_data.epoch(epoch))]
+        ev = module.validation_epoch_end(val_outputs)
+        et = module.training_epoch_end(step_outputs)
+        train_loss = float(torch.stack(losses).mean())
+        if rank == 0:
+            logging.info(f"epoch {epoch}: train_loss {train_loss:.5f} train acc cle/pse {float(et['acc_cle']):.3f}/"
+                         f"{float(et['acc_pse']):.3f} val acc cle/pse {float(ev['acc_cle']):.3f}/{float(ev['acc_pse']):.3f} "
+                         f"class weights {module.cle_class_weights.tolist()}")
         scheduler.step()                           # ExponentialLR(gamma=0.95), per epoch
         if rank == 0:                              # ModelCheckpoint(save_top_k=-1, every_n_epochs=1, '{epoch:02d}')
-            torch.save(checkpoint_dict(module, optimizer, scheduler, epoch, global_step, args),
-                       ckp_path / f"epoch={epoch:02d}.ckpt")
+            path = ckp_path / f"epoch={epoch:02d}.ckpt"
+            torch.save(checkpoint_dict(module, optimizer, scheduler, epoch, global_step, args), path)
+            if train_loss < best[0]:               # monitor='train_loss' (train.py:92-99)
+                best = (train_loss, path)
+    if best[1] is not None or world > 1:           # trainer.test(ckpt_path='best') (train.py:108)
+        if best[1] is not None:
+            module.load_state_dict(torch.load(best[1], map_location="cpu", weights_only=False)["state_dict"])
+        module.eval()
+        test_outputs = [module.test_step(b, i) for i, b in enumerate(val_data.epoch(10_000))]
+        te = module.test_epoch_end(test_outputs)
+        if rank == 0:
+            logging.info(f"test (best = {best[1]}): acc cle/pse {float(te['acc_cle']):.3f}/{float(te['acc_pse']):.3f}")
     if world > 1:
         torch.distributed.destroy_process_group()
     return module

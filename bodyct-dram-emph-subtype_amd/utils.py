@@ -58,3 +58,14 @@ def load_state_dict_greedy(model: torch.nn.Module, state_dict_to_load: Dict):
     report("[load_state_dict_greedy] loaded %d/%d tensors; shape mismatch: %s; unexpected: %s; missing: %s",
            len(usable), len(have), mismatched or "-", unexpected or "-", missing or "-")
     return dict(mismatched=mismatched, unexpected=unexpected, missing=missing)
+
+
+def cat_all_gather(t: torch.Tensor) -> torch.Tensor:
+    """utils.py:66-80: all_gather + concatenate along dim 0 (identity without an initialised process group --
+    the reference requires one)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return t
+    parts = [torch.ones_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t, async_op=False)
+    return torch.cat(parts, dim=0)

@@ -383,6 +383,13 @@ typedef struct DramChunkRef {
 int dram_adam_multi(const DramTensorRef* table, const DramChunkRef* chunks, int nchunks, float lr,
                     float beta1, float beta2, float eps, float weight_decay, float bias_corr1,
                     float bias_corr2, float grad_scale, dram_stream_t stream);
+/* Same update with every hyper-parameter and the step count in DEVICE memory:
+ *   hyper = float[7] {lr, beta1, beta2, eps, weight_decay, grad_scale, step}
+ * step is incremented on the device first and the bias corrections 1 - beta^step are computed in the
+ * kernel (double), so a hipGraph captured around a train step stays valid across steps and lr changes
+ * (the host only rewrites hyper[0] when the scheduler moves lr). */
+int dram_adam_multi_dev(const DramTensorRef* table, const DramChunkRef* chunks, int nchunks, float* hyper,
+                        dram_stream_t stream);
 int dram_sgd_multi(const DramTensorRef* table, const DramChunkRef* chunks, int nchunks, float lr,
                    float momentum, float weight_decay, int first_step, float grad_scale,
                    dram_stream_t stream);
@@ -401,6 +408,35 @@ int dram_prep_image(const float* scan, const int* zidx, const float* mean_invstd
                     int Do, int Ho, int Wo, float lo, float hi, dram_stream_t stream);
 int dram_prep_mask(const float* mask, const int* zidx, float* out, int D, int H, int W, int Do, int Ho, int Wo,
                    dram_stream_t stream);
+
+/* Predict post-processing (processor.py:111-129, :143): src [D,H,W] resized (trilinear, align_corners=True) to
+ * the lung-crop size (rd,rh,rw) and pasted at offset (oz,oy,ox) into a zero volume of the original grid
+ * [Do,Ho,Wo]; out_f32 and/or out_u8 (= utils.windowing(., (0,1) -> (0,255)) truncated to uint8). */
+int dram_resample_paste(const float* src, float* out_f32, uint8_t* out_u8, int D, int H, int W, int rd, int rh, int rw,
+                        int oz, int oy, int ox, int Do, int Ho, int Wo, dram_stream_t stream);
+
+/* Train-time augmentations (models.py:66-74) with GIVEN parameters, fused into one gather pass:
+ * GaussianAddictive (intensity_transforms.py:145-177; noise [D,H,W] supplied by the caller, minmax[2] = volume
+ * {min, max} on the device, e.g. folded from dram_minmax partials [nblk][2]), BoxMaskOut (:180-237), Flip
+ * (spatial_transforms.py:100-131), CropAndResize (:133-197, functional.py:68-94: affine_grid + grid_sample;
+ * image trilinear / align_corners=True, mask nearest / align_corners=False, zero padding).
+ * flags: bit 0 noise, 1 boxes, 2 flip, 3 crop-resize; boxes[b] = {z0,z1,y0,y1,x0,x1} half-open, pre-flip grid;
+ * flip_axes: bit 0 z, 1 y, 2 x; box_lo/box_hi: bounding box / size per axis (z, y, x).  x != out. */
+typedef struct DramAugment {
+  int32_t flags;
+  int32_t n_boxes;
+  int32_t boxes[10][6];
+  int32_t flip_axes;
+  float sigma;
+  float box_lo[3];
+  float box_hi[3];
+} DramAugment;
+int dram_minmax_nblk(long long n);
+int dram_minmax(const float* x, float* partial, long long n, dram_stream_t stream);
+int dram_augment_image(const float* x, const float* noise, const float* minmax, float* out, int D, int H, int W,
+                       const DramAugment* aug, dram_stream_t stream);
+int dram_augment_mask(const float* mask, float* out, int D, int H, int W, const DramAugment* aug,
+                      dram_stream_t stream);
 
 /* out[i] = a[i] + b[i]  (gradient accumulation where two consumers meet) */
 int dram_add(const float* a, const float* b, float* out, long long n, dram_stream_t stream);

@@ -434,3 +434,97 @@ def ddp_emulated_grads(sd, xs: List[Tensor], lungs: List[Optional[Tensor]], arch
         off += b
     total.backward()
     return {k: v.grad for k, v in leaves.items() if isinstance(v, Tensor) and v.requires_grad}, total.detach()
+
+
+# ---------------------------------------------------------------------------
+# predict post-processing (processor.py:34-38, 111-143)
+# ---------------------------------------------------------------------------
+def paste_resampled(dense: Tensor, crop, original_size) -> Tensor:
+    """processor.py:115-122: dense [D,H,W] -> trilinear(align_corners) to the crop size -> pasted into zeros of
+    the original grid.  crop = [[z0,z1],[y0,y1],[x0,x1]]."""
+    recon = tuple(int(c[1]) - int(c[0]) for c in crop)
+    up = F.interpolate(dense[None, None], size=recon, mode="trilinear", align_corners=True)[0, 0]
+    full = torch.zeros(tuple(int(s) for s in original_size), dtype=up.dtype)
+    full[tuple(slice(int(c[0]), int(c[1])) for c in crop)] = up
+    return full
+
+
+def window_u8(full: Tensor) -> Tensor:
+    """utils.windowing(full, from_span=(0, 1)) (utils.py:28-37, to_span (0, 255)) + .astype(np.uint8) (processor.py:143)."""
+    w = full.double().clamp(0.0, 1.0) / 1.0 * 255.0
+    return w.to(torch.uint8)            # float -> uint8 truncates, like numpy astype
+
+
+def severity_label(ratio: float, ratio_map) -> int:
+    """processor.ratio_to_label (processor.py:34-38)."""
+    return [k for k, (lo, hi) in ratio_map.items() if lo <= ratio < hi][0]
+
+
+# ---------------------------------------------------------------------------
+# epoch-end bookkeeping (models.py:287-317, 367-379)
+# ---------------------------------------------------------------------------
+def dedup_by_index(indices: Tensor, *cols: Tensor):
+    """models.py:303-309: np.unique(indices, return_index=True) keeps the FIRST occurrence of every sample index
+    (sorted by index); accuracies (models.py:300-301) are taken BEFORE the de-duplication."""
+    order = torch.argsort(indices, stable=True)
+    s = indices[order]
+    first = torch.ones_like(s, dtype=torch.bool)
+    first[1:] = s[1:] != s[:-1]
+    keep = order[first]
+    return indices[keep], tuple(c[keep] for c in cols)
+
+
+def update_class_weights(weights: Tensor, y_true: Tensor, y_pred: Tensor) -> Tensor:
+    """models.py:367-377: per-class accuracy = diag / row sums of sklearn's confusion_matrix (labels = sorted
+    union of the values that occur); new weights = w * (1 - acc), renormalised to sum 1."""
+    labels = torch.unique(torch.cat([y_true, y_pred]))
+    acc = []
+    for c in labels.tolist():
+        row = y_true == c
+        acc.append(float(((y_pred == c) & row).sum()) / float(row.sum()))
+    w = weights.double() * (1.0 - torch.tensor(acc, dtype=torch.float64))
+    return w / w.sum()
+
+
+# ---------------------------------------------------------------------------
+# train-time augmentations with given parameters (models.py:66-74)
+# ---------------------------------------------------------------------------
+def gaussian_additive(img: Tensor, sigma: float, noise: Tensor) -> Tensor:
+    """GaussianAddictive.apply_to_image (intensity_transforms.py:163-177); `noise` = the torch.randn draw."""
+    d_min, d_max = img.min(), img.max()
+    d_range = d_max - d_min
+    r = (img - d_min) / float(d_range + 1e-7) + sigma * noise
+    r = r.clamp(0.0, 1.0)
+    return r * d_range + d_min
+
+
+def _frac_box(center, size, shape):
+    """the integer box of BoxMaskOut / CropAndResize (intensity_transforms.py:226-235, spatial_transforms.py:172-177)"""
+    return [(max(0, int(mc * ds) - int(ms * ds) // 2), min(int(mc * ds) + (int(ms * ds) - int(ms * ds) // 2), ds))
+            for mc, ds, ms in zip(center, shape, size)]
+
+
+def box_mask_out(img: Tensor, centers, sizes) -> Tensor:
+    """BoxMaskOut.apply_to_image (intensity_transforms.py:220-237), assign_value 0."""
+    out = img.clone()
+    for c, s in zip(centers, sizes):
+        out[tuple(slice(a, b) for a, b in _frac_box(c, s, img.shape))] = 0
+    return out
+
+
+def flip(t: Tensor, dims) -> Tensor:
+    """Flip.apply (spatial_transforms.py:121-125)."""
+    return torch.flip(t, dims=list(dims))
+
+
+def crop_and_resize(t: Tensor, center, size, mask: bool = False) -> Tensor:
+    """CropAndResize.apply (spatial_transforms.py:169-197) + functional.roi_align (functional.py:68-94):
+    affine_grid over the normalised box (axes reversed to x,y,z), grid_sample with zero padding; images
+    'bilinear' (trilinear) align_corners=True, masks nearest align_corners=False."""
+    box = torch.tensor(_frac_box(center, size, t.shape), dtype=torch.float32) / torch.tensor(t.shape, dtype=torch.float32)[:, None]
+    box = box.flip(0)                                   # (z,y,x) -> (x,y,z)
+    theta = torch.cat([torch.diag(box[:, 1] - box[:, 0]), (-1.0 + box.sum(-1))[:, None]], dim=-1)[None]
+    grid = F.affine_grid(theta, (1, 1) + tuple(t.shape), align_corners=False)
+    out = F.grid_sample(t[None, None].float(), grid, mode="nearest" if mask else "bilinear", padding_mode="zeros",
+                        align_corners=False if mask else True)
+    return out[0, 0].to(t.dtype)

@@ -187,3 +187,61 @@ def test_trainer_harness_flags_and_checkpoint_roundtrip(tmp_path):
     assert abs(o2.param_groups[0]["lr"] - args.lr) < 1e-12               # optimizer state restored
     assert train.restore(fresh, o2, s2, str(tmp_path / "weights.pth"), reload_only_weights=True) == 0
     assert torch.allclose(fresh.state_dict()["model.conv1.weight"], mod.state_dict()["model.conv1.weight"] + 1)
+
+
+def test_epoch_end_and_class_weight_update_match_reference_fixture():
+    """models.py:287-317 / :367-379 through the package's module methods (pure torch glue: runs on CPU tensors),
+    against the fixture recorded from the reference's own shared_epoch_end."""
+    from bodyct_dram_emph_subtype_amd import models
+    g = np.load(os.path.join(ROOT, "tests", "golden", "epoch_end.npz"))
+    m = models.ScanCLSLightningModule.__new__(models.ScanCLSLightningModule)
+    torch.nn.Module.__init__(m)
+    m.cle_class_weights = torch.from_numpy(g["w_cle_before"])
+    m.pse_class_weights = torch.from_numpy(g["w_pse_before"])
+    t = {k: torch.from_numpy(g[k]) for k in ("index", "cle", "pse", "pred_cle", "pred_pse")}
+    outs = [dict(pred_cle_labels=t["pred_cle"][i:i + 8], cle_labels=t["cle"][i:i + 8], pred_pse_labels=t["pred_pse"][i:i + 8],
+                 pse_labels=t["pse"][i:i + 8], index=t["index"][i:i + 8]) for i in range(0, 40, 8)]
+    r = m.training_epoch_end(outs)
+    assert abs(float(r["acc_cle"]) - float(g["acc_cle"])) < 1e-7 and abs(float(r["acc_pse"]) - float(g["acc_pse"])) < 1e-7
+    for a, b in (("indices", "dedup_indices"), ("pred_cle_labels", "dedup_pred_cle"), ("pred_pse_labels", "dedup_pred_pse"),
+                 ("cle_labels", "dedup_cle"), ("pse_labels", "dedup_pse")):
+        assert np.array_equal(r[a].numpy(), g[b]), a
+    assert np.allclose(m.cle_class_weights.numpy(), g["w_cle_after"], rtol=1e-12)
+    assert np.allclose(m.pse_class_weights.numpy(), g["w_pse_after"], rtol=1e-12)
+    # validation phase: same gather / de-dup, weights untouched
+    w = m.cle_class_weights.clone()
+    m.validation_epoch_end(outs)
+    assert torch.equal(w, m.cle_class_weights)
+
+
+def test_processor_labels_reports_and_augment_parameter_boxes(tmp_path):
+    from bodyct_dram_emph_subtype_amd import models, processor, transforms
+    g = np.load(os.path.join(ROOT, "tests", "golden", "processor.npz"))
+    for p, a, b in zip(g["pcts"], g["cle_scores"], g["pse_scores"]):
+        assert processor.ratio_to_label(float(p), models.CLE_RATIO_MAP) == int(a)
+        assert processor.ratio_to_label(float(p), models.PSE_RATIO_MAP) == int(b)
+    with pytest.raises(IndexError):
+        processor.ratio_to_label(1.5, models.CLE_RATIO_MAP)
+    res = [{"entity": "scan0", "error_messages": [], "metrics": {"cle_severity_score": "3", "cle_lesion_percentage_per_lung": "0.123",
+                                                                   "pse_severity_score": "1", "pse_lesion_percentage_per_lung": "0.020"}}]
+    processor.write_reports(res, str(tmp_path / "c.json"), str(tmp_path / "p.json"), str(tmp_path / "o.json"))
+    import json
+    assert json.load(open(tmp_path / "c.json")) == {"score": 3, "percentage": 0.123}
+    assert json.load(open(tmp_path / "p.json")) == {"score": 1, "percentage": 0.02}
+    assert json.load(open(tmp_path / "o.json"))[0]["entity"] == "scan0"
+    # augmentation parameters -> the C struct (integer boxes of intensity_transforms.py:226-235)
+    a = np.load(os.path.join(ROOT, "tests", "golden", "augment.npz"))
+    ap = transforms.AugmentParams(noise_sigma=0.045, box_centers=[tuple(c) for c in a["box_centers"]],
+                                  box_sizes=[tuple(c) for c in a["box_sizes"]], flip_dims=(2, 0),
+                                  crop_center=tuple(a["crop_center"]), crop_size=tuple(a["crop_size"]))
+    st = ap.to_struct((12, 20, 28))
+    assert st.flags == 15 and st.n_boxes == 3 and st.flip_axes == 5
+    zeroed = (a["after_box"] == 0) & (a["after_noise"] != 0)
+    box = np.zeros_like(zeroed)
+    for b in range(3):
+        z0, z1, y0, y1, x0, x1 = list(st.boxes[b])
+        box[z0:z1, y0:y1, x0:x1] = True
+    assert np.array_equal(box & (a["after_noise"] != 0), zeroed)
+    draws = [transforms.TrainAugment(rng=__import__("random").Random(s)).draw() for s in range(200)]
+    assert 60 < sum(d.noise_sigma is not None for d in draws) < 140 and all(len(d.box_centers) <= 10 for d in draws)
+    assert all(0.03 <= d.noise_sigma <= 0.06 for d in draws if d.noise_sigma is not None)

@@ -1,11 +1,12 @@
 """GPU: the LightningModule mirrors (models.py) -- train/val steps, predict-time dRAM
 up-projection, configure_optimizers -- against the CPU oracle restating reference
 models.py:236-276, :430-450, :539-592, and the metrics drop-ins."""
+import os
 import numpy as np
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import GOLDEN, rel_l2
 from oracle import med3d_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -167,3 +168,44 @@ def test_input_transforms_match_oracle(src, tgt):
     assert out["lesion_mask"].dtype == torch.int16
     assert torch.equal(out["lesion_mask"].cpu(), orc.prepare_mask(lab, tgt))
     assert out["cls_label"] == 3
+
+
+def test_processor_resample_paste_matches_reference_fixture():
+    """processor.py:111-129, :143 as one gather kernel, against the fixture recorded from the reference statements."""
+    from bodyct_dram_emph_subtype_amd import processor
+    g = np.load(os.path.join(GOLDEN, "processor.npz"))
+    dense = torch.from_numpy(g["dense"][0]).to(DEV)
+    f32, u8 = processor.resample_paste(dense, torch.from_numpy(g["crop"]), torch.from_numpy(g["original"]), True, True)
+    assert tuple(f32.shape) == tuple(g["original"])
+    assert float((f32.cpu() - torch.from_numpy(g["full"])).abs().max()) < 2e-6
+    outside = torch.from_numpy(g["full"]) == 0
+    assert torch.equal(f32.cpu()[outside], torch.zeros(int(outside.sum())))          # exact zeros outside the crop box
+    d = (u8.cpu().int() - torch.from_numpy(g["full_u8"]).int()).abs()
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-3                # truncation at an integer boundary
+    with pytest.raises(ValueError):
+        processor.resample_paste(dense, [[0, 50], [0, 10], [0, 10]], (40, 61, 75))
+
+
+def test_augmentations_match_reference_fixture():
+    """models.py:66-74 with given parameters: each prefix of the chain noise -> boxes -> flip -> crop-resize through
+    the ONE fused kernel equals the reference classes applied one after the other."""
+    from bodyct_dram_emph_subtype_amd.transforms import AugmentParams, augment_image, augment_mask
+    g = np.load(os.path.join(GOLDEN, "augment.npz"))
+    img, mask = torch.from_numpy(g["image"]).to(DEV), torch.from_numpy(g["mask"]).to(DEV)
+    torch.manual_seed(int(g["noise_seed"]))
+    noise = torch.randn(g["image"].shape).to(DEV)
+    cen, siz = [tuple(c) for c in g["box_centers"]], [tuple(c) for c in g["box_sizes"]]
+    cc, cs = tuple(g["crop_center"]), tuple(g["crop_size"])
+    chain = [(AugmentParams(noise_sigma=float(g["noise_sigma"])), "after_noise"),
+             (AugmentParams(noise_sigma=float(g["noise_sigma"]), box_centers=cen, box_sizes=siz), "after_box"),
+             (AugmentParams(noise_sigma=float(g["noise_sigma"]), box_centers=cen, box_sizes=siz, flip_dims=(2, 0)), "after_flip"),
+             (AugmentParams(noise_sigma=float(g["noise_sigma"]), box_centers=cen, box_sizes=siz, flip_dims=(2, 0),
+                            crop_center=cc, crop_size=cs), "after_crop")]
+    for ap, key in chain:
+        out = augment_image(img, ap, noise).cpu()
+        assert float((out - torch.from_numpy(g[key])).abs().max()) < 5e-6, key
+    m = augment_mask(mask, AugmentParams(flip_dims=(2, 0))).cpu()
+    assert torch.equal(m, torch.from_numpy(g["mask_after_flip"]))
+    m = augment_mask(mask, chain[-1][0]).cpu()
+    assert torch.equal(m, torch.from_numpy(g["mask_after_crop"]))
+    assert augment_mask(mask, AugmentParams(noise_sigma=0.05)) is mask                # image-only transforms leave masks alone

@@ -208,3 +208,43 @@ def test_pinned_decisions_reproduce_the_unpinned_oracle(factory, shape):
     flipped["us3.1"] = ~rec["us3.1"]
     out2, _ = run(flipped)
     assert not torch.allclose(out2[0], out0[0], rtol=1e-3)
+
+
+# ------------------------------------------------------------------ SURVEY.md §8(f) rows
+def test_processor_postprocessing_matches_reference():
+    g = np.load(os.path.join(GOLDEN, "processor.npz"))
+    full = orc.paste_resampled(torch.from_numpy(g["dense"][0]), g["crop"], g["original"])
+    assert torch.equal(full, torch.from_numpy(g["full"]))
+    assert torch.equal(orc.window_u8(full), torch.from_numpy(g["full_u8"]))
+    for p, a, b in zip(g["pcts"], g["cle_scores"], g["pse_scores"]):
+        assert orc.severity_label(float(p), orc.CLE_RATIO_MAP) == int(a)
+        assert orc.severity_label(float(p), orc.PSE_RATIO_MAP) == int(b)
+
+
+def test_epoch_end_bookkeeping_matches_reference():
+    g = np.load(os.path.join(GOLDEN, "epoch_end.npz"))
+    t = {k: torch.from_numpy(g[k]) for k in ("index", "cle", "pse", "pred_cle", "pred_pse")}
+    assert abs(float((t["pred_cle"] == t["cle"]).float().mean()) - float(g["acc_cle"])) < 1e-7
+    assert abs(float((t["pred_pse"] == t["pse"]).float().mean()) - float(g["acc_pse"])) < 1e-7
+    idx, (pc, pp, c, p) = orc.dedup_by_index(t["index"], t["pred_cle"], t["pred_pse"], t["cle"], t["pse"])
+    for a, b in ((idx, "dedup_indices"), (pc, "dedup_pred_cle"), (pp, "dedup_pred_pse"), (c, "dedup_cle"), (p, "dedup_pse")):
+        assert np.array_equal(a.numpy(), g[b]), b
+    assert np.allclose(orc.update_class_weights(torch.from_numpy(g["w_cle_before"]), c, pc).numpy(), g["w_cle_after"], rtol=1e-12)
+    assert np.allclose(orc.update_class_weights(torch.from_numpy(g["w_pse_before"]), p, pp).numpy(), g["w_pse_after"], rtol=1e-12)
+
+
+def test_augmentations_match_reference():
+    g = np.load(os.path.join(GOLDEN, "augment.npz"))
+    img, mask = torch.from_numpy(g["image"]), torch.from_numpy(g["mask"])
+    torch.manual_seed(int(g["noise_seed"]))
+    noise = torch.randn(img.shape)
+    a1 = orc.gaussian_additive(img, float(g["noise_sigma"]), noise)
+    assert torch.allclose(a1, torch.from_numpy(g["after_noise"]), rtol=0, atol=1e-6)
+    a2 = orc.box_mask_out(a1, g["box_centers"].tolist(), g["box_sizes"].tolist())
+    assert torch.equal(a2 == 0, torch.from_numpy(g["after_box"]) == 0) and torch.allclose(a2, torch.from_numpy(g["after_box"]), atol=1e-6)
+    a3, m3 = orc.flip(a2, g["flip_dims"].tolist()), orc.flip(mask, g["flip_dims"].tolist())
+    assert torch.allclose(a3, torch.from_numpy(g["after_flip"]), atol=1e-6) and torch.equal(m3, torch.from_numpy(g["mask_after_flip"]))
+    a4 = orc.crop_and_resize(a3, g["crop_center"].tolist(), g["crop_size"].tolist())
+    m4 = orc.crop_and_resize(m3, g["crop_center"].tolist(), g["crop_size"].tolist(), mask=True)
+    assert torch.allclose(a4, torch.from_numpy(g["after_crop"]), atol=1e-6)
+    assert torch.equal(m4, torch.from_numpy(g["mask_after_crop"]))
