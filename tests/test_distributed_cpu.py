@@ -154,3 +154,71 @@ def test_oracle_ddp_emulation_equals_single_process_when_loss_is_additive():
     ((o[0].sum() + o[1].sum()) / 2).backward()
     for n in ("conv1.weight", "layer3.0.conv1.weight", "fcs.1.weight"):
         assert torch.allclose(grads[n], leaves[n].grad, rtol=1e-4, atol=1e-7), n
+
+
+def _strategy_worker(rank, world, port, q):
+    """Lightning seam (B4): a stand-in DDPStrategy with the 1.9 hook names; DramDDPStrategy must attach the engine's
+    DistContext to module.model (broadcasting rank 0's parameters) and return the module UNWRAPPED."""
+    import types
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        class DDPStrategy:                                   # pytorch_lightning.strategies.DDPStrategy (1.9) outline
+            def __init__(self, **kw):
+                self._ddp_kwargs = kw
+                self.model = None
+
+            def _setup_model(self, model):
+                raise AssertionError("the stock strategy would wrap the module in DistributedDataParallel")
+
+            def _register_ddp_hooks(self):
+                raise AssertionError("no DDP hooks for the fused engine")
+
+            def configure_ddp(self):
+                self.model = self._setup_model(types.SimpleNamespace(module=self.lightning_module))
+                self._register_ddp_hooks()
+
+        pl = types.ModuleType("pytorch_lightning")
+        st = types.ModuleType("pytorch_lightning.strategies")
+        st.DDPStrategy = DDPStrategy
+        pl.strategies = st
+        sys.modules["pytorch_lightning"], sys.modules["pytorch_lightning.strategies"] = pl, st
+        from bodyct_dram_emph_subtype_amd import med3d
+        from bodyct_dram_emph_subtype_amd.lightning import make_ddp_strategy
+        torch.manual_seed(50 + rank)
+        lm = torch.nn.Module()
+        lm.model = med3d.resnet18segreg()
+        s = make_ddp_strategy(process_group_backend="gloo")
+        s.lightning_module = lm
+        s.configure_ddp()
+        ok = s._ddp_kwargs == dict(process_group_backend="gloo", find_unused_parameters=False)
+        ok = ok and s.model.module is lm and lm.model._dist is s.dram_context and s.dram_context.world == world
+        w = lm.model.conv1.weight.data
+        ws = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(ws, w)
+        ok = ok and torch.equal(ws[0], ws[1])                 # attach() broadcast rank 0's parameters
+        bad = torch.nn.Module()
+        s.lightning_module = bad
+        try:
+            s.configure_ddp()
+            ok = False
+        except RuntimeError:
+            pass
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_lightning_ddp_strategy_binding_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 27500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_strategy_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
