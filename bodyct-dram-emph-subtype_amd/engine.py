@@ -13,6 +13,7 @@ Fusion boundaries
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -44,6 +45,7 @@ class _State:
         self.grads: Dict[str, Tensor] = {}
         self.nbt: List[Tensor] = []
         self.deferred = None          # (ctx, dy) of the unit whose weight gradient is still to be launched
+        self.side = None              # second HIP stream for the weight-gradient kernels (set by backward)
 
 
 class Engine:
@@ -132,6 +134,8 @@ class Engine:
             # data parallel: this unit's weight gradient is launched inside the NEXT unit's statistic
             # all-reduce (see _bn_bwd), hiding that latency-bound collective behind a long kernel
             st.deferred = (c, dy)
+        elif st.side is not None:
+            self._wgrad_side(st, c, dy)
         else:
             self._wgrad(st, c, dy)
         if not need_dx:
@@ -145,6 +149,21 @@ class Engine:
         if st.dist is not None:
             names = [c["w"], c["bn"] + ".weight", c["bn"] + ".bias"] + ([c["b"]] if c["b"] else [])
             st.dist.grads_ready(st.grads, names)
+
+    def _wgrad_side(self, st: _State, c: dict, dy: Tensor):
+        """Weight gradient on the engine's second stream, concurrent with the data-gradient chain that continues
+        on the caller's stream: the two are independent (both only read dy), and the chain's BN-backward /
+        Winograd-transform / pooling kernels are HBM-bound while the weight-gradient GEMMs are matrix-bound, so
+        co-resident workgroups of the two streams use different pipes of a CU."""
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for t in (c["x"], dy, c.get("v")):
+            if t is not None:
+                t.record_stream(st.side)      # the allocator must not recycle them under the side stream's kernels
+        with ops.on_stream(st.side):
+            st.side.wait_event(ready)
+            self._wgrad(st, c, dy)
 
     def _flush_wgrad(self, st: _State):
         if st.deferred is not None:
@@ -268,6 +287,8 @@ class Engine:
         st: _State = saved["st"]
         if st.dist is not None:
             st.dist.begin_backward(saved["dense"].device)
+        elif os.environ.get("DRAM_WGRAD_STREAM", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+            st.side = ops.side_stream(saved["dense"].device.index)
         n0, n1 = saved["n0"], saved["n1"]
         NO = n0 + n1
         dense = saved["dense"]
@@ -325,6 +346,8 @@ class Engine:
         dy0 = self._bn_bwd(st, c0, dxs)
         st.grads["conv1.weight"] = ops.stem_bwd_weight(saved["x4"], dy0,
                                                        out=st.dist.grad_out("conv1.weight") if st.dist else None)
+        if st.side is not None:
+            torch.cuda.current_stream().wait_stream(st.side)      # every weight gradient is final from here on
         if st.dist is not None:
             st.dist.grads_ready(st.grads, ["conv1.weight", "bn1.weight", "bn1.bias"])
             st.dist.finish(st.grads)

@@ -50,6 +50,32 @@ def launch_scope(device):
             _TLS.scope = prev
 
 
+_SIDE: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def side_stream(device_index: int) -> "torch.cuda.Stream":
+    """The per-device second HIP stream of the engine (weight-gradient kernels run there, concurrently with the
+    data-gradient chain on the caller's stream)."""
+    s = _SIDE.get(device_index)
+    if s is None:
+        s = _SIDE[device_index] = torch.cuda.Stream(device=device_index)
+    return s
+
+
+@contextlib.contextmanager
+def on_stream(stream: "torch.cuda.Stream"):
+    """Launch the enclosed kernels (and make the enclosed allocations) on `stream`; inside a launch_scope the
+    cached stream handle follows."""
+    prev = getattr(_TLS, "scope", None)
+    with torch.cuda.stream(stream):
+        if prev is not None:
+            _TLS.scope = (prev[0], ctypes.c_void_p(stream.cuda_stream))
+        try:
+            yield
+        finally:
+            _TLS.scope = prev
+
+
 def _launch_device() -> int:
     sc = getattr(_TLS, "scope", None)
     return sc[0] if sc is not None else torch.cuda.current_device()
@@ -246,19 +272,21 @@ class ConvGeom:
 
 
 # --------------------------------------------------------------------------- conv
-_WORKSPACE: Dict[torch.device, Tensor] = {}
+_WORKSPACE: Dict[tuple, Tensor] = {}
 
 
 def _workspace(nbytes: int, device) -> Tensor:
-    """Grow-only scratch shared by the conv passes (they run back to back on one stream)."""
+    """Grow-only scratch shared by the conv passes that run back to back on ONE stream (one buffer per
+    (device, launch stream): the weight-gradient stream has its own)."""
     device = torch.device(device)
     n = (nbytes + 3) // 4
-    ws = _WORKSPACE.get(device)
+    key = (device, _stream().value)
+    ws = _WORKSPACE.get(key)
     if ws is None or ws.numel() < n:
-        _WORKSPACE.pop(device, None)
+        _WORKSPACE.pop(key, None)
         ws = None
         ws = torch.empty((n,), device=device, dtype=torch.float32)
-        _WORKSPACE[device] = ws
+        _WORKSPACE[key] = ws
     return ws
 
 
