@@ -46,6 +46,9 @@ class _State:
         self.nbt: List[Tensor] = []
         self.deferred = None          # (ctx, dy) of the unit whose weight gradient is still to be launched
         self.side = None              # second HIP stream for the weight-gradient kernels (set by backward)
+        self.convs: List[tuple] = []  # (weight name, geometry) in call order, recorded for the pre-pack of later steps
+        self.packed: Dict[str, tuple] = {}   # weight name -> (wf, wb) packed ahead on the side stream
+        self.packed_ready = None      # event: every entry of `packed` is complete
 
 
 class Engine:
@@ -57,6 +60,7 @@ class Engine:
         self.net, self.head = net, head
         self.kind, self.layers = ARCHS[net]
         self.e = EXPANSION[self.kind]
+        self._conv_lists: Dict[tuple, list] = {}     # input shape -> [(weight name, geometry)] of a forward
 
     # ------------------------------------------------------------------ BN helpers
     def _bn_fwd(self, st: _State, y: Tensor, sp: Optional[Tensor], bnp: str, residual, rs, relu=True):
@@ -116,8 +120,16 @@ class Engine:
         w = st.P[wname]
         B, D, H, W, Cin = x.shape
         g = ConvGeom(B, D, H, W, Cin, w.shape[0], k, stride, pad, dil)
+        st.convs.append((wname, g))
         if st.need_grad:
-            wf, wb = ops.pack_conv_weight(w, True, True, g)
+            pre = st.packed.pop(wname, None)
+            if pre is not None and pre[2] == g:
+                if st.packed_ready is not None:         # first consumer: order the caller's stream after the pre-pack
+                    torch.cuda.current_stream().wait_event(st.packed_ready)
+                    st.packed_ready = None
+                wf, wb = pre[0], pre[1]
+            else:
+                wf, wb = ops.pack_conv_weight(w, True, True, g)
         else:                                           # inference: packed / transformed once per weight version
             wf, wb = ops.packed_forward_weight(w, g), None
         y, sp, v = ops.conv3d_fwd_keep(x, wf, st.P[bname] if bname else None, g, st.training, st.need_grad)
@@ -231,11 +243,33 @@ class Engine:
         with ops.launch_scope(saved["dense"].device):
             return self._backward(saved, g_dense, g_outs)
 
+    def _prepack(self, st: _State, key):
+        """Training steps repack / re-transform every convolution weight (21 launches for ResNet-18, independent
+        of the activations).  From the second step of an input shape on they all run on the engine's second
+        stream at the start of forward, under the stem convolution, instead of in front of each layer."""
+        plan = self._conv_lists.get(key)
+        if plan is None or os.environ.get("DRAM_WGRAD_STREAM", "1") == "0" or torch.cuda.is_current_stream_capturing():
+            return
+        side = ops.side_stream(key[-1])
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)                         # the optimizer's update of the weights precedes the packing
+        with ops.on_stream(side):
+            for wname, g in plan:
+                wf, wb = ops.pack_conv_weight(st.P[wname], True, True, g)
+                wf.record_stream(main)
+                wb.record_stream(main)
+                st.packed[wname] = (wf, wb, g)
+            st.packed_ready = torch.cuda.Event()
+            st.packed_ready.record(side)
+
     def _forward(self, P, x, lungs, training, need_grad, dist):
         if need_grad and not training:
             raise NotImplementedError("gradients through eval-mode BatchNorm are not part of the hot path")
         st = _State(P, training, need_grad, dist)
         B, _, D, H, W = x.shape
+        shape_key = (tuple(x.shape), x.device.index)
+        if need_grad:
+            self._prepack(st, shape_key)
         x4 = x.reshape(B, D, H, W)
         lungs4 = None if lungs is None else lungs.reshape(B, *lungs.shape[-3:]).contiguous()
 
@@ -279,6 +313,9 @@ class Engine:
             saved = dict(st=st, x4=x4, y0=y0, xs=xs, mean0=mean0, invstd0=invstd0, count0=count0, ss0=ss0, amax=amax,
                          blocks=block_ctx, cu1=cu1, cu2=cu2, cu3=cu3, xup3=xup3, hw=hw, dense=dense, lungs4=lungs4,
                          denom=denom, n0=n0, n1=n1, xs_shape=tuple(xs.shape))
+        if need_grad:
+            self._conv_lists[shape_key] = list(st.convs)
+            st.packed.clear()
         if st.nbt:
             torch._foreach_add_(st.nbt, 1)               # one launch for all num_batches_tracked counters
         return dense_list, outs, saved
