@@ -377,26 +377,36 @@ def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True, g: Optional["ConvG
 
 
 # Packed forward weights of inference calls (no_grad): repacking / re-transforming every weight on every
-# forward is pure overhead when the weights did not change.  Key = storage address + torch version counter +
-# WEIGHT_EPOCH (bumped by the fused optimizers, whose kernels update parameters behind torch's back) + plan.
+# forward is pure overhead when the weights did not change.  Entries hang off the weight TENSOR OBJECT (weakly:
+# they die with it) and hold a reference to the storage they were packed from, so that address cannot be
+# recycled for another tensor while the entry lives; an entry is valid while the tensor still uses that storage,
+# its torch version counter is unchanged and no raw-pointer writer (FusedAdam / FusedSGD bump WEIGHT_EPOCH)
+# has run.
+import weakref  # noqa: E402
+
 WEIGHT_EPOCH = 0
-_PACKED: Dict[tuple, Tensor] = {}
+_PACKED: Dict[int, tuple] = {}      # id(weight) -> (weakref to the weight, {plan key: entry}); removed when it dies
 
 
 def weights_changed():
     """Called by anything that rewrites parameters through raw pointers (FusedAdam / FusedSGD)."""
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1
-    _PACKED.clear()
 
 
 def packed_forward_weight(w: Tensor, g: "ConvGeom") -> Tensor:
-    key = (w.data_ptr(), w._version, WEIGHT_EPOCH, g) + tuple(os.environ.get(k) for k in _PLAN_ENV)
-    wf = _PACKED.get(key)
-    if wf is None:
-        if len(_PACKED) > 1024:
-            _PACKED.clear()
-        wf = _PACKED[key] = pack_conv_weight(w, True, False, g)[0]
+    slot = _PACKED.get(id(w))
+    if slot is None or slot[0]() is not w:          # identity, never tensor ==
+        wid = id(w)
+        slot = _PACKED[wid] = (weakref.ref(w, lambda _r, wid=wid: _PACKED.pop(wid, None)), {})
+    per = slot[1]
+    key = (g,) + tuple(os.environ.get(k) for k in _PLAN_ENV)
+    ent = per.get(key)
+    st = w.untyped_storage()
+    if ent is not None and ent[0].data_ptr() == st.data_ptr() and ent[1] == (w.data_ptr(), w._version, WEIGHT_EPOCH):
+        return ent[2]
+    wf = pack_conv_weight(w, True, False, g)[0]
+    per[key] = (st, (w.data_ptr(), w._version, WEIGHT_EPOCH), wf)
     return wf
 
 

@@ -364,3 +364,36 @@ def test_full_size_train_step_vs_oracle(config):
         worst = max(worst, (e, n))
         assert e <= 2e-4, f"{n}: full-size gradient vs decision-pinned fp64 oracle {e:.2e}"
     print(f"[config {config} full size] loss {loss_hip:.6f}; worst gradient vs decision-pinned fp64 oracle {worst}")
+
+
+def test_inference_weight_cache_tracks_weight_identity_and_updates():
+    """no_grad forwards reuse packed / Winograd-transformed weights.  The cache must never serve another tensor's
+    packing (a freed weight's address recycled by a new model) nor a stale one (in-place torch update, fused
+    optimizer step through raw pointers, load_state_dict)."""
+    from bodyct_dram_emph_subtype_amd.optim import FusedAdam
+    x, lungs = make_inputs(3, (1, 1, 16, 32, 32))
+
+    def check(m, what):
+        sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        with torch.no_grad():
+            d, o = m(x.to(DEV), lungs.to(DEV))
+            d, o = m(x.to(DEV), lungs.to(DEV))            # second call: served from the cache
+            dr, orf = orc.forward(sd, x, lungs, "resnet18segreg", train=False)
+        assert_close_rel(o[0].cpu(), orf[0], OUT_TOL, what)
+        assert_close_rel(d[1].cpu(), dr[1], OUT_TOL, what)
+
+    for seed in (1, 2, 3):                                 # models die between iterations: addresses get recycled
+        m = build("resnet18segreg", seed).to(DEV).eval()
+        check(m, f"fresh model {seed}")
+    with torch.no_grad():
+        m.layer3[0].conv1.weight.mul_(1.5)                 # torch in-place update (version counter)
+    check(m, "after in-place update")
+    m.train()
+    opt = FusedAdam(m.parameters(), lr=1e-2)
+    dd, od = m(x.to(DEV), lungs.to(DEV))
+    (od[0].sum() + od[1].sum()).backward()
+    opt.step()                                             # raw-pointer update (WEIGHT_EPOCH)
+    m.eval()
+    check(m, "after a fused optimizer step")
+    m.load_state_dict(build("resnet18segreg", 7).state_dict())
+    check(m, "after load_state_dict")
