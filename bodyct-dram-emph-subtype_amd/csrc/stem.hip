@@ -15,7 +15,14 @@
 namespace {
 
 constexpr int PZ = 13, PY = 21, PX = 21;          // forward patch (4x8x8 outputs)
-constexpr int PATCH = PZ * PY * PX;               // 5733
+constexpr int PATCH = PZ * PY * PX;               // 5733 logical values
+// LDS pitches chosen against bank conflicts (64 banks x 4 B; conflict cycles counted per wave-level ds_read_b32 for
+// every lane pattern of the kernels): an x-row pitch of 24 puts the four output rows of a half-wave (offsets 2*24*ty
+// = 0, 48, 32, 16 mod 64) on disjoint even banks -- 1.16 cycles per A read where the dense pitch 21 took 2.04 --
+// and a weight-row pitch of 96 puts the two k rows of an MFMA (lanes 0-31 / 32-63) 32 banks apart (1 cycle, was 2).
+constexpr int PXP = 24;                           // patch x-row pitch in LDS
+constexpr int PATCHP = PZ * PY * PXP;             // 6552 floats
+constexpr int WLP = 96;                           // weight row pitch in LDS
 constexpr int KT = 50;                            // taps per kz plane, padded
 constexpr int WPT = (KT * 64 + 255) / 256;        // weight floats per thread (13)
 
@@ -28,9 +35,9 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const float* __restric
                                                           const float* __restrict__ w,
                                                           float* __restrict__ y, float* __restrict__ stats,
                                                           const StemGeom g) {
-  __shared__ __attribute__((aligned(16))) float lds[PATCH + 3 + KT * 64];
+  __shared__ __attribute__((aligned(16))) float lds[PATCHP + KT * WLP];
   float* patch = lds;
-  float* wl = lds + PATCH + 3;  // [KT][64]
+  float* wl = lds + PATCHP;  // [KT][WLP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
 
@@ -49,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const float* __restric
     const int py = rem / PX, px = rem - py * PX;
     const int zi = 2 * z0 - 3 + pz, yi = 2 * y0 - 3 + py, xi = 2 * x0 - 3 + px;
     const bool ok = (zi >= 0) & (zi < g.D) & (yi >= 0) & (yi < g.H) & (xi >= 0) & (xi < g.W);
-    patch[idx] = ok ? x[(((long)b * g.D + zi) * g.H + yi) * g.W + xi] : 0.f;
+    patch[(pz * PY + py) * PXP + px] = ok ? x[(((long)b * g.D + zi) * g.H + yi) * g.W + xi] : 0.f;
   }
 
   float rw[WPT];
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const float* __restric
 #pragma unroll
     for (int p = 0; p < WPT; ++p) {
       const int idx = p * 256 + tid;
-      if (idx < KT * 64) wl[idx] = rw[p];
+      if (idx < KT * 64) wl[(idx >> 6) * WLP + (idx & 63)] = rw[p];
     }
   };
 
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const float* __restric
   // rows of this wave: row = 64*wave + 32*mi + li -> (tz, ty, tx) = (wave, 4*mi + li>>3, li&7)
   int abase[2];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) abase[mi] = (2 * wave) * (PY * PX) + (2 * (4 * mi + (li >> 3))) * PX + 2 * (li & 7);
+  for (int mi = 0; mi < 2; ++mi) abase[mi] = (2 * wave) * (PY * PXP) + (2 * (4 * mi + (li >> 3))) * PXP + 2 * (li & 7);
 
   load_w(0);
   for (int kz = 0; kz < 7; ++kz) {
@@ -88,19 +95,19 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const float* __restric
     store_w();
     __syncthreads();
     if (kz + 1 < 7) load_w(kz + 1);
-    const float* pk = patch + kz * (PY * PX);
+    const float* pk = patch + kz * (PY * PXP);
 #pragma unroll
     for (int kk = 0; kk < KT / 2; ++kk) {
       constexpr int dummy = 0;
       (void)dummy;
       const int k0 = 2 * kk, k1 = 2 * kk + 1;
-      const int o0 = (k0 < 49) ? (k0 / 7) * PX + (k0 % 7) : 0;
-      const int o1 = (k1 < 49) ? (k1 / 7) * PX + (k1 % 7) : 0;
+      const int o0 = (k0 < 49) ? (k0 / 7) * PXP + (k0 % 7) : 0;
+      const int o1 = (k1 < 49) ? (k1 / 7) * PXP + (k1 % 7) : 0;
       const int ko = lh ? o1 : o0;
       const float a0 = pk[abase[0] + ko];
       const float a1 = pk[abase[1] + ko];
-      const float b0 = wl[(2 * kk + lh) * 64 + li];
-      const float b1 = wl[(2 * kk + lh) * 64 + 32 + li];
+      const float b0 = wl[(2 * kk + lh) * WLP + li];
+      const float b1 = wl[(2 * kk + lh) * WLP + 32 + li];
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -151,9 +158,12 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const float* __restric
 
 // ---------------------------------------------------------------------------------------
 constexpr int GZ = 7, GY = 21, GX = 21;   // wgrad patch: 1x8x8 outputs
-constexpr int GPATCH = GZ * GY * GX;      // 3087
+constexpr int GPATCH = GZ * GY * GX;      // 3087 logical values
+constexpr int GXP = 27;                   // x-row pitch in LDS: the 32 taps of a B read (7-value runs 27 apart, planes
+                                          // 567 apart) then hit 1.18 bank cycles per read instead of 2.0 (pitch 21)
+constexpr int GPATCHP = GZ * GY * GXP;    // 3969 floats
 constexpr int NTAP = 352;                 // 343 padded to 11 x 32
-constexpr int GLDY = 68;                  // dy row (64 co + pad)
+constexpr int GLDY = 96;                  // dy row pitch: the two k rows of an MFMA 32 banks apart (was 68: 2-way)
 constexpr int GPT = (GPATCH + 255) / 256; // 13
 
 struct StemWGeom {
@@ -165,9 +175,9 @@ struct StemWGeom {
 __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ dy,
                                                             float* __restrict__ slab, const StemWGeom g) {
-  __shared__ __attribute__((aligned(16))) float lds[GPATCH + 1 + 64 * GLDY];
+  __shared__ __attribute__((aligned(16))) float lds[GPATCHP + 3 + 64 * GLDY];
   float* patch = lds;
-  float* dyl = lds + GPATCH + 1;  // [64 vox][GLDY]
+  float* dyl = lds + GPATCHP + 3;  // [64 vox][GLDY], 16-byte aligned (3972 floats in)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int ntw = (wave < 3) ? 3 : 2;  // N tiles of this wave: wave, wave+4, wave+8
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const float* __restr
   for (int j = 0; j < 3; ++j) {
     const int tap = 32 * (wave + 4 * j) + li;
     const int kz = tap / 49, rem = tap - kz * 49, ky = rem / 7, kx = rem - ky * 7;
-    toff[j] = (tap < 343 ? kz * (GY * GX) + ky * GX + kx : 0) + 2 * lh;
+    toff[j] = (tap < 343 ? kz * (GY * GXP) + ky * GXP + kx : 0) + 2 * lh;
   }
 
   f32x16 acc[3][2];
@@ -221,7 +231,10 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const float* __restr
 #pragma unroll
     for (int p = 0; p < GPT; ++p) {
       const int idx = p * 256 + tid;
-      if (idx < GPATCH) patch[idx] = rp[p];
+      if (idx < GPATCH) {
+        const int pz = idx / (GY * GX), rem = idx - pz * (GY * GX);
+        patch[(pz * GY + rem / GX) * GXP + rem % GX] = rp[p];
+      }
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const float* __restr
 #pragma unroll 8
     for (int kk = 0; kk < 32; ++kk) {
       // vox = 2*kk + lh -> (ty, tx) = (kk>>2, 2*(kk&3) + lh); the 2*lh is folded into toff
-      const int vbase = (2 * (kk >> 2)) * GX + 4 * (kk & 3);
+      const int vbase = (2 * (kk >> 2)) * GXP + 4 * (kk & 3);
       const float a0 = dyl[(2 * kk + lh) * GLDY + li];
       const float a1 = dyl[(2 * kk + lh) * GLDY + 32 + li];
 #pragma unroll

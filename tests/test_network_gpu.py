@@ -397,3 +397,56 @@ def test_inference_weight_cache_tracks_weight_identity_and_updates():
     check(m, "after a fused optimizer step")
     m.load_state_dict(build("resnet18segreg", 7).state_dict())
     check(m, "after load_state_dict")
+
+
+@pytest.mark.slow
+def test_config4_geometry_train_step_properties():
+    """BASELINE configs[4] geometry (resnet50segreg, 1x1x256x512x512 -- 8x the voxels of the headline shape; fp32
+    storage, no activation checkpointing: ~161 GB of HBM).  No CPU oracle finishes at this size, so the step is held
+    to size-independent properties: finite loss and gradients for every parameter, dense maps inside [0, 1], the
+    pooled scores equal to the lung-masked mean of the dense maps they come from (recomputed with torch from the
+    returned volumes), BN running statistics moved, and a second identical step from the same state reproducing
+    loss and gradients BIT FOR BIT (32-bit offsets, tile counts and workspaces all exercised at 8x scale)."""
+    from bodyct_dram_emph_subtype_amd import med3d, models
+    if torch.cuda.get_device_properties(0).total_memory < 200e9:
+        pytest.skip("needs the 288 GB of an MI355X")
+    dims = (256, 512, 512)
+    torch.manual_seed(0)
+    m = med3d.resnet50segreg().to(DEV).train()
+    g = torch.Generator(device=DEV).manual_seed(1234)
+    x = torch.randn(1, 1, *dims, device=DEV, generator=g)
+    D, H, W = dims
+    z = (torch.arange(D, device=DEV).float() - (D - 1) / 2) / (0.4 * D)
+    y = (torch.arange(H, device=DEV).float() - (H - 1) / 2) / (0.35 * H)
+    xx = (torch.arange(W, device=DEV).float() - (W - 1) / 2) / (0.4 * W)
+    lungs = ((z[:, None, None] ** 2 + y[None, :, None] ** 2 + xx[None, None, :] ** 2) <= 1.0).float()[None, None].contiguous()
+    ems = ((x < -1.0).float() * lungs)
+    cle, pse = torch.tensor([3], device=DEV), torch.tensor([1], device=DEV)
+    cw, pw = torch.tensor([0.3], device=DEV), torch.tensor([0.6], device=DEV)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def step():
+        m.load_state_dict(sd0)
+        m.zero_grad(set_to_none=True)
+        dense, outs = m(x, lungs)
+        loss, _ = models.reg_train_loss(dense, outs, lungs, ems, cle, pse, cw, pw)
+        loss.backward()
+        return dense, outs, loss.detach(), {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    dense, outs, loss, grads = step()
+    assert torch.isfinite(loss)
+    assert all(bool(torch.isfinite(v).all()) for v in grads.values())
+    assert float(grads["conv1.weight"].norm()) > 0 and float(grads["layer4.2.conv3.weight"].norm()) > 0
+    lg = torch.nn.functional.interpolate(lungs, size=dense[0].shape[-3:], mode="nearest")
+    for d, o in zip(dense, outs):
+        assert float(d.min()) >= 0.0 and float(d.max()) <= 1.0      # sigmoid saturates to exactly 1.0 in fp32
+        ref = (d.double() * lg).sum() / lg.double().sum()
+        assert abs(float(o) - float(ref)) < 1e-5 * abs(float(ref))
+    assert float((m.state_dict()["bn1.running_mean"] - sd0["bn1.running_mean"]).abs().max()) > 0
+    peak = torch.cuda.max_memory_allocated() / 1e9
+    del dense, outs
+    _, _, loss2, grads2 = step()
+    assert torch.equal(loss, loss2)
+    for n in grads:
+        assert torch.equal(grads[n], grads2[n]), n
+    print(f"[configs[4] geometry] loss {float(loss):.6f}, peak HBM {peak:.0f} GB")
