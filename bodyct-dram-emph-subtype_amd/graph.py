@@ -1,0 +1,66 @@
+"""hipGraph capture of a whole train step (forward + loss + backward + fused Adam update).
+
+Small volumes make the step launch-bound: BASELINE configs[0] (ResNet-34, 1x64x128x128) issues ~700 kernels of
+5-40 us each.  Everything the engine launches is a plain kernel on torch's current stream with host-side
+arguments that do not change from step to step, and ``FusedAdam(capturable=True)`` keeps lr / step / bias
+corrections in device memory, so the step can be captured once and replayed:
+
+    opt = FusedAdam(module.parameters(), lr=1e-4, capturable=True)
+    step = GraphedTrainStep(module, opt, lambda image, lung, cle, pse: loss_of(module(image, lung), cle, pse),
+                            (image, lung, cle, pse))
+    for batch in loader:
+        loss = step(*batch)              # copies the batch into the static buffers, replays the graph
+    scheduler.step()                     # lr changes reach the captured update through the device-side copy
+
+Single GPU only (the data-parallel collectives are not captured); BN running statistics, num_batches_tracked
+and the Adam state are updated by the replay exactly as by the eager step (tests/test_models_gpu.py).
+"""
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+import torch
+
+from .optim import FusedAdam
+
+
+class GraphedTrainStep:
+    def __init__(self, module: torch.nn.Module, optimizer: FusedAdam, loss_fn: Callable[..., torch.Tensor],
+                 example_inputs: Sequence[torch.Tensor], warmup: int = 2):
+        if not isinstance(optimizer, FusedAdam) or not optimizer.capturable:
+            raise TypeError("GraphedTrainStep needs FusedAdam(..., capturable=True)")
+        if getattr(getattr(module, "model", module), "_dist", None) is not None:
+            raise NotImplementedError("graph capture of the data-parallel step is not supported")
+        self.module, self.optimizer, self.loss_fn = module, optimizer, loss_fn
+        self.static = [t.clone() for t in example_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # warm-up on a side stream, as torch.cuda.graph asks
+            for _ in range(max(1, warmup)):           # (creates optimizer state, scratch buffers, plans)
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_loss = self._eager()
+        self.steps_captured_eagerly = max(1, warmup) + 1      # the capture pass itself does not execute
+
+    def _eager(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.loss_fn(*self.static)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self, *inputs: torch.Tensor) -> torch.Tensor:
+        if len(inputs) != len(self.static):
+            raise ValueError(f"expected {len(self.static)} inputs")
+        for s, t in zip(self.static, inputs):
+            if s.shape != t.shape or s.dtype != t.dtype:
+                raise ValueError("GraphedTrainStep: input shapes / dtypes are fixed at capture time")
+            if s.data_ptr() != t.data_ptr():
+                s.copy_(t)
+        self.optimizer.sync_hyper()                   # lr moved by the scheduler since the last replay?
+        self.graph.replay()
+        self.optimizer.note_replayed_step()
+        return self.static_loss

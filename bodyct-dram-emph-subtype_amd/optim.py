@@ -40,13 +40,35 @@ class _FusedBase(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._cache_key = None
         self._cache = None
+        self._pinned_spare = None     # pinned staging pair for the next graph capture (capturable mode)
+        self._pinned_owned = []       # pairs captured graphs read on every replay: never written again
         self.grad_scale = 1.0   # DDP folds the 1/world_size of the gradient mean in here
 
     def _tables(self, key, ptrs, device):
         if key != self._cache_key:
             table, chunks = build_tables(ptrs)
-            t = torch.from_numpy(table.view(np.uint8).copy()).to(device)
-            c = torch.from_numpy(chunks.view(np.uint8).copy()).to(device)
+            ht, hc = torch.from_numpy(table.view(np.uint8).copy()), torch.from_numpy(chunks.view(np.uint8).copy())
+            capturing = torch.cuda.is_current_stream_capturing()
+            if capturing:
+                # inside a hipGraph capture neither a pageable host->device copy nor a pinned allocation is
+                # allowed: the tables go through a pinned pair that an EAGER step allocated beforehand (sizes depend
+                # only on the parameter sizes).  The pair now belongs to this graph -- its copy node re-reads it on
+                # every replay -- so it is never written again; the next eager step allocates a new spare.
+                sp = self._pinned_spare
+                if sp is None or sp[0].numel() != ht.numel() or sp[1].numel() != hc.numel():
+                    raise RuntimeError("run one eager step with the same parameters before capturing")
+                self._pinned_spare = None
+                sp[0].copy_(ht)
+                sp[1].copy_(hc)
+                t = torch.empty(ht.shape, dtype=ht.dtype, device=device)
+                c = torch.empty(hc.shape, dtype=hc.dtype, device=device)
+                t.copy_(sp[0], non_blocking=True)
+                c.copy_(sp[1], non_blocking=True)
+                self._pinned_owned.append(sp)
+            else:
+                t, c = ht.to(device), hc.to(device)        # synchronous w.r.t. the host buffers
+                if getattr(self, "capturable", False) and self._pinned_spare is None:
+                    self._pinned_spare = (torch.empty_like(ht).pin_memory(), torch.empty_like(hc).pin_memory())
             self._cache_key, self._cache = key, (t, c, len(chunks))
         return self._cache
 
@@ -60,10 +82,87 @@ class _FusedBase(torch.optim.Optimizer):
 
 
 class FusedAdam(_FusedBase):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """capturable=True keeps lr / betas / eps / weight decay / grad scale AND the step count in a device tensor
+    (`dram_adam_multi_dev`): the update can then be captured in a hipGraph together with forward and backward
+    (graph.GraphedTrainStep) and replayed across steps and lr changes; requires one parameter group whose
+    parameters share their step count."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.capturable = bool(capturable)
+        self._hyper = None            # device float32[7]: lr, b1, b2, eps, wd, grad_scale, step
+        self._hyper_host = None
+        self._replayed = 0            # graph replays whose step the host-side state has not absorbed yet
+
+    # ---- capturable mode -----------------------------------------------------------------------------------
+    def _host_hyper(self, group):
+        b1, b2 = group["betas"]
+        return [float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                float(self.grad_scale)]
+
+    def sync_hyper(self):
+        """Push lr (ExponentialLR mutates param_groups[0]['lr']) and friends to the device copy when they changed.
+        Called by step() and by GraphedTrainStep before every replay; never inside a capture."""
+        if self._hyper is None:
+            return
+        want = self._host_hyper(self.param_groups[0])
+        if want != self._hyper_host:
+            self._hyper[:6].copy_(torch.tensor(want, dtype=torch.float32))
+            self._hyper_host = want
+
+    def note_replayed_step(self):
+        """A captured step was replayed: the device-side step counter advanced without this object's step()."""
+        self._replayed += 1
+
+    def _absorb_replays(self):
+        if self._replayed:
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"] += self._replayed
+            self._replayed = 0
+
+    def state_dict(self):
+        self._absorb_replays()
+        return super().state_dict()
+
+    def _step_capturable(self):
+        if len(self.param_groups) != 1:
+            raise RuntimeError("FusedAdam(capturable=True) supports one parameter group")
+        group = self.param_groups[0]
+        plist = [p for p in group["params"] if p.grad is not None]
+        if not plist:
+            return
+        capturing = torch.cuda.is_current_stream_capturing()
+        self._absorb_replays()
+        steps = set()
+        for p in plist:
+            self._check(p)
+            st = self.state[p]
+            if len(st) == 0:
+                if capturing:
+                    raise RuntimeError("run at least one eager step before capturing (optimizer state is created lazily)")
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            steps.add(int(st["step"].item()))
+        if len(steps) != 1:
+            raise RuntimeError("FusedAdam(capturable=True): parameters must share their step count")
+        if self._hyper is None:
+            if capturing:
+                raise RuntimeError("run at least one eager step before capturing")
+            self._hyper_host = self._host_hyper(group)
+            self._hyper = torch.tensor(self._hyper_host + [float(steps.pop())], dtype=torch.float32, device=plist[0].device)
+        elif not capturing:
+            self.sync_hyper()
+        ptrs = [(p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
+                 self.state[p]["exp_avg_sq"].data_ptr(), p.numel()) for p in plist]
+        t, c, n = self._tables((0, "dev", tuple(ptrs)), ptrs, plist[0].device)
+        ops.adam_multi_dev(t, c, n, self._hyper)
+        if not capturing:             # a capture pass records the update without executing it; replays are counted
+            for p in plist:           # through note_replayed_step()
+                self.state[p]["step"] += 1
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -71,6 +170,10 @@ class FusedAdam(_FusedBase):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self.capturable:
+            self._step_capturable()
+            ops.weights_changed()
+            return loss
         for gi, group in enumerate(self.param_groups):
             by_step = {}
             for p in group["params"]:

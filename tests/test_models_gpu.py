@@ -211,3 +211,78 @@ def test_augmentations_match_reference_fixture():
     m = augment_mask(mask, chain[-1][0]).cpu()
     assert torch.equal(m, torch.from_numpy(g["mask_after_crop"]))
     assert augment_mask(mask, AugmentParams(noise_sigma=0.05)) is mask                # image-only transforms leave masks alone
+
+
+def test_graphed_train_step_equals_eager_steps():
+    """graph.GraphedTrainStep: forward + CE loss + backward + FusedAdam(capturable) captured in one hipGraph and
+    replayed.  Weights, BN running statistics, num_batches_tracked and Adam state after 3 replays (with an lr
+    change by ExponentialLR in between) must equal the eager capturable path bit for bit, and that path must
+    match plain FusedAdam to optimizer-arithmetic tolerance."""
+    from bodyct_dram_emph_subtype_amd import med3d
+    from bodyct_dram_emph_subtype_amd.graph import GraphedTrainStep
+    from bodyct_dram_emph_subtype_amd.models import cls_train_loss
+    from bodyct_dram_emph_subtype_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randn(2, 1, 16, 32, 32, generator=g).to(DEV), (torch.rand(2, 1, 16, 32, 32, generator=g) > 0.3).float().to(DEV),
+                torch.randint(0, 6, (2,), generator=g).to(DEV), torch.randint(0, 3, (2,), generator=g).to(DEV)) for _ in range(4)]
+    cw, pw = torch.full((6,), 1 / 6, device=DEV), torch.full((3,), 1 / 3, device=DEV)
+
+    def run(mode):
+        torch.manual_seed(11)
+        m = med3d.resnet18segcls(n_classes=[6, 3]).to(DEV).train()
+        opt = FusedAdam(m.parameters(), lr=1e-3, capturable=(mode != "plain"))
+        sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.5)
+
+        def loss_fn(image, lung, cle, pse):
+            return cls_train_loss(m(image, lung)[1], cle, pse, cw, pw)[0]
+
+        def eager(b):
+            opt.zero_grad(set_to_none=True)
+            loss = loss_fn(*b)
+            loss.backward()
+            opt.step()
+            return loss.detach().clone()
+        losses = []
+        if mode == "graph":
+            # the constructor runs 2 eager warm-up steps on the example batch: mirror them in the other modes
+            step = GraphedTrainStep(m, opt, loss_fn, batches[0], warmup=2)
+        else:
+            eager(batches[0]); eager(batches[0])
+            step = lambda *b: eager(b)
+        for i, b in enumerate(batches[1:]):
+            losses.append(step(*b).clone())
+            if i == 0:
+                sched.step()                       # lr 1e-3 -> 5e-4 must reach the captured update
+        torch.cuda.synchronize()
+        sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        st = opt.state_dict()["state"]
+        return losses, sd, st
+
+    l_g, sd_g, st_g = run("graph")
+    l_e, sd_e, st_e = run("eager-capturable")
+    l_p, sd_p, st_p = run("plain")
+    print("graph", [float(v) for v in l_g], "eager-capturable", [float(v) for v in l_e], "plain", [float(v) for v in l_p])
+    for a, b in zip(l_g, l_e):
+        assert torch.equal(a, b)
+    for k in sd_e:
+        assert torch.equal(sd_g[k], sd_e[k]), k
+    assert int(sd_g["bn1.num_batches_tracked"]) == 5
+    assert float(st_g[0]["step"]) == float(st_e[0]["step"]) == 5.0
+    assert torch.equal(st_g[0]["exp_avg"].cpu(), st_e[0]["exp_avg"].cpu())
+    # the device-side bias corrections (float betas, double pow in the kernel) against the host-side ones of the
+    # plain optimizer: first compared loss (after two updates) within 5e-4; later steps diverge chaotically
+    # (Adam's normalised steps flip ReLU decisions), so they are not compared
+    assert abs(float(l_e[0]) - float(l_p[0])) < 5e-4 * abs(float(l_p[0]))
+    # one update from identical state: parameter-for-parameter agreement
+    def one_step(capturable):
+        torch.manual_seed(11)
+        m = med3d.resnet18segcls(n_classes=[6, 3]).to(DEV).train()
+        opt = FusedAdam(m.parameters(), lr=1e-3, capturable=capturable)
+        loss = cls_train_loss(m(batches[0][0], batches[0][1])[1], batches[0][2], batches[0][3], cw, pw)[0]
+        loss.backward()
+        opt.step()
+        return {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    a, b = one_step(True), one_step(False)
+    for k in a:
+        if a[k].is_floating_point():
+            assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7), k
