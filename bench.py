@@ -211,6 +211,9 @@ def main():
                     help="kernel timeline (roofline table): 'after' = a second pass of the same K steps right after "
                          "the timed region (default: the ~1,400 hipEventRecords per step cost 4-5 %% of a step, "
                          "so `value` is timed without them); 'in' = inside the timed region; 'off' = none")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the train step (fwd + loss + bwd + Adam) in one hipGraph and time its replays "
+                         "(single GPU; for launch-bound small volumes such as config 0)")
     ap.add_argument("--force-dist", action="store_true",
                     help="keep the data-parallel collectives (RCCL) in place at world size 1")
     args = ap.parse_args()
@@ -250,9 +253,30 @@ def main():
     if use_dist:
         from bodyct_dram_emph_subtype_amd import distributed as ddist
         dctx = ddist.attach(module, force=args.force_dist)
-    opt = FusedAdam(module.parameters(), lr=args.lr)
+    opt = FusedAdam(module.parameters(), lr=args.lr, capturable=args.graph)
     batch = synth_batch(B, dims, rank, device)
     step = make_step(factory, module, opt, batch)
+    if args.graph:
+        if use_dist:
+            raise SystemExit("--graph is single-GPU")
+        from bodyct_dram_emph_subtype_amd.graph import GraphedTrainStep
+        from bodyct_dram_emph_subtype_amd.models import cls_train_loss, reg_train_loss
+        if factory.endswith("cls"):
+            cw = torch.full((6,), 1.0 / 6, device=device)
+            pw = torch.full((3,), 1.0 / 3, device=device)
+
+            def loss_fn(image, lung, em, cle, pse):
+                return cls_train_loss(module(image, lung)[1], cle, pse, cw, pw)[0]
+        else:
+            cwt = torch.full((B,), 1.0 / 6, device=device)
+            pwt = torch.full((B,), 1.0 / 3, device=device)
+
+            def loss_fn(image, lung, em, cle, pse):
+                dense, outs = module(image, lung)
+                return reg_train_loss(dense, outs, lung, em, cle, pse, cwt, pwt)[0]
+        eager_step = step
+        graphed = GraphedTrainStep(module, opt, loss_fn, batch, warmup=2)
+        step = lambda: graphed(*batch)      # noqa: E731
 
     def barrier():
         if world > 1:
@@ -276,7 +300,10 @@ def main():
     dt = time.perf_counter() - t0
     ops.set_profiler(None)
     tl_step_s = dt / args.steps
-    if timeline and args.timeline == "after":
+    if args.graph:
+        step = eager_step                   # the timeline pass brackets individual launches: eager
+    # every rank runs the second pass (its steps contain collectives); rank 0 records the timeline
+    if args.timeline == "after":
         # same K steps again, every kernel launch bracketed by hipEvents on its launch stream.  The timeline pass
         # runs the step on ONE stream (DRAM_WGRAD_STREAM=0): with the weight-gradient kernels overlapping the
         # data-gradient chain on a second stream a kernel's event interval would also contain the time it
@@ -284,7 +311,8 @@ def main():
         os.environ["DRAM_WGRAD_STREAM"] = "0"
         step()
         barrier()
-        timeline.start()
+        if timeline:
+            timeline.start()
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -321,7 +349,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{args.config}]: {factory} train step (fwd+loss+bwd+Adam), "
                                    f"batch {B}/GPU, 1x{dims[0]}x{dims[1]}x{dims[2]}, fp32, inputs resident in HBM",
-                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(args.graph),
                        "train_gflop_per_volume": gflop_per_vol},
             "loss": float(loss.detach()),
             "peak_hbm_gb": torch.cuda.max_memory_allocated(device) / 1e9,
