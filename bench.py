@@ -355,7 +355,8 @@ def main():
             "peak_hbm_gb": torch.cuda.max_memory_allocated(device) / 1e9,
         }
         if dctx is not None:
-            out["collectives_per_step"] = {k: v / (args.steps + args.warmup) for k, v in dctx.stats.items()}
+            ran = args.warmup + args.steps + (args.steps + 1 if args.timeline == "after" else 0)
+            out["collectives_per_step"] = {k: v / ran for k, v in dctx.stats.items()}
         if timeline:
             fams = timeline.families()
             rows = family_table(fams, args.steps, tl_step_s)
