@@ -48,7 +48,7 @@ tot = sum(float(r["TotalDurationNs"]) for r in rows)
 fam = collections.defaultdict(lambda: [0.0, 0])
 with open(os.path.join(dst, f"{tag}_rocprofv3_summary.txt"), "w") as out:
     out.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --timeline off "
-              "--no-cpu-baseline   (config 1, one MI355X)\n")
+              "--no-cpu-baseline   (config 1, one MI355X; DRAM_WGRAD_STREAM=0: single-stream pass)\n")
     out.write(f"# total kernel time {tot / steps / 1e6:.2f} ms/step over 7 steps (2 warm-up + 5 timed); "
               "columns: ms/step, calls/step, avg us, %, kernel\n")
     for r in rows[:48]:
