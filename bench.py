@@ -300,14 +300,10 @@ def main():
     dt = time.perf_counter() - t0
     ops.set_profiler(None)
     tl_step_s = dt / args.steps
-<<<<<<< Updated upstream
     if args.graph:
         step = eager_step                   # the timeline pass brackets individual launches: eager
     # every rank runs the second pass (its steps contain collectives); rank 0 records the timeline
     if args.timeline == "after":
-=======
-    if timeline and args.timeline == "after":
->>>>>>> Stashed changes
         # same K steps again, every kernel launch bracketed by hipEvents on its launch stream.  The timeline pass
         # runs the step on ONE stream (DRAM_WGRAD_STREAM=0): with the weight-gradient kernels overlapping the
         # data-gradient chain on a second stream a kernel's event interval would also contain the time it
@@ -315,12 +311,8 @@ def main():
         os.environ["DRAM_WGRAD_STREAM"] = "0"
         step()
         barrier()
-<<<<<<< Updated upstream
         if timeline:
             timeline.start()
-=======
-        timeline.start()
->>>>>>> Stashed changes
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()

@@ -142,12 +142,14 @@ class Engine:
 
     def _conv_bn_bwd(self, st: _State, c: dict, dz: Tensor, need_dx=True, add=None, gate=None):
         dy = self._bn_bwd(st, c, dz)
-        if st.dist is not None:
-            # data parallel: this unit's weight gradient is launched inside the NEXT unit's statistic
+        if st.side is not None:
+            # second stream: concurrent with the data-gradient chain (and, data parallel, with the host-visible
+            # wait for the next unit's statistic all-reduce: the GPU keeps executing this kernel meanwhile)
+            self._wgrad_side(st, c, dy)
+        elif st.dist is not None:
+            # data parallel on ONE stream: this unit's weight gradient is launched inside the NEXT unit's statistic
             # all-reduce (see _bn_bwd), hiding that latency-bound collective behind a long kernel
             st.deferred = (c, dy)
-        elif st.side is not None:
-            self._wgrad_side(st, c, dy)
         else:
             self._wgrad(st, c, dy)
         if not need_dx:
@@ -170,11 +172,14 @@ class Engine:
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)
-        for t in (c["x"], dy, c.get("v")):
+        arena = st.dist.grad_out(c["w"]) if st.dist is not None else None     # written by the side stream's kernel
+        for t in (c["x"], dy, c.get("v"), arena):
             if t is not None:
                 t.record_stream(st.side)      # the allocator must not recycle them under the side stream's kernels
         with ops.on_stream(st.side):
             st.side.wait_event(ready)
+            # data parallel: grads_ready() inside _wgrad launches the arena all-reduce from THIS stream context,
+            # so the collective is ordered after the weight-gradient kernels that fill the range
             self._wgrad(st, c, dy)
 
     def _flush_wgrad(self, st: _State):
@@ -324,7 +329,7 @@ class Engine:
         st: _State = saved["st"]
         if st.dist is not None:
             st.dist.begin_backward(saved["dense"].device)
-        elif os.environ.get("DRAM_WGRAD_STREAM", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+        if os.environ.get("DRAM_WGRAD_STREAM", "1") != "0" and not torch.cuda.is_current_stream_capturing():
             st.side = ops.side_stream(saved["dense"].device.index)
         n0, n1 = saved["n0"], saved["n1"]
         NO = n0 + n1

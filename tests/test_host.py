@@ -245,3 +245,16 @@ def test_processor_labels_reports_and_augment_parameter_boxes(tmp_path):
     draws = [transforms.TrainAugment(rng=__import__("random").Random(s)).draw() for s in range(200)]
     assert 60 < sum(d.noise_sigma is not None for d in draws) < 140 and all(len(d.box_centers) <= 10 for d in draws)
     assert all(0.03 <= d.noise_sigma <= 0.06 for d in draws if d.noise_sigma is not None)
+
+
+def test_every_python_source_compiles_and_has_no_merge_markers():
+    """bench.py, __graft_entry__.py, tools/ and the package are not imported by the CPU suite as a whole; a stray
+    merge marker or syntax error must not wait for the GPU box to be found."""
+    import glob
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for sub in ("bodyct-dram-emph-subtype_amd", "tools", "tests", "oracle", os.path.join("tests", "golden")):
+        files += glob.glob(os.path.join(ROOT, sub, "*.py"))
+    for f in files:
+        src = open(f).read()
+        compile(src, f, "exec")
+        assert "<<<<<<< " not in src and ">>>>>>> " not in src, f
