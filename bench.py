@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="capture the train step (fwd + loss + bwd + Adam) in one hipGraph and time its replays "
                          "(single GPU; for launch-bound small volumes such as config 0)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend; gloo + --share-gpu rehearses the N>1 control flow on a one-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only, not a measurement)")
     ap.add_argument("--force-dist", action="store_true",
                     help="keep the data-parallel collectives (RCCL) in place at world size 1")
     args = ap.parse_args()
@@ -232,6 +235,8 @@ def main():
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(factory, dims)          # first: the GPU burst below is then the tail of the run
 
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -239,7 +244,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)     # RCCL
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import bodyct_dram_emph_subtype_amd as dram
     from bodyct_dram_emph_subtype_amd import med3d, ops
@@ -322,7 +330,7 @@ def main():
     if timeline:
         timeline.stop()
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     if rank == 0 and prof is not None:
