@@ -37,11 +37,12 @@ BN_MOMENTUM = 0.1
 class _State:
     """Per-call state: parameter/buffer dicts, flags, saved contexts, gradient sink."""
 
-    def __init__(self, P: Dict[str, Tensor], training: bool, need_grad: bool, dist=None):
+    def __init__(self, P: Dict[str, Tensor], training: bool, need_grad: bool, dist=None, recompute: bool = False):
         self.P = P
         self.training = training
         self.need_grad = need_grad
         self.dist = dist
+        self.recompute = bool(recompute) and need_grad
         self.grads: Dict[str, Tensor] = {}
         self.nbt: List[Tensor] = []
         self.deferred = None          # (ctx, dy) of the unit whose weight gradient is still to be launched
@@ -116,7 +117,10 @@ class Engine:
 
     # ------------------------------------------------------------------ conv + BN unit
     def _conv_bn_fwd(self, st: _State, x: Tensor, wname: str, bname: Optional[str], bnp: str, k: int, stride: int,
-                     pad: int, dil: int, residual=None, rs: int = 1):
+                     pad: int, dil: int, residual=None, rs: int = 1, xr=None):
+        """xr: how to RE-DERIVE x in backward (activation-recompute mode): ('bn', ctx of the unit whose BN+ReLU output
+        x is) or ('upcat', src, skip).  With st.recompute the context then holds neither x nor the cached
+        Winograd-domain image of x, and a unit without residual does not hold its z (its consumer re-derives it)."""
         w = st.P[wname]
         B, D, H, W, Cin = x.shape
         g = ConvGeom(B, D, H, W, Cin, w.shape[0], k, stride, pad, dil)
@@ -132,12 +136,15 @@ class Engine:
                 wf, wb = ops.pack_conv_weight(w, True, True, g)
         else:                                           # inference: packed / transformed once per weight version
             wf, wb = ops.packed_forward_weight(w, g), None
-        y, sp, v = ops.conv3d_fwd_keep(x, wf, st.P[bname] if bname else None, g, st.training, st.need_grad)
+        y, sp, v = ops.conv3d_fwd_keep(x, wf, st.P[bname] if bname else None, g, st.training,
+                                       st.need_grad and not st.recompute)
         z, mean, invstd, count, ss = self._bn_fwd(st, y, sp, bnp, residual, rs)
         c = None
         if st.need_grad:
-            c = dict(x=x, y=y, z=z, mean=mean, invstd=invstd, g=g, wb=wb, count=count, w=wname, b=bname, bn=bnp, v=v,
-                     ss=ss)
+            drop_x = st.recompute and xr is not None
+            c = dict(x=None if drop_x else x, xr=xr if drop_x else None, y=y,
+                     z=None if (st.recompute and residual is None) else z, mean=mean, invstd=invstd, g=g, wb=wb,
+                     count=count, w=wname, b=bname, bn=bnp, v=v, ss=ss)
         return z, c
 
     def _conv_bn_bwd(self, st: _State, c: dict, dz: Tensor, need_dx=True, add=None, gate=None):
@@ -156,9 +163,30 @@ class Engine:
             return None
         return ops.conv3d_bwd_data(dy, c["wb"], c["g"], add, gate)
 
+    @staticmethod
+    def _recipe_inputs(c: dict):
+        """tensors the re-derivation of c's input reads"""
+        xr = c.get("xr")
+        if xr is None:
+            return ()
+        if xr[0] == "bn":
+            return (xr[1]["y"],) + tuple(xr[1]["ss"])
+        return (xr[1], xr[2])
+
+    def _input_of(self, c: dict) -> Tensor:
+        """The unit's input: saved, or (activation recompute) re-derived with the kernels that produced it in the
+        forward pass -- bit-identical to the tensor the forward convolution read."""
+        if c["x"] is not None:
+            return c["x"]
+        xr = c["xr"]
+        if xr[0] == "bn":
+            sc, sh = xr[1]["ss"]
+            return ops.bn_apply(xr[1]["y"], sc, sh, None, 1, True)
+        return ops.upcat_fwd(xr[1], xr[2])
+
     def _wgrad(self, st: _State, c: dict, dy: Tensor):
         out = st.dist.grad_out(c["w"]) if st.dist is not None else None
-        st.grads[c["w"]] = ops.conv3d_bwd_weight(c["x"], dy, c["g"], out=out, v_cache=c.get("v"))
+        st.grads[c["w"]] = ops.conv3d_bwd_weight(self._input_of(c), dy, c["g"], out=out, v_cache=c.get("v"))
         c["v"] = None                                   # release the cached Winograd-domain input
         if st.dist is not None:
             names = [c["w"], c["bn"] + ".weight", c["bn"] + ".bias"] + ([c["b"]] if c["b"] else [])
@@ -173,7 +201,7 @@ class Engine:
         ready = torch.cuda.Event()
         ready.record(main)
         arena = st.dist.grad_out(c["w"]) if st.dist is not None else None     # written by the side stream's kernel
-        for t in (c["x"], dy, c.get("v"), arena):
+        for t in (c["x"], dy, c.get("v"), arena) + self._recipe_inputs(c):
             if t is not None:
                 t.record_stream(st.side)      # the allocator must not recycle them under the side stream's kernels
         with ops.on_stream(st.side):
@@ -193,12 +221,12 @@ class Engine:
         if self.kind == "basic":
             z1, c1 = self._conv_bn_fwd(st, x, p + ".conv1.weight", None, p + ".bn1", 3, stride, dil, dil)
             z2, c2 = self._conv_bn_fwd(st, z1, p + ".conv2.weight", None, p + ".bn2", 3, 1, dil, dil,
-                                       residual=x, rs=stride if has_ds else 1)
+                                       residual=x, rs=stride if has_ds else 1, xr=("bn", c1))
             return z2, (c1, c2, has_ds)
         z1, c1 = self._conv_bn_fwd(st, x, p + ".conv1.weight", None, p + ".bn1", 1, 1, 0, 1)
-        z2, c2 = self._conv_bn_fwd(st, z1, p + ".conv2.weight", None, p + ".bn2", 3, stride, dil, dil)
+        z2, c2 = self._conv_bn_fwd(st, z1, p + ".conv2.weight", None, p + ".bn2", 3, stride, dil, dil, xr=("bn", c1))
         z3, c3 = self._conv_bn_fwd(st, z2, p + ".conv3.weight", None, p + ".bn3", 1, 1, 0, 1,
-                                   residual=x, rs=stride if has_ds else 1)
+                                   residual=x, rs=stride if has_ds else 1, xr=("bn", c2))
         del e
         return z3, (c1, c2, c3, has_ds)
 
@@ -220,9 +248,11 @@ class Engine:
     def _up_fwd(self, st, src, skip, p):
         cat = ops.upcat_fwd(src, skip)
         za, ca = self._conv_bn_fwd(st, cat, f"{p}.conv_blocks.0.0.weight", f"{p}.conv_blocks.0.0.bias",
-                                   f"{p}.conv_blocks.0.1", 3, 1, 1, 1)
+                                   f"{p}.conv_blocks.0.1", 3, 1, 1, 1, xr=("upcat", src, skip))
         zb, cb = self._conv_bn_fwd(st, za, f"{p}.conv_blocks.1.0.weight", f"{p}.conv_blocks.1.0.bias",
-                                   f"{p}.conv_blocks.1.1", 3, 1, 1, 1)
+                                   f"{p}.conv_blocks.1.1", 3, 1, 1, 1, xr=("bn", ca))
+        if st.recompute and cb is not None:
+            cb["z"] = zb                                # a block output: the next stage reads it (kept)
         return zb, (ca, cb, tuple(src.shape), tuple(skip.shape))
 
     def _up_bwd(self, st, ctx, dz, skip_view=False):
@@ -237,12 +267,12 @@ class Engine:
 
     # ------------------------------------------------------------------ whole network
     def forward(self, P: Dict[str, Tensor], x: Tensor, lungs: Optional[Tensor], training: bool, need_grad: bool,
-                dist=None):
+                dist=None, recompute: bool = False):
         """x [B,1,D,H,W] (NCDHW == NDHW for C=1), lungs None or [B,1,D,H,W] float.
         Returns (dense_list, outs_list, saved-or-None).  Every kernel is launched on x's device (its
         current stream); operands on any other device are rejected before launch."""
         with ops.launch_scope(x.device):
-            return self._forward(P, x, lungs, training, need_grad, dist)
+            return self._forward(P, x, lungs, training, need_grad, dist, recompute)
 
     def backward(self, saved: dict, g_dense: List[Optional[Tensor]], g_outs: List[Optional[Tensor]]):
         with ops.launch_scope(saved["dense"].device):
@@ -267,10 +297,10 @@ class Engine:
             st.packed_ready = torch.cuda.Event()
             st.packed_ready.record(side)
 
-    def _forward(self, P, x, lungs, training, need_grad, dist):
+    def _forward(self, P, x, lungs, training, need_grad, dist, recompute=False):
         if need_grad and not training:
             raise NotImplementedError("gradients through eval-mode BatchNorm are not part of the hot path")
-        st = _State(P, training, need_grad, dist)
+        st = _State(P, training, need_grad, dist, recompute)
         B, _, D, H, W = x.shape
         shape_key = (tuple(x.shape), x.device.index)
         if need_grad:
@@ -414,5 +444,9 @@ def forward_decisions(saved: dict) -> Dict[str, Tensor]:
         units.extend(cu[:2])
     units.append(saved["cu3"])
     for c in units:
-        out[c["bn"]] = mask(c["z"])
+        if c["z"] is not None:
+            out[c["bn"]] = mask(c["z"])
+        else:                               # activation recompute: z was not kept; same fma as bn_apply_kernel
+            sc, sh = c["ss"]
+            out[c["bn"]] = (torch.addcmul(sh, c["y"], sc) > 0).permute(0, 4, 1, 2, 3).contiguous()
     return out

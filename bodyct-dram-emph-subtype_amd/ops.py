@@ -58,7 +58,8 @@ def side_stream(device_index: int) -> "torch.cuda.Stream":
     data-gradient chain on the caller's stream)."""
     s = _SIDE.get(device_index)
     if s is None:
-        s = _SIDE[device_index] = torch.cuda.Stream(device=device_index)
+        prio = int(os.environ.get("DRAM_SIDE_PRIORITY", "0"))     # A/B switch (tools): HIP stream priority of the side stream
+        s = _SIDE[device_index] = torch.cuda.Stream(device=device_index, priority=prio)
     return s
 
 

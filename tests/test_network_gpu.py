@@ -400,7 +400,8 @@ def test_inference_weight_cache_tracks_weight_identity_and_updates():
 
 
 @pytest.mark.slow
-def test_config4_geometry_train_step_properties():
+@pytest.mark.parametrize("recompute", [False, True], ids=["keep", "recompute"])
+def test_config4_geometry_train_step_properties(recompute):
     """BASELINE configs[4] geometry (resnet50segreg, 1x1x256x512x512 -- 8x the voxels of the headline shape; fp32
     storage, no activation checkpointing: ~161 GB of HBM).  No CPU oracle finishes at this size, so the step is held
     to size-independent properties: finite loss and gradients for every parameter, dense maps inside [0, 1], the
@@ -413,6 +414,9 @@ def test_config4_geometry_train_step_properties():
     dims = (256, 512, 512)
     torch.manual_seed(0)
     m = med3d.resnet50segreg().to(DEV).train()
+    m.activation_recompute = recompute
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
     g = torch.Generator(device=DEV).manual_seed(1234)
     x = torch.randn(1, 1, *dims, device=DEV, generator=g)
     D, H, W = dims
@@ -449,4 +453,38 @@ def test_config4_geometry_train_step_properties():
     assert torch.equal(loss, loss2)
     for n in grads:
         assert torch.equal(grads[n], grads2[n]), n
-    print(f"[configs[4] geometry] loss {float(loss):.6f}, peak HBM {peak:.0f} GB")
+    print(f"[configs[4] geometry, activation recompute {recompute}] loss {float(loss):.6f}, peak HBM {peak:.0f} GB")
+
+
+@pytest.mark.parametrize("factory,shape", [("resnet18segreg", (2, 1, 16, 32, 32)), ("resnet50segcls", (1, 1, 16, 32, 32)),
+                                           ("resnet34segreg", (1, 1, 32, 64, 64))])
+def test_activation_recompute_is_bit_identical_and_smaller(factory, shape):
+    """module.activation_recompute = True: backward re-derives intra-block BN+ReLU outputs, the upsample+concat
+    tensors and the Winograd-domain images instead of keeping them (the build-side "activation checkpointing" of
+    BASELINE configs[4]).  Same kernels on the same inputs -> every gradient, output and running statistic must
+    be BIT-identical to the default mode; the memory held between forward and backward must be smaller."""
+    x, lungs = make_inputs(17, shape)
+    res = {}
+    for mode in (False, True):
+        m = build(factory, 4).to(DEV).train()
+        m.activation_recompute = mode
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        dense, outs = m(x.to(DEV), lungs.to(DEV))
+        held = torch.cuda.memory_allocated() - base
+        pins = pinned_decisions(dense[0])
+        loss = (outs[0].sum() * 0.7 - outs[1].sum() * 1.3 + 0.1 * (dense[0] * dense[0]).mean())
+        loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = (loss.detach().cpu(), {n: p.grad.cpu() for n, p in m.named_parameters()},
+                     {k: v.cpu() for k, v in m.state_dict().items() if "running" in k}, held, pins)
+    assert torch.equal(res[False][0], res[True][0])
+    for n in res[False][1]:
+        assert torch.equal(res[False][1][n], res[True][1][n]), n
+    for k in res[False][2]:
+        assert torch.equal(res[False][2][k], res[True][2][k]), k
+    for k in res[False][4]:
+        assert torch.equal(res[False][4][k], res[True][4][k]), k          # exported decisions agree too
+    assert res[True][3] < 0.9 * res[False][3], (res[True][3], res[False][3])
+    print(f"[{factory} {shape}] held between forward and backward: {res[False][3] / 1e6:.1f} MB -> {res[True][3] / 1e6:.1f} MB")
