@@ -211,6 +211,10 @@ def main():
                     help="kernel timeline (roofline table): 'after' = a second pass of the same K steps right after "
                          "the timed region (default: the ~1,400 hipEventRecords per step cost 4-5 %% of a step, "
                          "so `value` is timed without them); 'in' = inside the timed region; 'off' = none")
+    ap.add_argument("--predict", action="store_true",
+                    help="time the predict path instead (models.py:430-450 + processor.py:111-129: eval forward, dRAM "
+                         "up-projection x ess mask, percentages, resample + paste to an original grid) -- an extra "
+                         "number for DESIGN.md, not the BASELINE metric")
     ap.add_argument("--graph", action="store_true",
                     help="capture the train step (fwd + loss + bwd + Adam) in one hipGraph and time its replays "
                          "(single GPU; for launch-bound small volumes such as config 0)")
@@ -264,6 +268,24 @@ def main():
     opt = FusedAdam(module.parameters(), lr=args.lr, capturable=args.graph)
     batch = synth_batch(B, dims, rank, device)
     step = make_step(factory, module, opt, batch)
+    if args.predict:
+        from bodyct_dram_emph_subtype_amd import models as dmodels, processor
+        if not factory.endswith("reg"):
+            raise SystemExit("--predict needs a dRAM (reg) config: 2, 3 or 4")
+        lm = dmodels.ScanRegLightningModule.__new__(dmodels.ScanRegLightningModule)
+        torch.nn.Module.__init__(lm)
+        lm.model = module.eval()
+        image, lung, em, _, _ = batch
+        D, H, W = dims
+        pb = {"image": image[:, 0], "lung_mask": lung[:, 0] > 0, "ess_mask": (image[:, 0] < -0.5) & (lung[:, 0] > 0),
+              "crop_slice": torch.tensor([[[3, 3 + D + 8], [5, 5 + H + 16], [7, 7 + W + 16]]] * B),
+              "original_size": torch.tensor([[D + 20, H + 40, W + 40]] * B), "uid": [f"scan{i}" for i in range(B)]}
+
+        def step():
+            out = lm.predict_step(pb, 0)
+            res = processor.build_outputs([out], want_u8=True)
+            return res[0]["full_cle"].float().mean()
+        args.timeline = "off"
     if args.graph:
         if use_dist:
             raise SystemExit("--graph is single-GPU")
@@ -343,7 +365,7 @@ def main():
         vols = args.steps * B * world
         step_s = dt / args.steps
         out = {
-            "metric": f"CT volumes/sec (train step, 1x{dims[0]}x{dims[1]}x{dims[2]})",
+            "metric": f"CT volumes/sec ({'predict step + post-processing' if args.predict else 'train step'}, 1x{dims[0]}x{dims[1]}x{dims[2]})",
             "value": vols / dt,
             "unit": "volumes/sec",
             "n_gpus": world,
