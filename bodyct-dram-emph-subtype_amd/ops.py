@@ -282,12 +282,13 @@ def _workspace(nbytes: int, device) -> Tensor:
     device = torch.device(device)
     n = (nbytes + 3) // 4
     key = (device, _stream().value)
-    ws = _WORKSPACE.get(key)
+    ws = _WORKSPACE.pop(key, None)                  # re-inserted below: the dict stays in least-recently-used order
     if ws is None or ws.numel() < n:
-        _WORKSPACE.pop(key, None)
         ws = None
         ws = torch.empty((n,), device=device, dtype=torch.float32)
-        _WORKSPACE[key] = ws
+        while len(_WORKSPACE) >= 4:                 # caller stream + side stream + a graph-capture stream or two; streams
+            _WORKSPACE.pop(next(iter(_WORKSPACE)))  # that went away (old captures) must not pin up to 0.7 GB each
+    _WORKSPACE[key] = ws
     return ws
 
 
