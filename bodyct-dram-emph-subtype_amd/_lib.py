@@ -99,10 +99,6 @@ SIGNATURES = {
     "dram_bn_bwd_apply_nparts": (I, [LL, I]),
     "dram_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, D, P, P, P, LL, I, I, P]),
     "dram_colsum": (I, [P, P, LL, I, P]),
-    "dram_bn_fused_applicable": (I, [I, I]),
-    "dram_bn_stats_apply": (I, [P, I, D, P, P, P, P, F, F, I, P, P, P, P, P, P, P, LL, I, I, P]),
-    "dram_bn_bwd_fold_apply_nparts": (I, [LL, I]),
-    "dram_bn_bwd_fold_apply": (I, [P, I, P, P, P, P, P, P, P, P, D, P, P, P, P, LL, I, I, P]),
     "dram_maxpool_fwd": (I, [P, P, P, I, I, I, I, I, P]),
     "dram_maxpool_bwd": (I, [P, P, P, I, P, I, I, I, I, I, P]),
     "dram_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),

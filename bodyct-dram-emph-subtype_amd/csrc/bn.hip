@@ -256,148 +256,6 @@ __global__ void add_kernel(const float4* __restrict__ a, const float4* __restric
     os[i] = as[i] + bs[i];
 }
 
-
-// ---------------------------------------------------------------------------------------------------
-// Small layers (<= 64 statistic partials, <= 1024 channels): the three forward launches partial-fold ->
-// finalize -> apply and the two backward launches partial-fold -> apply are each ONE kernel.  Every workgroup
-// folds the partials itself (double, fixed order: identical in all workgroups) into LDS, workgroup 0 also writes
-// what the rest of the step needs (mean / invstd / scale / shift, running statistics; backward: the double sums and
-// their float copies = the BN parameter gradients).  On 8x16x16 stages a kernel costs ~6 us whatever it does, so
-// this removes 4 of 8 launches per BatchNorm (config 0: 152 launches, ~0.6 ms of an 11 ms step).
-constexpr int BNF_MAXC = 1024, BNF_MAXP = 64;
-
-template <int RES>   // 0 none, 1 same-shape identity residual
-__global__ __launch_bounds__(256) void bn_stats_apply_kernel(
-    const float* __restrict__ partial, const int nparts, const double count, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, const float momentum,
-    const float eps, const int update, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
-    float* __restrict__ shift, const float4* __restrict__ y, const float4* __restrict__ res, float4* __restrict__ z,
-    const int C, const long total4, const int relu) {
-  __shared__ float lsc[BNF_MAXC], lsh[BNF_MAXC];
-  for (int c = threadIdx.x; c < C; c += 256) {
-    // same summation order as the single-stage dram_reduce_partials (four interleaved chains p = k, k+4, ..., then
-    // ((a0 + a1) + a2) + a3): the fused and the separate path give bit-identical statistics
-    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int p = 0; p < nparts; ++p) {
-      a1[p & 3] += (double)partial[((long)p * 2 + 0) * C + c];
-      a2[p & 3] += (double)partial[((long)p * 2 + 1) * C + c];
-    }
-    const double s1 = a1[0] + a1[1] + a1[2] + a1[3], s2 = a2[0] + a2[1] + a2[2] + a2[3];
-    const double m = s1 / count;
-    double v = s2 / count - m * m;
-    if (v < 0.0) v = 0.0;
-    const double is = 1.0 / sqrt(v + (double)eps);
-    const float sc = (float)((double)gamma[c] * is);
-    const float sh = (float)((double)beta[c] - m * (double)gamma[c] * is);
-    lsc[c] = sc;
-    lsh[c] = sh;
-    if (blockIdx.x == 0) {
-      mean[c] = (float)m;
-      invstd[c] = (float)is;
-      scale[c] = sc;
-      shift[c] = sh;
-      if (update) {
-        const double unb = count > 1.0 ? v * (count / (count - 1.0)) : v;
-        rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * m);
-        rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
-      }
-    }
-  }
-  __syncthreads();
-  const int Q = C >> 2;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % Q);
-    const float4 sc = *reinterpret_cast<const float4*>(lsc + 4 * q);
-    const float4 sh = *reinterpret_cast<const float4*>(lsh + 4 * q);
-    const float4 v = y[i];
-    float4 o;
-    // same fma as bn_apply_kernel: the backward pass re-derives the ReLU mask from y with it (bitwise)
-    o.x = __builtin_fmaf(v.x, sc.x, sh.x); o.y = __builtin_fmaf(v.y, sc.y, sh.y);
-    o.z = __builtin_fmaf(v.z, sc.z, sh.z); o.w = __builtin_fmaf(v.w, sc.w, sh.w);
-    if (RES == 1) {
-      const float4 rr = res[i];
-      o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
-    }
-    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    z[i] = o;
-  }
-}
-
-// backward: partial [P][2][C] (sum g, sum g*xhat per workgroup of dram_bn_bwd_reduce) -> folded in every workgroup,
-// then the same arithmetic as bn_bwd_apply_kernel.  Workgroup 0 writes sums_out (double [2][C]) and grad_out
-// (float [2][C]: row 0 = d beta, row 1 = d gamma).
-__global__ __launch_bounds__(256) void bn_bwd_fold_apply_kernel(
-    const float* __restrict__ partial, const int nparts, const float4* __restrict__ dz, const float4* __restrict__ z,
-    const float4* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const double inv_count, double* __restrict__ sums_out, float* __restrict__ grad_out,
-    float4* __restrict__ dy, const int C, const long total4, const int relu, const float* __restrict__ scale,
-    const float* __restrict__ shift, float* __restrict__ colpart) {
-  __shared__ float lmg[BNF_MAXC], lmgx[BNF_MAXC];
-  for (int c = threadIdx.x; c < C; c += 256) {
-    // same summation order as the single-stage dram_reduce_partials (four interleaved chains p = k, k+4, ..., then
-    // ((a0 + a1) + a2) + a3): the fused and the separate path give bit-identical statistics
-    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int p = 0; p < nparts; ++p) {
-      a1[p & 3] += (double)partial[((long)p * 2 + 0) * C + c];
-      a2[p & 3] += (double)partial[((long)p * 2 + 1) * C + c];
-    }
-    const double s1 = a1[0] + a1[1] + a1[2] + a1[3], s2 = a2[0] + a2[1] + a2[2] + a2[3];
-    lmg[c] = (float)(s1 * inv_count);
-    lmgx[c] = (float)(s2 * inv_count);
-    if (blockIdx.x == 0) {
-      sums_out[c] = s1;
-      sums_out[C + c] = s2;
-      grad_out[c] = (float)s1;
-      grad_out[C + c] = (float)s2;
-    }
-  }
-  __syncthreads();
-  const int Q = C >> 2;
-  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const int c = 4 * (int)(i % Q);
-    float4 g = dz[i];
-    const float4 yv = y[i];
-    if (relu) {
-      float4 zv;
-      if (z) zv = z[i];
-      else {
-        const float4 sc = *reinterpret_cast<const float4*>(scale + c);
-        const float4 sh = *reinterpret_cast<const float4*>(shift + c);
-        zv = make_float4(__builtin_fmaf(yv.x, sc.x, sh.x), __builtin_fmaf(yv.y, sc.y, sh.y),
-                         __builtin_fmaf(yv.z, sc.z, sh.z), __builtin_fmaf(yv.w, sc.w, sh.w));
-      }
-      g.x = zv.x > 0.f ? g.x : 0.f; g.y = zv.y > 0.f ? g.y : 0.f;
-      g.z = zv.z > 0.f ? g.z : 0.f; g.w = zv.w > 0.f ? g.w : 0.f;
-    }
-    const float4 mu = *reinterpret_cast<const float4*>(mean + c);
-    const float4 is = *reinterpret_cast<const float4*>(invstd + c);
-    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
-    const float4 mg = *reinterpret_cast<const float4*>(lmg + c);
-    const float4 mgx = *reinterpret_cast<const float4*>(lmgx + c);
-    float4 o;
-    o.x = ga.x * is.x * (g.x - mg.x - (yv.x - mu.x) * is.x * mgx.x);
-    o.y = ga.y * is.y * (g.y - mg.y - (yv.y - mu.y) * is.y * mgx.y);
-    o.z = ga.z * is.z * (g.z - mg.z - (yv.z - mu.z) * is.z * mgx.z);
-    o.w = ga.w * is.w * (g.w - mg.w - (yv.w - mu.w) * is.w * mgx.w);
-    dy[i] = o;
-    cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
-  }
-  if (colpart) {
-    __shared__ float4 sm[256];
-    sm[threadIdx.x] = cs;
-    __syncthreads();
-    if ((int)threadIdx.x < Q) {
-      float4 t = sm[threadIdx.x];
-      for (int k = threadIdx.x + Q; k < 256; k += Q) {
-        const float4 u = sm[k];
-        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-      }
-      *reinterpret_cast<float4*>(colpart + (long)blockIdx.x * C + 4 * threadIdx.x) = t;
-    }
-  }
-}
-
 inline int ew_grid(long total4) {
   long b = (total4 + 255) / 256;
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -547,64 +405,6 @@ extern "C" int dram_add(const float* a, const float* b, float* out, long long n,
   DramProf prof(DRAM_FAM_BN, 6, 0.0, 12.0 * (double)n, (hipStream_t)stream);
   hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n4 > 0 ? n4 : (n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)a, (const float4*)b, (float4*)out, n4, a, b, out, (long)n);
-  DRAM_LAUNCH_CHECK();
-  return DRAM_OK;
-}
-
-// ---- fused small-layer forms (see bn_stats_apply_kernel) ------------------------------------------------------
-extern "C" int dram_bn_fused_applicable(int nparts, int C) {
-  return (nparts >= 1 && nparts <= BNF_MAXP && C >= 4 && C <= BNF_MAXC && (C & 3) == 0) ? 1 : 0;
-}
-
-static inline int fused_grid(long total4) {
-  const int g = ew_grid(total4);
-  return g > 64 ? 64 : g;      // every workgroup folds the partials: few, fat workgroups
-}
-
-extern "C" int dram_bn_stats_apply(const float* partial, int nparts, double count, const float* gamma, const float* beta,
-                                   float* running_mean, float* running_var, float momentum, float eps, int update_running,
-                                   float* mean, float* invstd, float* scale, float* shift, const float* y,
-                                   const float* residual, float* z, long long rows, int C, int relu,
-                                   dram_stream_t stream) {
-  if (!partial || !gamma || !beta || !mean || !invstd || !scale || !shift || !y || !z || rows < 1 || count <= 0.0)
-    return DRAM_ERR_BAD_ARG;
-  if (!dram_bn_fused_applicable(nparts, C)) return DRAM_ERR_UNSUPPORTED;
-  if (update_running && (!running_mean || !running_var)) return DRAM_ERR_BAD_ARG;
-  const long total4 = (long)rows * (C >> 2);
-  hipStream_t s = (hipStream_t)stream;
-  DramProf prof(DRAM_FAM_BN, 7, 0.0, 16.0 * (double)total4 * (residual ? 3.0 : 2.0) + 8.0 * (double)nparts * C, s);
-  if (residual)
-    hipLaunchKernelGGL((bn_stats_apply_kernel<1>), dim3(fused_grid(total4)), dim3(256), 0, s, partial, nparts, count, gamma,
-                       beta, running_mean, running_var, momentum, eps, update_running, mean, invstd, scale, shift,
-                       (const float4*)y, (const float4*)residual, (float4*)z, C, total4, relu);
-  else
-    hipLaunchKernelGGL((bn_stats_apply_kernel<0>), dim3(fused_grid(total4)), dim3(256), 0, s, partial, nparts, count, gamma,
-                       beta, running_mean, running_var, momentum, eps, update_running, mean, invstd, scale, shift,
-                       (const float4*)y, (const float4*)nullptr, (float4*)z, C, total4, relu);
-  DRAM_LAUNCH_CHECK();
-  return DRAM_OK;
-}
-
-extern "C" int dram_bn_bwd_fold_apply_nparts(long long rows, int C) {
-  if (rows < 1 || C < 4 || (C & 3) || 256 % (C >> 2) != 0) return DRAM_ERR_UNSUPPORTED;
-  return fused_grid((long)rows * (C >> 2));
-}
-
-extern "C" int dram_bn_bwd_fold_apply(const float* partial, int nparts, const float* dz, const float* z, const float* y,
-                                      const float* mean, const float* invstd, const float* gamma, const float* scale,
-                                      const float* shift, double count, double* sums_out, float* grad_out, float* dy,
-                                      float* colsum_partial, long long rows, int C, int relu, dram_stream_t stream) {
-  if (!partial || !dz || !y || !mean || !invstd || !gamma || !sums_out || !grad_out || !dy || rows < 1 || count <= 0.0)
-    return DRAM_ERR_BAD_ARG;
-  if (!dram_bn_fused_applicable(nparts, C)) return DRAM_ERR_UNSUPPORTED;
-  if (relu && !z && !(scale && shift)) return DRAM_ERR_BAD_ARG;
-  if (colsum_partial && dram_bn_bwd_fold_apply_nparts(rows, C) < 1) return DRAM_ERR_UNSUPPORTED;
-  const long total4 = (long)rows * (C >> 2);
-  hipStream_t s = (hipStream_t)stream;
-  DramProf prof(DRAM_FAM_BN, 8, 0.0, 16.0 * (double)total4 * (relu && z ? 4.0 : 3.0) + 8.0 * (double)nparts * C, s);
-  hipLaunchKernelGGL(bn_bwd_fold_apply_kernel, dim3(fused_grid(total4)), dim3(256), 0, s, partial, nparts, (const float4*)dz,
-                     (const float4*)z, (const float4*)y, mean, invstd, gamma, 1.0 / count, sums_out, grad_out, (float4*)dy, C,
-                     total4, relu, scale, shift, colsum_partial);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

@@ -68,15 +68,6 @@ class Engine:
         P = st.P
         count = float(y.numel() // y.shape[-1])
         count_dev = None
-        syncbn = st.dist is not None and st.dist.sync_bn
-        if (st.training and not syncbn and sp is not None and ops.bn_fused_applicable(sp.shape[0], y.shape[-1])
-                and (residual is None or (rs == 1 and tuple(residual.shape) == tuple(y.shape)))):
-            # small layer: statistic fold + finalize + apply in one launch
-            z, mean, invstd, scale, shift = ops.bn_stats_apply(sp, count, P[bnp + ".weight"], P[bnp + ".bias"],
-                                                               P[bnp + ".running_mean"], P[bnp + ".running_var"],
-                                                               BN_MOMENTUM, BN_EPS, True, y, residual, relu)
-            st.nbt.append(P[bnp + ".num_batches_tracked"])
-            return z, mean, invstd, (count, None), (None if residual is not None else (scale, shift))
         if st.training:
             if st.dist is not None and st.dist.sync_bn:
                 # SyncBN (train.py:101): [sum, sum^2, count] summed over ranks in ONE in-place all-reduce;
@@ -102,18 +93,6 @@ class Engine:
         bnp = c["bn"]
         zmask, (sc, sh) = (c["z"], (None, None)) if c.get("ss") is None else (None, c["ss"])
         part = ops.bn_bwd_reduce(dz, zmask, c["y"], c["mean"], c["invstd"], True, sc, sh)
-        syncbn = st.dist is not None and st.dist.sync_bn
-        if not syncbn and ops.bn_fused_applicable(part.shape[0], part.shape[2]):
-            # small layer: partial fold + apply in one launch (the float copies of the sums ARE the BN parameter gradients)
-            dy, _, pg, colpart = ops.bn_bwd_fold_apply(part, dz, zmask, c["y"], c["mean"], c["invstd"], st.P[bnp + ".weight"],
-                                                       c["count"][0], True, sc, sh, want_colsum=bool(c.get("b")))
-            st.grads[bnp + ".weight"] = pg[1]
-            st.grads[bnp + ".bias"] = pg[0]
-            if c.get("b"):
-                if colpart is None:
-                    colpart = ops.colsum(dy)
-                st.grads[c["b"]] = ops.reduce_partials(colpart)[0].float()
-            return dy
         sums = ops.reduce_partials(part)
         # parameter gradients use the LOCAL sums (DDP averages them afterwards), the input
         # gradient the all-reduced ones -- torch SyncBatchNorm semantics.

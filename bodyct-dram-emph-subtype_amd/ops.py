@@ -691,63 +691,6 @@ def bn_bwd_apply(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, invst
     return (dy, colpart) if want_colsum else dy
 
 
-def bn_fused_applicable(nparts: int, C: int) -> bool:
-    return bool(_L().dram_bn_fused_applicable(int(nparts), int(C)))
-
-
-def bn_stats_apply(partial: Tensor, count: float, gamma: Tensor, beta: Tensor, running_mean: Tensor, running_var: Tensor,
-                   momentum: float, eps: float, update_running: bool, y: Tensor, residual: Optional[Tensor], relu: bool):
-    """Small layers: statistic fold + finalize + apply(+identity residual)(+ReLU) in ONE launch.
-    -> z, mean, invstd, scale, shift"""
-    _req(partial, "partial")
-    Pn, R, C = partial.shape
-    if R != 2 or not bn_fused_applicable(Pn, C):
-        raise ValueError("bn_stats_apply: not applicable (see dram_bn_fused_applicable)")
-    _req(y, "y")
-    if y.shape[-1] != C:
-        raise ValueError("bn_stats_apply: channel mismatch")
-    for t, n in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
-        _req(t, n, shape=(C,))
-    if residual is not None:
-        _req(residual, "residual", shape=y.shape)
-    out = torch.empty((4, C), device=y.device, dtype=torch.float32)
-    z = torch.empty_like(y)
-    _chk(_L().dram_bn_stats_apply(_p(partial), Pn, float(count), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                                  float(momentum), float(eps), int(update_running), _p(out[0]), _p(out[1]), _p(out[2]),
-                                  _p(out[3]), _p(y), _p(residual), _p(z), _rows(y), C, int(relu), _stream()),
-         "dram_bn_stats_apply")
-    return z, out[0], out[1], out[2], out[3]
-
-
-def bn_bwd_fold_apply(partial: Tensor, dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, invstd: Tensor,
-                      gamma: Tensor, count: float, relu: bool, scale: Optional[Tensor] = None,
-                      shift: Optional[Tensor] = None, want_colsum: bool = False):
-    """Small layers: fold of bn_bwd_reduce's partials + bn_bwd_apply in ONE launch.
-    -> dy, sums (float64 [2,C]), grads (float32 [2,C]: d beta, d gamma), colsum partials or None"""
-    _req(partial, "partial")
-    Pn, R, C = partial.shape
-    if R != 2 or not bn_fused_applicable(Pn, C):
-        raise ValueError("bn_bwd_fold_apply: not applicable")
-    _req(dz, "dz", shape=y.shape)
-    _req(y, "y")
-    _mask_args(z, y, scale, shift, relu)
-    _req(mean, "mean", shape=(C,))
-    _req(invstd, "invstd", shape=(C,))
-    _req(gamma, "gamma", shape=(C,))
-    colpart = None
-    if want_colsum:
-        npart = _L().dram_bn_bwd_fold_apply_nparts(_rows(y), C)
-        if npart >= 1:
-            colpart = torch.empty((npart, 1, C), device=y.device, dtype=torch.float32)
-    sums = torch.empty((2, C), device=y.device, dtype=torch.float64)
-    grads = torch.empty((2, C), device=y.device, dtype=torch.float32)
-    dy = torch.empty_like(y)
-    _chk(_L().dram_bn_bwd_fold_apply(_p(partial), Pn, _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(scale),
-                                     _p(shift), float(count), _p(sums), _p(grads), _p(dy), _p(colpart), _rows(y), C,
-                                     int(relu), _stream()), "dram_bn_bwd_fold_apply")
-    return dy, sums, grads, colpart
-
-
 def colsum(a: Tensor) -> Tensor:
     """[..., C] -> partial [P,1,C]."""
     _req(a, "a")

@@ -295,22 +295,6 @@ int dram_bn_bwd_apply(const float* dz, const float* z, const float* y, const flo
                       const float* invstd, const float* gamma, const float* scale, const float* shift,
                       const double* sums, double count, const double* count_dev, float* dy,
                       float* colsum_partial, long long rows, int C, int relu, dram_stream_t stream);
-/* Small layers (dram_bn_fused_applicable: <= 64 partials, <= 1024 channels): one launch instead of three / two.
- *   dram_bn_stats_apply   = dram_reduce_partials + dram_bn_finalize + dram_bn_apply (no residual, or a same-shape
- *                           identity residual) on the conv epilogue's statistic partials [nparts][2][C];
- *   dram_bn_bwd_fold_apply = dram_reduce_partials + dram_bn_bwd_apply on dram_bn_bwd_reduce's partials; also writes
- *                           sums_out (double [2][C]) and grad_out (float [2][C]: d beta, d gamma).
- *   colsum_partial rows: dram_bn_bwd_fold_apply_nparts(rows, C). */
-int dram_bn_fused_applicable(int nparts, int C);
-int dram_bn_stats_apply(const float* partial, int nparts, double count, const float* gamma, const float* beta,
-                        float* running_mean, float* running_var, float momentum, float eps, int update_running,
-                        float* mean, float* invstd, float* scale, float* shift, const float* y, const float* residual,
-                        float* z, long long rows, int C, int relu, dram_stream_t stream);
-int dram_bn_bwd_fold_apply_nparts(long long rows, int C);
-int dram_bn_bwd_fold_apply(const float* partial, int nparts, const float* dz, const float* z, const float* y,
-                           const float* mean, const float* invstd, const float* gamma, const float* scale,
-                           const float* shift, double count, double* sums_out, float* grad_out, float* dy,
-                           float* colsum_partial, long long rows, int C, int relu, dram_stream_t stream);
 /* partial[p][0][c] = sum_rows a[row][c]  (conv-bias gradient) */
 int dram_colsum(const float* a, float* partial, long long rows, int C, dram_stream_t stream);
 

@@ -598,42 +598,3 @@ def test_upproject(ops):
     assert rel_l2(out.cpu().reshape(up_ref.shape), up_ref) < 1e-6
     pct = partial.sum(1).cpu() / lungs.sum()
     assert torch.allclose(pct, pct_ref, rtol=1e-5)
-
-
-@pytest.mark.parametrize("C,rows,res", [(64, 2048, False), (512, 2048, True), (128, 1000, False), (1024, 512, True)])
-def test_fused_small_layer_batchnorm_equals_separate_path(ops, C, rows, res):
-    """dram_bn_stats_apply / dram_bn_bwd_fold_apply (one launch per direction for small layers) must reproduce the
-    separate partial-fold -> finalize -> apply path BIT FOR BIT: outputs, saved statistics, running statistics,
-    input gradient, parameter-gradient sums, bias column sums."""
-    g = torch.Generator().manual_seed(C + rows)
-    y = torch.randn(1, 1, 1, rows, C, generator=g).to(DEV)
-    resid = torch.randn(1, 1, 1, rows, C, generator=g).to(DEV) if res else None
-    nparts = 32
-    # statistic partials as a conv epilogue would write them: per-chunk sums of y and y*y
-    chunks = torch.chunk(y.reshape(rows, C), nparts, dim=0)
-    sp = torch.stack([torch.stack([c.sum(0), (c * c).sum(0)]) for c in chunks]).contiguous()
-    gamma, beta = torch.rand(C, generator=g).to(DEV) + 0.5, torch.randn(C, generator=g).to(DEV)
-    assert ops.bn_fused_applicable(sp.shape[0], C)
-    rm_a, rv_a = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
-    rm_b, rv_b = rm_a.clone(), rv_a.clone()
-    # separate path
-    sums = ops.reduce_partials(sp)
-    mean, invstd, scale, shift = ops.bn_finalize(sums, float(rows), gamma, beta, rm_a, rv_a, 0.1, 1e-5, True)
-    z_a = ops.bn_apply(y, scale, shift, resid, 1, True)
-    # fused
-    z_b, mean_b, invstd_b, scale_b, shift_b = ops.bn_stats_apply(sp, float(rows), gamma, beta, rm_b, rv_b, 0.1, 1e-5, True,
-                                                                  y, resid, True)
-    for a, b in ((z_a, z_b), (mean, mean_b), (invstd, invstd_b), (scale, scale_b), (shift, shift_b), (rm_a, rm_b), (rv_a, rv_b)):
-        assert torch.equal(a, b)
-    dz = torch.randn(1, 1, 1, rows, C, generator=g).to(DEV)
-    zmask = z_a if res else None
-    sc, sh = (None, None) if res else (scale, shift)
-    part = ops.bn_bwd_reduce(dz, zmask, y, mean, invstd, True, sc, sh)
-    bs = ops.reduce_partials(part)
-    dy_a, cp_a = ops.bn_bwd_apply(dz, zmask, y, mean, invstd, gamma, bs, float(rows), True, sc, sh, want_colsum=True)
-    if ops.bn_fused_applicable(part.shape[0], C):
-        dy_b, sums_b, pg, cp_b = ops.bn_bwd_fold_apply(part, dz, zmask, y, mean, invstd, gamma, float(rows), True, sc, sh,
-                                                       want_colsum=True)
-        assert torch.equal(dy_a, dy_b) and torch.equal(bs, sums_b) and torch.equal(bs.float(), pg)
-        if cp_a is not None and cp_b is not None:
-            assert torch.allclose(ops.reduce_partials(cp_a), ops.reduce_partials(cp_b), rtol=1e-6, atol=1e-6)
