@@ -198,6 +198,32 @@ def family_table(fams, steps, step_s):
     return rows
 
 
+def self_launch(n: int) -> int:
+    """Run this same command line under `python -m torch.distributed.run --nproc-per-node n` as a child
+    process (one rank per GPU, rendezvous on 127.0.0.1 at a free port), relay its stdout / stderr, return its
+    exit status.  The parent never initialises the GPU and never exec()s."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this stack
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    proc = subprocess.Popen(cmd, env=env)
+    try:
+        return proc.wait()
+    except BaseException:
+        proc.terminate()
+        try:
+            proc.wait(30)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+        raise
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +251,11 @@ def main():
                     help="keep the data-parallel collectives (RCCL) in place at world size 1")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N` (the reference's `--ngpus N` alone starts N ranks, train.py:24,100-104):
+        # start the N ranks as CHILD processes -- nothing in this parent has touched the GPU yet, and it never
+        # will: it relays the children's output and exits with their status.
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -323,11 +354,18 @@ def main():
         ops.set_profiler(prof)
     if timeline and args.timeline == "in":
         timeline.start()
+    # per-step hipEvent marks on the stream the step is launched on (median of the per-step
+    # intervals); `value` stays the wall clock over exactly K steps between two barriers (driver contract)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_step_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     ops.set_profiler(None)
     tl_step_s = dt / args.steps
     if args.graph:
@@ -341,6 +379,8 @@ def main():
         os.environ["DRAM_WGRAD_STREAM"] = "0"
         step()
         barrier()
+        if dctx is not None:
+            dctx.timing = True             # event pairs around every SyncBN statistic exchange (caller's stream)
         if timeline:
             timeline.start()
         t1 = time.perf_counter()
@@ -349,6 +389,9 @@ def main():
         barrier()
         tl_step_s = (time.perf_counter() - t1) / args.steps
         os.environ.pop("DRAM_WGRAD_STREAM", None)
+        if dctx is not None:
+            exposed_ms = dctx.exposed_ms() / args.steps
+            dctx.timing = False
     if timeline:
         timeline.stop()
     if world > 1:
@@ -372,6 +415,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * step_s,
+            "ms_per_step_median_hipevent": median_step_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -387,6 +431,10 @@ def main():
         if dctx is not None:
             ran = args.warmup + args.steps + (args.steps + 1 if args.timeline == "after" else 0)
             out["collectives_per_step"] = {k: v / ran for k, v in dctx.stats.items()}
+            if args.timeline == "after":
+                # time the data path's stream sat between issuing a SyncBN statistic exchange and continuing, per step
+                # (single-stream pass; the gradient buckets are asynchronous and not part of it)
+                out["exposed_collective_ms"] = exposed_ms
         if timeline:
             fams = timeline.families()
             rows = family_table(fams, args.steps, tl_step_s)

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void segloss_fwd_kernel(const float* __restrict__ cle, const float* __restrict__ pse,
                                                           const float* __restrict__ lungs, const float* __restrict__ ems,
                                                           const float* __restrict__ binary, NearGeom ng,
-                                                          float* __restrict__ partial, int B, int D, int H, int W) {
+                                                          float* __restrict__ partial, int B, int D, int H, int W,
+                                                          float smoothness) {
   __shared__ float red[4][6];
   const long vps = (long)D * H * W;
   const long total = vps * B;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void segloss_fwd_kernel(const float* __restric
     p = fminf(fmaxf(p, 0.f), 1.f);
     const float pt = p * t + (1.f - p) * (1.f - t);
     const float ptc = fminf(fmaxf(pt, 1e-6f), 1.f - 1e-6f);
-    const float cw = 0.85f * L + (1.f - L);
+    const float cw = smoothness * L + (1.f - L);
     const float nl = -cw * logf(ptc);
     s[0] += t;
     s[1] += nl * t;
@@ -232,7 +233,8 @@ __global__ __launch_bounds__(256) void segloss_fwd_kernel(const float* __restric
 __global__ void segloss_bwd_kernel(const float* __restrict__ cle, const float* __restrict__ pse,
                                    const float* __restrict__ lungs, const float* __restrict__ ems,
                                    const float* __restrict__ binary, NearGeom ng, const float* __restrict__ coef,
-                                   float* __restrict__ gcle, float* __restrict__ gpse, int B, int D, int H, int W) {
+                                   float* __restrict__ gcle, float* __restrict__ gpse, int B, int D, int H, int W,
+                                   float smoothness) {
   const long vps = (long)D * H * W;
   const long total = vps * B;
   const float k0 = coef[0], k1 = coef[1], k2 = coef[2], k3 = coef[3];
@@ -250,7 +252,7 @@ __global__ void segloss_bwd_kernel(const float* __restrict__ cle, const float* _
     const float p = fminf(fmaxf(sum, 0.f), 1.f);
     const float pt = p * t + (1.f - p) * (1.f - t);
     const float ptc = fminf(fmaxf(pt, 1e-6f), 1.f - 1e-6f);
-    const float cw = 0.85f * L + (1.f - L);
+    const float cw = smoothness * L + (1.f - L);
     // d/dp of -cw*log(ptc)*w, clamp gradients are inclusive at the bounds (torch.clamp)
     float gb = 0.f;
     if (pt >= 1e-6f && pt <= 1.f - 1e-6f && sum >= 0.f && sum <= 1.f)
@@ -330,28 +332,28 @@ extern "C" int dram_segloss_nblk(long long voxels_total) {
 
 extern "C" int dram_segloss_fwd(const float* cle, const float* pse, const float* lungs, const float* ems,
                                 const float* binary, int Dl, int Hl, int Wl, float* partial, int B, int D, int H,
-                                int W, dram_stream_t stream) {
+                                int W, float smoothness, dram_stream_t stream) {
   if (!cle || !pse || !lungs || !ems || !binary || !partial || B < 1 || D < 1 || H < 1 || W < 1 || Dl < 1 || Hl < 1 ||
       Wl < 1)
     return DRAM_ERR_BAD_ARG;
   const long total = (long)B * D * H * W;
   DramProf prof(DRAM_FAM_HEAD_LOSS, 2, 0.0, 4.0 * (double)total * 2.25, (hipStream_t)stream);   // cle, pse + 1/8 of 2 masks
   hipLaunchKernelGGL(segloss_fwd_kernel, dim3(dram_segloss_nblk(total)), dim3(256), 0, (hipStream_t)stream, cle, pse,
-                     lungs, ems, binary, make_near(Dl, Hl, Wl, D, H, W), partial, B, D, H, W);
+                     lungs, ems, binary, make_near(Dl, Hl, Wl, D, H, W), partial, B, D, H, W, smoothness);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
 
 extern "C" int dram_segloss_bwd(const float* cle, const float* pse, const float* lungs, const float* ems,
                                 const float* binary, int Dl, int Hl, int Wl, const float* coef, float* gcle,
-                                float* gpse, int B, int D, int H, int W, dram_stream_t stream) {
+                                float* gpse, int B, int D, int H, int W, float smoothness, dram_stream_t stream) {
   if (!cle || !pse || !lungs || !ems || !binary || !coef || !gcle || !gpse || B < 1 || D < 1 || H < 1 || W < 1 ||
       Dl < 1 || Hl < 1 || Wl < 1)
     return DRAM_ERR_BAD_ARG;
   const long total = (long)B * D * H * W;
   DramProf prof(DRAM_FAM_HEAD_LOSS, 3, 0.0, 4.0 * (double)total * 4.25, (hipStream_t)stream);
   hipLaunchKernelGGL(segloss_bwd_kernel, dim3(dram_segloss_nblk(total)), dim3(256), 0, (hipStream_t)stream, cle, pse,
-                     lungs, ems, binary, make_near(Dl, Hl, Wl, D, H, W), coef, gcle, gpse, B, D, H, W);
+                     lungs, ems, binary, make_near(Dl, Hl, Wl, D, H, W), coef, gcle, gpse, B, D, H, W, smoothness);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

@@ -44,6 +44,20 @@ class _Done:
         return True
 
 
+class _TimedWork:
+    """work handle whose wait() is bracketed by two events on the caller's stream"""
+
+    def __init__(self, work, ctx):
+        self.work, self.ctx = work, ctx
+
+    def wait(self):
+        a = self.ctx._mark()
+        r = self.work.wait()
+        if a is not None:
+            self.ctx._timed.append((a, self.ctx._mark()))
+        return r
+
+
 class DistContext:
     def __init__(self, process_group=None, sync_bn: bool = True, bucket_bytes: int = 32 << 20,
                  average: bool = True, force: Optional[bool] = None):
@@ -59,12 +73,48 @@ class DistContext:
         self.bucket_bytes = bucket_bytes
         self.average = average
         self._backend = dist.get_backend(process_group)
+        # SyncBN statistics travel on their OWN communicator: a latency-critical 2C-double exchange the data path
+        # waits for must not queue, on one RCCL stream, behind a >= 32 MB gradient bucket that itself waits for the
+        # side stream's weight-gradient kernels.  Under RCCL the group gets a high-priority HIP stream (torch hands
+        # the results over with events: work.wait() / the blocking call order the caller's stream after it).
+        self.stat_pg = process_group
+        if self.active and (self.world > 1 or self._backend == "nccl"):
+            self.stat_pg = self._new_stat_group(process_group)
+        self.timing = False                                              # bench.py --force-dist: time the exchanges
+        self._timed: List[tuple] = []
         self._slots: Dict[str, Tuple[int, int, Tuple[int, ...]]] = {}    # big params: name -> (index, offset, shape)
         self._order: List[Tuple[str, int, int]] = []                     # (name, offset, numel) in parameter order
         self._total = 0
         self.stats = dict(bn_allreduce=0, grad_allreduce=0)              # collectives issued since construction
         self.last_arena = None                                           # (ptr, bytes) of the last finished step's arena
         self._reset()
+
+    def _new_stat_group(self, process_group):
+        ranks = dist.get_process_group_ranks(process_group) if process_group is not None else None
+        if self._backend == "nccl":
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                return dist.new_group(ranks=ranks, backend="nccl", pg_options=opts)
+            except Exception:  # noqa: BLE001  (older torch: no options object) -- still a separate communicator
+                return dist.new_group(ranks=ranks, backend="nccl")
+        return dist.new_group(ranks=ranks, backend=self._backend)
+
+    def _mark(self):
+        if not self.timing or not torch.cuda.is_available():
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def exposed_ms(self, reset: bool = True) -> float:
+        """Sum of the intervals the CALLER'S stream spent between issuing a statistic exchange and being allowed
+        to continue (forward: the blocking call; backward: work.wait()), over everything timed since the last
+        reset.  Synchronises the device."""
+        torch.cuda.synchronize()
+        total = sum(a.elapsed_time(b) for a, b in self._timed)
+        if reset:
+            self._timed = []
+        return total
 
     # ---------------------------------------------------------------- layout
     def bind(self, named_params):
@@ -118,7 +168,10 @@ class DistContext:
         if not (self.sync_bn and self.active):
             return
         self.stats["bn_allreduce"] += 1
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+        a = self._mark()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.stat_pg)
+        if a is not None:
+            self._timed.append((a, self._mark()))
 
     def all_reduce_stats_async(self, flat: Tensor):
         """Same, asynchronous: returns a handle whose wait() orders the current stream (RCCL) or the
@@ -126,7 +179,8 @@ class DistContext:
         if not (self.sync_bn and self.active):
             return _Done()
         self.stats["bn_allreduce"] += 1
-        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.stat_pg, async_op=True)
+        return _TimedWork(work, self) if self.timing else work
 
     # ---------------------------------------------------------------- gradients
     def grads_ready(self, grads: Dict[str, Tensor], names: List[str]):
@@ -219,3 +273,6 @@ def broadcast_parameters(module, process_group=None, src: int = 0):
         for t in ts:
             t.copy_(flat[off:off + t.numel()].view_as(t))
             off += t.numel()
+    # written through p.data: no version counter moved, so invalidate the packed-weight cache of no_grad forwards
+    from . import ops
+    ops.weights_changed()

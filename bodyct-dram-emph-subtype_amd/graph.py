@@ -43,7 +43,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_loss = self._eager()
-        self.steps_captured_eagerly = max(1, warmup) + 1      # the capture pass itself does not execute
+        self.steps_captured_eagerly = max(1, warmup)          # the capture pass itself does not execute
 
     def _eager(self):
         self.optimizer.zero_grad(set_to_none=True)

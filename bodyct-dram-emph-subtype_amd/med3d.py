@@ -13,6 +13,10 @@ There is no CPU path: calling the network on a CPU tensor raises.
 """
 from __future__ import annotations
 
+if not __package__:          # imported top-level (this directory on sys.path): bind to the package, see _dropin.py
+    import _dropin
+    __package__ = _dropin.adopt(__name__)
+
 import os
 from typing import List, Optional
 

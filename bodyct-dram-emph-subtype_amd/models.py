@@ -13,6 +13,10 @@ The dRAM losses (models.py:512-531 + metrics.py) run as fused HIP kernels
 """
 from __future__ import annotations
 
+if not __package__:          # imported top-level (this directory on sys.path): bind to the package, see _dropin.py
+    import _dropin
+    __package__ = _dropin.adopt(__name__)
+
 from types import SimpleNamespace
 from typing import Dict, Optional
 
@@ -99,16 +103,19 @@ class _SegLossFn(torch.autograd.Function):
     nearest-resized on the fly (models.py:567-570).  One HBM pass forward, one backward."""
 
     @staticmethod
-    def forward(ctx, cle, pse, lungs, ems, binary):
+    def forward(ctx, cle, pse, lungs, ems, binary, smooth=1e-7, smoothness=0.85):
+        """smooth: BinaryDice's constant (1e-7 at models.py:412); smoothness: the in-mask BCE weight
+        (0.85 at models.py:529)."""
         B, D, H, W = cle.shape
-        part = ops.segloss_fwd(cle, pse, lungs, ems, binary)
+        part = ops.segloss_fwd(cle, pse, lungs, ems, binary, smoothness)
         st, A1, A0, I, S1, S2 = part.double().sum(0).unbind(0)
         N = float(B * D * H * W)
         alpha = (1.0 - st / B).clamp(0.3, 0.7)          # metrics.py:18
         sw = alpha * st + (1.0 - alpha) * (N - st)       # sum of w
         seg = (alpha * A1 + (1.0 - alpha) * A0) / sw
-        den = S1 + S2 + 1e-7                             # BinaryDice(1e-7), models.py:412
-        mul = (2.0 * I + 1e-7) / den
+        den = S1 + S2 + smooth                           # BinaryDice(1e-7), models.py:412
+        mul = (2.0 * I + smooth) / den
+        ctx.smooth, ctx.smoothness = float(smooth), float(smoothness)
         ctx.save_for_backward(cle, pse, lungs, ems, binary, torch.stack([alpha, sw, den, I]))
         return mul.float(), seg.float()
 
@@ -119,10 +126,10 @@ class _SegLossFn(torch.autograd.Function):
         gm = g_mul.double() if g_mul is not None else torch.zeros((), dtype=torch.float64, device=cle.device)
         gs = g_seg.double() if g_seg is not None else torch.zeros((), dtype=torch.float64, device=cle.device)
         z = torch.zeros((), dtype=torch.float64, device=cle.device)
-        coef = torch.stack([gm * 2.0 / den, gm * (2.0 * I + 1e-7) / (den * den), gs * alpha / sw,
+        coef = torch.stack([gm * 2.0 / den, gm * (2.0 * I + ctx.smooth) / (den * den), gs * alpha / sw,
                             gs * (1.0 - alpha) / sw, z, z, z, z]).float()
-        gcle, gpse = ops.segloss_bwd(cle, pse, lungs, ems, binary, coef)
-        return gcle, gpse, None, None, None
+        gcle, gpse = ops.segloss_bwd(cle, pse, lungs, ems, binary, coef, ctx.smoothness)
+        return gcle, gpse, None, None, None, None, None
 
 
 def segmentation_loss(dense_cle, dense_pse, ems, lungs, binary):

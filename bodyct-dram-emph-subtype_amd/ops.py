@@ -831,8 +831,10 @@ def head_bwd(x: Tensor, w: Tensor, dense: Optional[Tensor], gdense: Optional[Ten
     return dx, wpartial
 
 
-def segloss_fwd(cle: Tensor, pse: Tensor, lungs: Tensor, ems: Tensor, binary: Tensor) -> Tensor:
-    """cle/pse [B,D,H,W]; lungs/ems [B,Dl,Hl,Wl]; binary [B] -> partial [nblk,6]."""
+def segloss_fwd(cle: Tensor, pse: Tensor, lungs: Tensor, ems: Tensor, binary: Tensor,
+                smoothness: float = 0.85) -> Tensor:
+    """cle/pse [B,D,H,W]; lungs/ems [B,Dl,Hl,Wl]; binary [B] -> partial [nblk,6].  smoothness: the in-mask
+    weight of metrics.py:24 (0.85 at the models.py:529 call site)."""
     _req(cle, "cle")
     B, D, H, W = cle.shape
     _req(pse, "pse", shape=cle.shape)
@@ -843,18 +845,19 @@ def segloss_fwd(cle: Tensor, pse: Tensor, lungs: Tensor, ems: Tensor, binary: Te
     nblk = _L().dram_segloss_nblk(B * D * H * W)
     partial = torch.empty((nblk, 6), device=cle.device, dtype=torch.float32)
     _chk(_L().dram_segloss_fwd(_p(cle), _p(pse), _p(lungs), _p(ems), _p(binary), Dl, Hl, Wl, _p(partial), B, D, H, W,
-                               _stream()), "dram_segloss_fwd")
+                               float(smoothness), _stream()), "dram_segloss_fwd")
     return partial
 
 
-def segloss_bwd(cle: Tensor, pse: Tensor, lungs: Tensor, ems: Tensor, binary: Tensor, coef: Tensor):
+def segloss_bwd(cle: Tensor, pse: Tensor, lungs: Tensor, ems: Tensor, binary: Tensor, coef: Tensor,
+                smoothness: float = 0.85):
     B, D, H, W = cle.shape
     _req(coef, "coef", shape=(8,))
     _, Dl, Hl, Wl = lungs.shape
     gcle = torch.empty_like(cle)
     gpse = torch.empty_like(pse)
     _chk(_L().dram_segloss_bwd(_p(cle), _p(pse), _p(lungs), _p(ems), _p(binary), Dl, Hl, Wl, _p(coef), _p(gcle),
-                               _p(gpse), B, D, H, W, _stream()), "dram_segloss_bwd")
+                               _p(gpse), B, D, H, W, float(smoothness), _stream()), "dram_segloss_bwd")
     return gcle, gpse
 
 

@@ -113,8 +113,11 @@ class FusedAdam(_FusedBase):
             self._hyper_host = want
 
     def note_replayed_step(self):
-        """A captured step was replayed: the device-side step counter advanced without this object's step()."""
+        """A captured step was replayed: the device-side step counter advanced without this object's step(), and
+        the replayed update rewrote every parameter through raw pointers -- no torch version counter moved -- so
+        the packed / Winograd-transformed weights cached for no_grad forwards are stale from here on."""
         self._replayed += 1
+        ops.weights_changed()
 
     def _absorb_replays(self):
         if self._replayed:

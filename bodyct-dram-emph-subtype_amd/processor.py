@@ -8,6 +8,10 @@ derive the severity score from the lesion percentage (:34-38, :130-136) and writ
 """
 from __future__ import annotations
 
+if not __package__:          # imported top-level (this directory on sys.path): bind to the package, see _dropin.py
+    import _dropin
+    __package__ = _dropin.adopt(__name__)
+
 import json
 from typing import Dict, List, Optional, Sequence
 

@@ -16,6 +16,10 @@ The reference's DataModule (SimpleITK / COPDGene cache) is out of scope; ``--syn
 """
 from __future__ import annotations
 
+if not __package__:          # imported top-level (this directory on sys.path): bind to the package, see _dropin.py
+    import _dropin
+    __package__ = _dropin.adopt(__name__)
+
 import glob
 import logging
 import os
@@ -199,14 +203,23 @@ def run_training_job(argv=None):
             torch.save(checkpoint_dict(module, optimizer, scheduler, epoch, global_step, args), path)
             if train_loss < best[0]:               # monitor='train_loss' (train.py:92-99)
                 best = (train_loss, path)
-    if best[1] is not None or world > 1:           # trainer.test(ckpt_path='best') (train.py:108)
-        if best[1] is not None:
-            module.load_state_dict(torch.load(best[1], map_location="cpu", weights_only=False)["state_dict"])
+    best_path = best[1]
+    if world > 1:
+        # trainer.test(ckpt_path='best') restores the SAME checkpoint on every rank: rank 0 tracked `best`, so its
+        # choice is broadcast, and nobody reads the file before rank 0 has finished writing it
+        box = [str(best_path) if best_path is not None else None]
+        torch.distributed.broadcast_object_list(box, src=0)
+        best_path = box[0]
+        torch.distributed.barrier()
+    if best_path is not None:                      # trainer.test(ckpt_path='best') (train.py:108)
+        module.load_state_dict(torch.load(best_path, map_location="cpu", weights_only=False)["state_dict"])
+        from . import ops
+        ops.weights_changed()
         module.eval()
         test_outputs = [module.test_step(b, i) for i, b in enumerate(val_data.epoch(10_000))]
         te = module.test_epoch_end(test_outputs)
         if rank == 0:
-            logging.info(f"test (best = {best[1]}): acc cle/pse {float(te['acc_cle']):.3f}/{float(te['acc_pse']):.3f}")
+            logging.info(f"test (best = {best_path}): acc cle/pse {float(te['acc_cle']):.3f}/{float(te['acc_pse']):.3f}")
     if world > 1:
         torch.distributed.destroy_process_group()
     return module

@@ -11,6 +11,10 @@ with given parameters they reproduce the reference classes (tests/golden/augment
 """
 from __future__ import annotations
 
+if not __package__:          # imported top-level (this directory on sys.path): bind to the package, see _dropin.py
+    import _dropin
+    __package__ = _dropin.adopt(__name__)
+
 import ctypes
 import random
 from dataclasses import dataclass, field

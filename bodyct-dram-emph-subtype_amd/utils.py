@@ -10,6 +10,10 @@ drop-in), the reference's own ``get_model_by_name`` works unchanged.
 """
 from __future__ import annotations
 
+if not __package__:          # imported top-level (this directory on sys.path): bind to the package, see _dropin.py
+    import _dropin
+    __package__ = _dropin.adopt(__name__)
+
 import importlib
 import logging
 import os

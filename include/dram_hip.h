@@ -346,16 +346,17 @@ int dram_head_bwd(const float* x, const float* w, const float* dense, const floa
 /* ------------------------------------------------------------------------- */
 /* dRAM segmentation losses -- models.py:523-531 + metrics.py:10-37, label prep
  * models.py:567-570.  cle/pse: [B,1,D,H,W] dense maps; lungs/ems: full-res masks
- * [B,Dl,Hl,Wl] sampled nearest; binary[b] in {0,1} multiplies ems.
+ * [B,Dl,Hl,Wl] sampled nearest; binary[b] in {0,1} multiplies ems; smoothness = the
+ * in-mask weight of metrics.py:10,24 (0.85 at the models.py:529 call site).
  *   partial [nblk][6]: sum t, A1, A0, I, S1, S2 (see csrc/loss.hip). */
 int dram_segloss_nblk(long long voxels_total);
 int dram_segloss_fwd(const float* cle, const float* pse, const float* lungs, const float* ems,
                      const float* binary, int Dl, int Hl, int Wl, float* partial, int B, int D, int H,
-                     int W, dram_stream_t stream);
+                     int W, float smoothness, dram_stream_t stream);
 /* coef[8] (device): c_dice_a, c_dice_b, c_bce1, c_bce0, -, -, -, - (see loss.hip) */
 int dram_segloss_bwd(const float* cle, const float* pse, const float* lungs, const float* ems,
                      const float* binary, int Dl, int Hl, int Wl, const float* coef, float* gcle,
-                     float* gpse, int B, int D, int H, int W, dram_stream_t stream);
+                     float* gpse, int B, int D, int H, int W, float smoothness, dram_stream_t stream);
 
 /* Predict-time up-projection (models.py:438-441): out = trilinear(dense -> Do,Ho,Wo,
  * align_corners) * ess; partial [B][nblk] per-block sums of out. */

@@ -186,7 +186,7 @@ def _strategy_worker(rank, world, port, q):
         pl.strategies = st
         sys.modules["pytorch_lightning"], sys.modules["pytorch_lightning.strategies"] = pl, st
         from bodyct_dram_emph_subtype_amd import med3d
-        from bodyct_dram_emph_subtype_amd.lightning import make_ddp_strategy
+        from bodyct_dram_emph_subtype_amd.ddp_strategy import make_ddp_strategy
         torch.manual_seed(50 + rank)
         lm = torch.nn.Module()
         lm.model = med3d.resnet18segreg()
@@ -222,3 +222,21 @@ def test_lightning_ddp_strategy_binding_world2_gloo():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_bench_gpus_n_bare_command_starts_child_ranks():
+    """bench.py --gpus 2 without WORLD_SIZE must start its own ranks (no GPU here: each child stops at the
+    "needs an MI355X" check -- which proves rank processes were started under torch.distributed.run -- and
+    the parent exits with their non-zero status instead of complaining about WORLD_SIZE)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("covered by the -m gpu rehearsal on a GPU box")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--backend", "gloo", "--share-gpu"], env=env, capture_output=True, text=True, timeout=600, cwd="/tmp")
+    assert r.returncode != 0
+    assert "WORLD_SIZE=" not in r.stderr, r.stderr[-2000:]
+    # (torchrun tears the sibling down as soon as one rank exits, so the message may appear once or twice)
+    assert r.stderr.count("bench.py needs an MI355X") >= 1 and "torch.distributed.elastic" in r.stderr, r.stderr[-2000:]

@@ -69,6 +69,28 @@ def _worker(rank, world, port, outdir, factory):
         dist.destroy_process_group()
 
 
+def _run_ranks(procs, timeout=300):
+    """Start the rank processes, wait, and ALWAYS reap them: a rank still alive after the timeout (or after a
+    sibling failed) is terminated, then killed, so a hung rank cannot keep holding the GPU after the test
+    has reported its failure."""
+    try:
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout)
+        codes = [p.exitcode for p in procs]
+        assert all(c == 0 for c in codes), f"rank exit codes {codes} (None = still running after {timeout} s)"
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(10)
+            if p.is_alive():
+                p.kill()
+                p.join(10)
+
+
 @pytest.mark.parametrize("factory", ["resnet18segreg", "resnet50segcls"])
 def test_two_rank_engine_matches_ddp_syncbn_emulation(factory):
     from oracle import med3d_oracle as orc
@@ -76,12 +98,7 @@ def test_two_rank_engine_matches_ddp_syncbn_emulation(factory):
     ctx = mp.get_context("spawn")
     port = 33500 + (os.getpid() % 2000) + (7 if factory.endswith("cls") else 0)
     with tempfile.TemporaryDirectory() as outdir:
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, outdir, factory)) for r in range(2)]
-        for p in procs:
-            p.start()
-        for p in procs:
-            p.join(300)
-            assert p.exitcode == 0, f"rank process failed with {p.exitcode}"
+        _run_ranks([ctx.Process(target=_worker, args=(r, 2, port, outdir, factory)) for r in range(2)])
         res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(2)]
     torch.manual_seed(21)                        # rank 0's initial weights
     sd = {k: v.clone() for k, v in _build(factory).state_dict().items()}
@@ -155,10 +172,7 @@ def test_rccl_world1_forced_collectives_equal_plain_step():
     import tempfile
     ctx = mp.get_context("spawn")
     with tempfile.TemporaryDirectory() as outdir:
-        p = ctx.Process(target=_nccl_world1, args=(35500 + (os.getpid() % 2000), outdir))
-        p.start()
-        p.join(300)
-        assert p.exitcode == 0, f"nccl world-1 process failed with {p.exitcode}"
+        _run_ranks([ctx.Process(target=_nccl_world1, args=(35500 + (os.getpid() % 2000), outdir))])
         out = torch.load(os.path.join(outdir, "w1.pt"))
     (g0, s0, st0), (g1, s1, st1) = out[False], out[True]
     assert st0["bn_allreduce"] == 0 and st1["bn_allreduce"] == 2 * 2 * 22 and st1["grad_allreduce"] >= 2 * 2
@@ -200,12 +214,7 @@ def test_two_rank_rccl_matches_ddp_syncbn_emulation():
     ctx = mp.get_context("spawn")
     port = 36500 + (os.getpid() % 2000)
     with tempfile.TemporaryDirectory() as outdir:
-        procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, outdir)) for r in range(2)]
-        for p in procs:
-            p.start()
-        for p in procs:
-            p.join(300)
-            assert p.exitcode == 0, f"rank process failed with {p.exitcode}"
+        _run_ranks([ctx.Process(target=_nccl_worker, args=(r, 2, port, outdir)) for r in range(2)])
         res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(2)]
     torch.manual_seed(21)
     sd = {k: v.clone() for k, v in _build("resnet18segreg").state_dict().items()}
@@ -217,3 +226,27 @@ def test_two_rank_rccl_matches_ddp_syncbn_emulation():
         if n.endswith(".0.bias") and n.startswith("us"):
             continue
         assert rel_l2(res[0][1][n], ref[n]) <= 2e-4, n
+
+
+def test_bench_gpus2_self_launches_its_ranks():
+    """`python bench.py --gpus 2` as a BARE command (no outer torch.distributed.run; the reference's `--ngpus N`
+    alone starts N ranks, train.py:24,100-104): bench.py starts the two ranks itself as child processes and relays
+    rank 0's JSON line.  Rehearsed here on one GPU with gloo + --share-gpu (control flow only, not a measurement)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "0",
+           "--backend", "gloo", "--share-gpu", "--timeline", "off"]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd="/tmp")
+    try:
+        out, err = proc.communicate(timeout=420)
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+            proc.communicate()
+    assert proc.returncode == 0, err[-3000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["value"] > 0
+    assert rec["collectives_per_step"]["bn_allreduce"] == 2 * 38          # ResNet-34: 38 BN layers, both directions

@@ -108,6 +108,41 @@ def test_factories_conf_and_state_dict_contract():
         utils.get_model_by_name("nope")
 
 
+def test_hydra_style_toplevel_import_of_the_dropin_modules():
+    """SURVEY.md §8b B1 / INTEGRATION.md §A.1: with the package DIRECTORY on PYTHONPATH, what
+    hydra.utils.instantiate does for `_target_: med3d.resnet18segreg` (reference utils.py:83-85,
+    conf/med3ddram18.yaml:1) -- importlib.import_module("med3d") + getattr + call -- must give the drop-in
+    factory, and the reference's sibling imports (`from metrics import ...`, `from models import ...`,
+    `from utils import ...`) must resolve too.  Run in a clean interpreter from a foreign cwd."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg_dir = os.path.join(root, "bodyct-dram-emph-subtype_amd")
+    code = (
+        "import importlib, sys\n"
+        "assert not any(p.rstrip('/').endswith('repo') for p in sys.path[:1]), sys.path\n"
+        "mod = importlib.import_module('med3d')\n"              # hydra's _locate(): import the longest importable prefix
+        "m = getattr(mod, 'resnet18segreg')()\n"
+        "assert len(m.state_dict()) == 141\n"
+        "import bodyct_dram_emph_subtype_amd.med3d as pm\n"
+        "assert mod is pm and isinstance(m, pm.ResNetSegReg), (mod, pm)\n"
+        "c = importlib.import_module('med3d').resnet50segcls(n_classes=[6, 3])\n"
+        "assert tuple(c.fcs[0].weight.shape) == (6, 32, 1, 1, 1)\n"
+        "from metrics import BinaryCrossEntropy, BinaryDice, dice_coef\n"
+        "from utils import get_model_by_name, load_state_dict_greedy, cat_all_gather\n"
+        "from models import ScanRegLightningModule, ScanCLSLightningModule\n"
+        "import train, processor, transforms\n"
+        "import inspect\n"
+        "sig = inspect.signature(BinaryCrossEntropy.__call__)\n"
+        "assert list(sig.parameters) == ['self', 'y', 'y_hat', 'mask', 'smoothness'], sig\n"
+        "assert sig.parameters['smoothness'].default == 0.65 and sig.parameters['mask'].default is None\n"
+        "assert type(get_model_by_name('med3ddram18')).__name__ == 'ResNetSegReg'\n"
+        "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=pkg_dir)
+    r = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
 def test_greedy_loader():
     from bodyct_dram_emph_subtype_amd import med3d, utils
     a, b = med3d.resnet18segreg(), med3d.resnet18segreg()
