@@ -1,6 +1,6 @@
 """bench.py -- CT volumes/sec of the Med3D + dRAM train step on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 0|1|2|3|4]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 0|1|2|3|4|5]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = forward + loss + backward + (N>1: RCCL gradient all-reduce, SyncBN exchanges) +
@@ -44,6 +44,9 @@ CONFIGS = {
     # configs[4] geometry (full-resolution volume) in fp32 without activation checkpointing: a capacity /
     # int32-offset check of the kernels at 8x the voxels, not a BASELINE metric (that one asks for bf16)
     4: ("resnet50segreg", 1, (256, 512, 512), 8 * 10313.4, (27.67 + 30.70) * 1e9, 47.86e6),
+    # the reference's own default job (reference train.py:21,30,42: med3ddram50, target_size 128x224x288, batch 1):
+    # 63/64 of config 3's voxels; S2 = 16x28x36, so the dilated stages run ragged F(4,3) Winograd tiles
+    5: ("resnet50segreg", 1, (128, 224, 288), 10313.4 * 63 / 64, (3.458 + 3.838) * 1e9 * 63 / 64, 47.86e6),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters
 PEAK_HBM_GBS = 8000.0           # same guide: HBM3E ~8 TB/s
@@ -421,7 +424,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{args.config}]: {factory} train step (fwd+loss+bwd+Adam), "
+            "config": {"workload": f"{'BASELINE configs[%d]' % args.config if args.config <= 4 else 'reference default job (train.py:21,30,42)'}: {factory} train step (fwd+loss+bwd+Adam), "
                                    f"batch {B}/GPU, 1x{dims[0]}x{dims[1]}x{dims[2]}, fp32, inputs resident in HBM",
                        "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(args.graph),
                        "train_gflop_per_volume": gflop_per_vol},

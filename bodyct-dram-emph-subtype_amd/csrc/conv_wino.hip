@@ -1263,10 +1263,8 @@ bool wino_geom_ok(const DramConvDesc* d) {
   return true;
 }
 
-// Tiling (outputs per tile along z, y): F(4,3) on an axis when the residue sub-lattice extent of that axis
-// is a multiple of 4 (no extra padding) -- largest first among the instantiated 4x4, 4x2, 2x2 -- as long
-// as at least 512 tiles remain (two GEMM M tiles per point; small volumes keep the finer tiling).
-// DRAM_WINO_NZ / DRAM_WINO_NY = 2 | 4 force one (tests).
+// Tiling (outputs per tile along z, y, x): the cheapest of the instantiated 4x4x4 / 4x4x2 / 4x2x2 / 2x2x2 by
+// points x rows (see pick_tiling), among those that leave two GEMM M tiles per point.
 long long tiles_for(const DramConvDesc* d, int nz, int ny, int nx) {
   const int dd = d->dil;
   auto tiles = [&](int n, int per) { return (long long)(((n + dd - 1) / dd + per - 1) / per); };
@@ -1283,20 +1281,28 @@ void pick_tiling(const DramConvDesc* d, const int pass, int& nz, int& ny, int& n
         if (cand[i][0] == a && cand[i][1] == b && cand[i][2] == c) { nz = a; ny = b; nx = c; return; }
   }
   if (math_mode() == 2) { nz = ny = nx = 2; return; }   // bf16 operands: F(4,3) amplifies their 2^-9 rounding 3-17x
-  const int sz = (d->D + d->dil - 1) / d->dil, sy = (d->H + d->dil - 1) / d->dil, sx = (d->W + d->dil - 1) / d->dil;
   // (pass is kept for per-pass choices; since the 216-value transform runs as two half-tile units --
   // wino_in444_kernel -- F(4,3) on all three axes wins wherever the extents allow it.  Measured, 4x4x4 vs
   // 4x4x2 tiles, fwd / dgrad / wgrad ms: 128->64 @ 2x64x128x128 3.39 / 3.13 / 3.51 vs 3.45 / 3.51 / 3.66;
   // 576->64 @ 2x32x64x64 1.66 / 1.39 / 1.70 vs 1.75 / 1.71 / 1.69; 256->256 dil 2 0.27 / 0.26 / 0.33 vs
   // 0.33 / 0.31 / 0.34.)
   (void)pass;
+  // Cost of a tiling = Winograd points x (GEMM rows actually computed = tiles padded to the 256-row M tile, plus
+  // the real tiles the transforms touch).  A sub-lattice extent that is not a multiple of 4 no longer rules
+  // F(4,3) out on that axis: its edge tiles are simply ragged (zero-filled loads, guarded stores), and e.g. the
+  // reference's default 128x224x288 volume (16x28x36 at stride 8: sub-lattice extents 7 and 9 under dilation 4)
+  // is cheaper on 4x4x4 tiles with padding (6 tiles x 216 points per lattice) than on 4x2x2 (20 x 96).  A tiling
+  // must still leave two GEMM M tiles per point (small volumes keep the finer tiling); ties go to the larger tile.
+  long long best = -1;
+  int bi = 3;
   for (int i = 0; i < 4; ++i) {
-    nz = cand[i][0]; ny = cand[i][1]; nx = cand[i][2];
-    if (nz == 4 && sz % 4 != 0) continue;
-    if (ny == 4 && sy % 4 != 0) continue;
-    if (nx == 4 && sx % 4 != 0) continue;
-    if (i == 3 || tiles_for(d, nz, ny, nx) >= 512) return;
+    const long long T = tiles_for(d, cand[i][0], cand[i][1], cand[i][2]);
+    const long long Tpad = (T + 255) / 256 * 256;
+    if (i < 3 && Tpad < 512) continue;
+    const long long cost = (long long)(cand[i][0] + 2) * (cand[i][1] + 2) * (cand[i][2] + 2) * (Tpad + T);
+    if (best < 0 || cost < best) { best = cost; bi = i; }
   }
+  nz = cand[bi][0]; ny = cand[bi][1]; nx = cand[bi][2];
 }
 
 WinoGeom make_geom(const DramConvDesc* d, const int pass = 0) {   // pass: 0 forward, 1 data gradient, 2 weight gradient

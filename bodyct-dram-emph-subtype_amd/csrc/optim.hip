@@ -71,15 +71,16 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const DramTensorRef* __
 
 // Graph-replayable form: every hyper-parameter AND the step count live in device memory, so a captured
 // hipGraph of the train step stays valid while lr decays (ExponentialLR) and the bias corrections change.
-// hyper = [lr, b1, b2, eps, wd, grad_scale, step]; step is advanced by adam_advance_kernel first.
+// hyper = [lr, b1, b2, eps, wd, grad_scale, step]; step is advanced by adam_advance_kernel first.  The step slot
+// holds the BITS of an int32 (exact for 2^31 steps; a float counter would stall at 2^24).
 __global__ void adam_advance_kernel(float* __restrict__ hyper) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) hyper[6] += 1.f;
+  if (threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<int*>(hyper)[6] += 1;
 }
 __global__ __launch_bounds__(256) void adam_multi_dev_kernel(const DramTensorRef* __restrict__ table,
                                                              const DramChunkRef* __restrict__ chunks,
                                                              const float* __restrict__ hyper) {
   const float b1 = hyper[1], b2 = hyper[2];
-  const double t = (double)hyper[6];
+  const double t = (double)reinterpret_cast<const int*>(hyper)[6];
   // torch: bias_correction = 1 - beta ** step, evaluated in double on the host
   const float bc1 = (float)(1.0 - pow((double)b1, t)), bc2 = (float)(1.0 - pow((double)b2, t));
   adam_chunk(table, chunks, hyper[0], b1, b2, hyper[3], hyper[4], bc1, bc2, hyper[5]);

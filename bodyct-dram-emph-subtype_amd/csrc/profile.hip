@@ -20,7 +20,12 @@ std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;  // events are created once per dram_profile_start and reused
 size_t g_pool_used = 0;
 int g_max = 0, g_dropped = 0;
-int g_open = -1;                 // index of the record begun and not yet ended (launches do not nest)
+// index of the record this THREAD has begun and not yet ended (launches do not nest within a thread, but the
+// forward / data-loader thread and autograd's backward thread may interleave theirs), and the timeline
+// generation it belongs to (a record index must not survive a dram_profile_start)
+thread_local int t_open = -1;
+thread_local unsigned t_gen = 0;
+unsigned g_gen = 0;
 
 const char* const kNames[DRAM_FAM_COUNT] = {
     "conv_wino2d", "wino_in", "wino_gemm_nn", "wino_out", "wino_gemm_tn", "wino_wgrad_out", "weight_pack",
@@ -30,21 +35,22 @@ const int kMfma[DRAM_FAM_COUNT] = {1, 0, 1, 0, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 
 
 void dram_prof_begin(int family, int variant, double mfma_flops, double hbm_bytes, double alg_flops, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_mu);
-  g_open = -1;
+  t_open = -1;
   if ((int)g_recs.size() >= g_max || g_pool_used + 2 > g_pool.size()) { ++g_dropped; return; }
   Rec r{family, variant, mfma_flops, hbm_bytes, alg_flops, g_pool[g_pool_used], g_pool[g_pool_used + 1], false};
   g_pool_used += 2;
   if (hipEventRecord(r.a, s) != hipSuccess) { ++g_dropped; return; }
   g_recs.push_back(r);
-  g_open = (int)g_recs.size() - 1;
+  t_open = (int)g_recs.size() - 1;
+  t_gen = g_gen;
 }
 
 void dram_prof_end(hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (g_open < 0) return;
-  Rec& r = g_recs[g_open];
+  if (t_open < 0 || t_gen != g_gen || t_open >= (int)g_recs.size()) { t_open = -1; return; }
+  Rec& r = g_recs[t_open];
   r.closed = hipEventRecord(r.b, s) == hipSuccess;
-  g_open = -1;
+  t_open = -1;
 }
 
 extern "C" const char* dram_profile_family_name(int family) {
@@ -69,7 +75,7 @@ extern "C" int dram_profile_start(int max_records) {
   g_pool_used = 0;
   g_max = max_records;
   g_dropped = 0;
-  g_open = -1;
+  ++g_gen;
   g_dram_prof_on = true;
   return DRAM_OK;
 }

@@ -209,6 +209,8 @@ class Engine:
             # data parallel: grads_ready() inside _wgrad launches the arena all-reduce from THIS stream context,
             # so the collective is ordered after the weight-gradient kernels that fill the range
             self._wgrad(st, c, dy)
+        # allocated from the side stream's pool, consumed (autograd accumulation, optimizer, zero_grad) on the caller's
+        st.grads[c["w"]].record_stream(main)
 
     def _flush_wgrad(self, st: _State):
         if st.deferred is not None:

@@ -92,7 +92,7 @@ class FusedAdam(_FusedBase):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.capturable = bool(capturable)
-        self._hyper = None            # device float32[7]: lr, b1, b2, eps, wd, grad_scale, step
+        self._hyper = None            # device float32[7]: lr, b1, b2, eps, wd, grad_scale, step (int32 bits)
         self._hyper_host = None
         self._replayed = 0            # graph replays whose step the host-side state has not absorbed yet
 
@@ -156,7 +156,8 @@ class FusedAdam(_FusedBase):
             if capturing:
                 raise RuntimeError("run at least one eager step before capturing")
             self._hyper_host = self._host_hyper(group)
-            self._hyper = torch.tensor(self._hyper_host + [float(steps.pop())], dtype=torch.float32, device=plist[0].device)
+            self._hyper = torch.tensor(self._hyper_host + [0.0], dtype=torch.float32, device=plist[0].device)
+            self._hyper[6:].view(torch.int32).fill_(int(steps.pop()))      # the kernel keeps the step count as int32 bits
         elif not capturing:
             self.sync_hyper()
         ptrs = [(p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),

@@ -118,6 +118,8 @@ def relu(x: Tensor, pins: Optional[Dict[str, Tensor]] = None, key: str = "") -> 
         return F.relu(x)
     if pins.get("__record__"):          # recording run: plain ReLU, decisions written into `pins`
         pins[key] = x.detach() > 0
+        if pins["__record__"] == "pre":  # ... and the values the decisions were taken on (decision audits)
+            pins["pre:" + key] = x.detach()
         return F.relu(x)
     return x * pins[key].to(x.dtype)
 
