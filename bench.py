@@ -49,7 +49,9 @@ CONFIGS = {
     5: ("resnet50segreg", 1, (128, 224, 288), 10313.4 * 63 / 64, (3.458 + 3.838) * 1e9 * 63 / 64, 47.86e6),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: ~2.5 PF dense bf16 (v_mfma_f32_32x32x16_bf16, 32 cycles per SIMD)
 PEAK_HBM_GBS = 8000.0           # same guide: HBM3E ~8 TB/s
+BF16_CONFIGS = (2, 4)           # BASELINE configs[2] and [4] are specified in bf16
 
 FAMILY_DESC = {
     "conv_wino2d": "conv_wino2d_kernel<NJ,..> (fused in-plane Winograd F(2x2,3x3) x direct-z conv, fwd + dgrad, fp32 MFMA 32x32x2)",
@@ -68,6 +70,8 @@ FAMILY_DESC = {
     "head_loss": "1x1x1 heads + pooled scores, dRAM loss kernels",
     "optim": "adam_multi / sgd_multi (fused multi-tensor optimizer)",
     "prep": "input transforms",
+    "conv_bf16": "conv3_bf16_kernel<NB,EPI> (bf16-storage direct implicit-GEMM 3x3x3 conv, fwd + dgrad, bf16 MFMA 32x32x16)",
+    "wgrad_bf16": "wgrad3_bf16_kernel + reduce (bf16-storage weight gradient, transposed LDS operands, bf16 MFMA 32x32x16)",
 }
 # family -> key in profiles/r*_pmc_hbm_traffic.json
 TRAFFIC_KEY = {"conv_wino2d": "conv_wino2d", "wino_in": "wino_in", "wino_gemm_nn": "wino_gemm_nn",
@@ -189,7 +193,7 @@ def family_table(fams, steps, step_s):
                "avg_launch_ms": f["ms"] / f["launches"], "step_time_share": sec / (step_s * steps)}
         if f["bound"] == "mfma":
             row["achieved"] = f["mfma_flops"] / sec / 1e12
-            row["peak"], row["unit"] = PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
+            row["peak"], row["unit"] = (PEAK_BF16_MFMA_TFLOPS if name.endswith("bf16") else PEAK_FP32_MFMA_TFLOPS), "TFLOP/s"
             row["algorithmic_speedup"] = f["alg_flops"] / f["mfma_flops"] if f["mfma_flops"] > 0 else 1.0
             row["hbm_gbs_algorithmic"] = f["hbm_bytes"] / sec / 1e9
         else:
@@ -235,6 +239,10 @@ def main():
     ap.add_argument("--config", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default=None,
+                    help="storage type of the activations: f32 = the reference's default arithmetic; bf16 = its "
+                         "`--precision bf16` (bf16 activations, fp32 accumulation / statistics / parameters).  Default: "
+                         "what BASELINE.json names for the config (bf16 for configs 2 and 4, f32 otherwise)")
     ap.add_argument("--detail", type=str, default="", help="write a per-convolution-call timing table to this file")
     ap.add_argument("--timeline", choices=("after", "in", "off"), default="after",
                     help="kernel timeline (roofline table): 'after' = a second pass of the same K steps right after "
@@ -268,6 +276,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     factory, B, dims, gflop_per_vol, act_elems, nparams = CONFIGS[args.config]
+    if args.dtype is None:
+        args.dtype = "bf16" if args.config in BF16_CONFIGS else "f32"
 
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -295,6 +305,8 @@ def main():
     torch.manual_seed(0)
     kw = dict(n_classes=[6, 3]) if factory.endswith("cls") else {}
     module = getattr(med3d, factory)(**kw).to(device).train()
+    if args.dtype == "bf16":
+        module.storage_dtype = torch.bfloat16
     dctx = None
     if use_dist:
         from bodyct_dram_emph_subtype_amd import distributed as ddist
@@ -422,10 +434,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"{'BASELINE configs[%d]' % args.config if args.config <= 4 else 'reference default job (train.py:21,30,42)'}: {factory} train step (fwd+loss+bwd+Adam), "
-                                   f"batch {B}/GPU, 1x{dims[0]}x{dims[1]}x{dims[2]}, fp32, inputs resident in HBM",
+                                   f"batch {B}/GPU, 1x{dims[0]}x{dims[1]}x{dims[2]}, "
+                                   f"{'fp32' if args.dtype == 'f32' else 'bf16 storage / fp32 accumulation, statistics and parameters'}, "
+                                   f"inputs resident in HBM",
                        "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(args.graph),
                        "train_gflop_per_volume": gflop_per_vol},
             "loss": float(loss.detach()),
@@ -455,11 +469,13 @@ def main():
                 "ms_per_step_with_timeline": 1e3 * tl_step_s,
                 "kernel_ms_per_step": kernel_ms, "timeline_coverage_of_step": kernel_ms / (1e3 * tl_step_s),
                 # step-level fractions are priced against the UNinstrumented step time
-                "executed_mfma_tflops": mfma / dt / 1e12, "executed_mfma_frac": mfma / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                "executed_mfma_tflops": mfma / dt / 1e12,
+                "executed_mfma_frac": sum(f["mfma_flops"] / (PEAK_BF16_MFMA_TFLOPS if n.endswith("bf16") else PEAK_FP32_MFMA_TFLOPS)
+                                          for n, f in fams.items()) / dt / 1e12,
                 "algorithmic_tflops": gflop_per_vol * vols / world / dt / 1e3,
                 "hbm_gbs_algorithmic": hbm / dt / 1e9, "hbm_frac_algorithmic": hbm / dt / 1e9 / PEAK_HBM_GBS,
                 # SURVEY.md §8d whole-step figure: fused-minimum activation traffic + 28 B/param
-                "hbm_gbs_fused_minimum": (act_elems * 4 * B + 28 * nparams) / step_s / 1e9,
+                "hbm_gbs_fused_minimum": (act_elems * (4 if args.dtype == "f32" else 2) * B + 28 * nparams) / step_s / 1e9,
                 "hbm_gbs_measured": (traffic["_step_total_bytes"] / step_s / 1e9) if traffic and "_step_total_bytes" in traffic else None,
                 "timeline_records_dropped": timeline.dropped,
             }

@@ -107,6 +107,28 @@ SIGNATURES = {
     "dram_head_fwd": (I, [P, P, P, P, I, I, I, P, P, I, I, I, I, I, I, P]),
     "dram_head_bwd_nparts": (I, [LL]),
     "dram_head_bwd": (I, [P, P, P, P, P, P, I, I, I, P, P, I, I, I, I, I, I, P]),
+    # bf16 storage path (same argument lists as the fp32 namesakes; activation tensors are bf16)
+    "dram_cast_f32_to_bf16": (I, [P, P, LL, P]),
+    "dram_cast_bf16_to_f32": (I, [P, P, LL, P]),
+    "dram_conv_bf16_supported": (I, [DP]),
+    "dram_conv_bf16_num_stat_rows": (I, [DP]),
+    "dram_pack_conv_weight_bf16": (I, [P, P, P, I, I, I, P]),
+    "dram_conv3d_fwd_bf16": (I, [P, P, P, P, P, DP, P]),
+    "dram_conv3d_bwd_data_bf16": (I, [P, P, P, P, P, DP, P]),
+    "dram_conv3d_bwd_weight_bf16_workspace": (SZ, [DP]),
+    "dram_conv3d_bwd_weight_bf16": (I, [P, P, P, DP, P, SZ, P]),
+    "dram_stem_fwd_bf16": (I, [P, P, P, P, I, I, I, I, P]),
+    "dram_stem_bwd_weight_bf16": (I, [P, P, P, I, I, I, I, P, SZ, P]),
+    "dram_bn_apply_bf16": (I, [P, P, P, P, I, I, I, I, I, P, I, I, I, I, I, I, P]),
+    "dram_bn_bwd_reduce_bf16": (I, [P, P, P, P, P, P, P, P, LL, I, I, P]),
+    "dram_bn_bwd_apply_bf16": (I, [P, P, P, P, P, P, P, P, P, D, P, P, P, LL, I, I, P]),
+    "dram_colsum_bf16": (I, [P, P, LL, I, P]),
+    "dram_maxpool_fwd_bf16": (I, [P, P, P, I, I, I, I, I, P]),
+    "dram_maxpool_bwd_bf16": (I, [P, P, P, I, P, I, I, I, I, I, P]),
+    "dram_upcat_fwd_bf16": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "dram_upcat_bwd_bf16": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "dram_head_fwd_bf16": (I, [P, P, P, P, I, I, I, P, P, I, I, I, I, I, I, P]),
+    "dram_head_bwd_bf16": (I, [P, P, P, P, P, P, I, I, I, P, P, I, I, I, I, I, I, P]),
     "dram_segloss_nblk": (I, [LL]),
     "dram_segloss_fwd": (I, [P, P, P, P, P, I, I, I, P, I, I, I, I, F, P]),
     "dram_segloss_bwd": (I, [P, P, P, P, P, I, I, I, P, P, P, I, I, I, I, F, P]),

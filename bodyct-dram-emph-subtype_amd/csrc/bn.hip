@@ -64,40 +64,41 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
 }
 
 // z = act(y*scale + shift + residual)
-template <int RES>  // 0 none, 1 same-shape identity (shortcut A: bn_apply_shortcut_a_kernel)
-__global__ void bn_apply_kernel(const float4* __restrict__ y, const float* __restrict__ scale,
-                                const float* __restrict__ shift, const float* __restrict__ res, int Cr, int rs,
-                                float4* __restrict__ z, int D, int H, int W, int C, long total4, int relu) {
+template <int RES, typename T>  // 0 none, 1 same-shape identity (shortcut A: bn_apply_shortcut_a_kernel)
+__global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const T* __restrict__ res, int Cr, int rs,
+                                T* __restrict__ z, int D, int H, int W, int C, long total4, int relu) {
   const int Q = C >> 2;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i % Q);
     const float4 sc = *reinterpret_cast<const float4*>(scale + 4 * q);
     const float4 sh = *reinterpret_cast<const float4*>(shift + 4 * q);
-    const float4 v = y[i];
+    const float4 v = ld4<T>(y, 4 * i);
     float4 o;
     // explicit fma: the backward pass re-derives the ReLU mask from y with the same expression (bitwise)
     o.x = __builtin_fmaf(v.x, sc.x, sh.x); o.y = __builtin_fmaf(v.y, sc.y, sh.y);
     o.z = __builtin_fmaf(v.z, sc.z, sh.z); o.w = __builtin_fmaf(v.w, sc.w, sh.w);
     if (RES == 1) {
-      const float4 rr = reinterpret_cast<const float4*>(res)[i];
+      const float4 rr = ld4<T>(res, 4 * i);
       o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
     }
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    z[i] = o;
+    st4<T>(z, 4 * i, o);
   }
 }
 
 // shortcut type A needs the residual tensor's own dims -> dedicated kernel
-__global__ void bn_apply_shortcut_a_kernel(const float4* __restrict__ y, const float* __restrict__ scale,
-                                           const float* __restrict__ shift, const float* __restrict__ res,
-                                           int Dr, int Hr, int Wr, int Cr, int rs, float4* __restrict__ z, int D,
+template <typename T>
+__global__ void bn_apply_shortcut_a_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, const T* __restrict__ res,
+                                           int Dr, int Hr, int Wr, int Cr, int rs, T* __restrict__ z, int D,
                                            int H, int W, int C, long total4, int relu) {
   const int Q = C >> 2;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i % Q);
     const float4 sc = *reinterpret_cast<const float4*>(scale + 4 * q);
     const float4 sh = *reinterpret_cast<const float4*>(shift + 4 * q);
-    const float4 v = y[i];
+    const float4 v = ld4<T>(y, 4 * i);
     float4 o;
     o.x = v.x * sc.x + sh.x; o.y = v.y * sc.y + sh.y; o.z = v.z * sc.z + sh.z; o.w = v.w * sc.w + sh.w;
     if (4 * q < Cr) {
@@ -107,20 +108,20 @@ __global__ void bn_apply_shortcut_a_kernel(const float4* __restrict__ y, const f
       const int zz = (int)(vox % D);
       const long b = vox / D;
       const long ro = ((((b * Dr + (long)zz * rs) * Hr + (long)yy * rs) * Wr + (long)xx * rs) * Cr) + 4 * q;
-      const float4 rr = *reinterpret_cast<const float4*>(res + ro);
+      const float4 rr = ld4<T>(res, ro);
       o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
     }
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    z[i] = o;
+    st4<T>(z, 4 * i, o);
   }
 }
 
 // Column reductions over rows of an [rows][C] tensor.
 // MODE 0: partial[p][0][c] = sum a          (R = 1)
 // MODE 1: BN backward: g = dz*(z>0); partial[p][0][c] = sum g, partial[p][1][c] = sum g*xhat (R = 2)
-template <int MODE>
-__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ a, const float* __restrict__ zz,
-                                                        const float* __restrict__ yy, const float* __restrict__ mean,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ a, const T* __restrict__ zz,
+                                                        const T* __restrict__ yy, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, float* __restrict__ partial,
                                                         long rows, int C, int rpb, int relu,
                                                         const float* __restrict__ scale = nullptr,
@@ -149,14 +150,14 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
       }
       for (long r = r0 + grp; r < r1; r += rg) {
         const long o = r * C + 4 * q;
-        float4 g = *reinterpret_cast<const float4*>(a + o);
+        float4 g = ld4<T>(a, o);
         if (MODE == 1) {
-          const float4 yv = *reinterpret_cast<const float4*>(yy + o);
+          const float4 yv = ld4<T>(yy, o);
           if (relu) {
             // mask of the forward ReLU: from the saved output z, or (no residual) re-derived from y with the
             // forward's own expression -- one tensor read less
             float4 zv;
-            if (zz) zv = *reinterpret_cast<const float4*>(zz + o);
+            if (zz) zv = ld4<T>(zz, o);
             else zv = make_float4(__builtin_fmaf(yv.x, sc.x, sh.x), __builtin_fmaf(yv.y, sc.y, sh.y),
                                   __builtin_fmaf(yv.z, sc.z, sh.z), __builtin_fmaf(yv.w, sc.w, sh.w));
             g.x = zv.x > 0.f ? g.x : 0.f; g.y = zv.y > 0.f ? g.y : 0.f;
@@ -186,11 +187,12 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   }
 }
 
-__global__ void bn_bwd_apply_kernel(const float4* __restrict__ dz, const float4* __restrict__ z,
-                                    const float4* __restrict__ y, const float* __restrict__ mean,
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ z,
+                                    const T* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const double* __restrict__ sums, double inv_count_host,
-                                    const double* __restrict__ count_dev, float4* __restrict__ dy, int C,
+                                    const double* __restrict__ count_dev, T* __restrict__ dy, int C,
                                     long total4, int relu, const float* __restrict__ scale,
                                     const float* __restrict__ shift, float* __restrict__ colpart) {
   const int Q = C >> 2;
@@ -198,11 +200,11 @@ __global__ void bn_bwd_apply_kernel(const float4* __restrict__ dz, const float4*
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // colpart: this thread's channel quad is fixed (256 % Q == 0)
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const int c = 4 * (int)(i % Q);
-    float4 g = dz[i];
-    const float4 yv = y[i];
+    float4 g = ld4<T>(dz, 4 * i);
+    const float4 yv = ld4<T>(y, 4 * i);
     if (relu) {
       float4 zv;
-      if (z) zv = z[i];
+      if (z) zv = ld4<T>(z, 4 * i);
       else {   // no residual: the forward mask re-derived from y (same fma as bn_apply_kernel)
         const float4 sc = *reinterpret_cast<const float4*>(scale + c);
         const float4 sh = *reinterpret_cast<const float4*>(shift + c);
@@ -225,7 +227,7 @@ __global__ void bn_bwd_apply_kernel(const float4* __restrict__ dz, const float4*
   }
     BN_BWD_1(x, 0) BN_BWD_1(y, 1) BN_BWD_1(z, 2) BN_BWD_1(w, 3)
 #undef BN_BWD_1
-    dy[i] = o;
+    st4<T>(dy, 4 * i, o);
     cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
   }
   if (colpart) {   // per-block column sums of dy: the gradient of the bias of the convolution in front
@@ -315,31 +317,43 @@ extern "C" int dram_bn_finalize(const double* sums, double count, const double* 
   return DRAM_OK;
 }
 
-extern "C" int dram_bn_apply(const float* y, const float* scale, const float* shift, const float* residual,
-                             int Dr, int Hr, int Wr, int Cr, int rs, float* z, int B, int D, int H, int W, int C,
-                             int relu, dram_stream_t stream) {
+template <typename T>
+static int bn_apply_impl(const T* y, const float* scale, const float* shift, const T* residual, int Dr, int Hr, int Wr,
+                         int Cr, int rs, T* z, int B, int D, int H, int W, int C, int relu, dram_stream_t stream) {
   if (!y || !scale || !shift || !z || B < 1 || D < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
   const long total4 = (long)B * D * H * W * (C >> 2);
   hipStream_t s = (hipStream_t)stream;
   const int grid = ew_grid(total4);
   // y read, z written, residual read (identity: full size; shortcut A: 1/rs^3 of Cr/C of it)
   const double res_frac = !residual ? 0.0 : ((double)Cr / C) / ((double)rs * rs * rs);
-  DramProf prof(DRAM_FAM_BN, 2, 0.0, 16.0 * (double)total4 * (2.0 + res_frac), s);
+  DramProf prof(DRAM_FAM_BN, 2, 0.0, 4.0 * sizeof(T) * (double)total4 * (2.0 + res_frac), s);
   if (!residual) {
-    hipLaunchKernelGGL((bn_apply_kernel<0>), dim3(grid), dim3(256), 0, s, (const float4*)y, scale, shift, nullptr, 0,
-                       1, (float4*)z, D, H, W, C, total4, relu);
+    hipLaunchKernelGGL((bn_apply_kernel<0, T>), dim3(grid), dim3(256), 0, s, y, scale, shift, (const T*)nullptr, 0,
+                       1, z, D, H, W, C, total4, relu);
   } else if (rs == 1 && Cr == C && Dr == D && Hr == H && Wr == W) {
-    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(grid), dim3(256), 0, s, (const float4*)y, scale, shift, residual,
-                       Cr, 1, (float4*)z, D, H, W, C, total4, relu);
+    hipLaunchKernelGGL((bn_apply_kernel<1, T>), dim3(grid), dim3(256), 0, s, y, scale, shift, residual,
+                       Cr, 1, z, D, H, W, C, total4, relu);
   } else {
     // shortcut type A (med3d.py:103-112): strided subsample, channels >= Cr read zero
     if ((Cr & 3) || Cr < 4 || Cr > C || rs < 1) return DRAM_ERR_BAD_ARG;
     if ((D - 1) * rs >= Dr || (H - 1) * rs >= Hr || (W - 1) * rs >= Wr) return DRAM_ERR_BAD_ARG;
-    hipLaunchKernelGGL(bn_apply_shortcut_a_kernel, dim3(grid), dim3(256), 0, s, (const float4*)y, scale, shift,
-                       residual, Dr, Hr, Wr, Cr, rs, (float4*)z, D, H, W, C, total4, relu);
+    hipLaunchKernelGGL((bn_apply_shortcut_a_kernel<T>), dim3(grid), dim3(256), 0, s, y, scale, shift,
+                       residual, Dr, Hr, Wr, Cr, rs, z, D, H, W, C, total4, relu);
   }
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
+}
+
+extern "C" int dram_bn_apply(const float* y, const float* scale, const float* shift, const float* residual,
+                             int Dr, int Hr, int Wr, int Cr, int rs, float* z, int B, int D, int H, int W, int C,
+                             int relu, dram_stream_t stream) {
+  return bn_apply_impl<float>(y, scale, shift, residual, Dr, Hr, Wr, Cr, rs, z, B, D, H, W, C, relu, stream);
+}
+extern "C" int dram_bn_apply_bf16(const void* y, const float* scale, const float* shift, const void* residual,
+                                  int Dr, int Hr, int Wr, int Cr, int rs, void* z, int B, int D, int H, int W, int C,
+                                  int relu, dram_stream_t stream) {
+  return bn_apply_impl<bf16_t>((const bf16_t*)y, scale, shift, (const bf16_t*)residual, Dr, Hr, Wr, Cr, rs, (bf16_t*)z,
+                               B, D, H, W, C, relu, stream);
 }
 
 extern "C" int dram_colsum_nparts(long long rows, int C) {
@@ -348,29 +362,48 @@ extern "C" int dram_colsum_nparts(long long rows, int C) {
   return (int)((rows + rpb - 1) / rpb);
 }
 
-extern "C" int dram_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean,
-                                  const float* invstd, const float* scale, const float* shift, float* partial,
-                                  long long rows, int C, int relu, dram_stream_t stream) {
+template <typename T>
+static int bn_bwd_reduce_impl(const T* dz, const T* z, const T* y, const float* mean, const float* invstd,
+                              const float* scale, const float* shift, float* partial, long long rows, int C, int relu,
+                              dram_stream_t stream) {
   if (!dz || !y || !mean || !invstd || !partial || rows < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
   if (relu && !z && !(scale && shift)) return DRAM_ERR_BAD_ARG;
   const int rpb = rows_per_block(rows);
   const int nparts = (int)((rows + rpb - 1) / rpb);
-  DramProf prof(DRAM_FAM_BN, 3, 0.0, 4.0 * (double)rows * C * (relu && z ? 3.0 : 2.0), (hipStream_t)stream);
-  hipLaunchKernelGGL((colreduce_kernel<1>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, z, y, mean, invstd,
+  DramProf prof(DRAM_FAM_BN, 3, 0.0, (double)sizeof(T) * (double)rows * C * (relu && z ? 3.0 : 2.0), (hipStream_t)stream);
+  hipLaunchKernelGGL((colreduce_kernel<1, T>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, z, y, mean, invstd,
                      partial, (long)rows, C, rpb, relu, scale, shift);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
+extern "C" int dram_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean,
+                                  const float* invstd, const float* scale, const float* shift, float* partial,
+                                  long long rows, int C, int relu, dram_stream_t stream) {
+  return bn_bwd_reduce_impl<float>(dz, z, y, mean, invstd, scale, shift, partial, rows, C, relu, stream);
+}
+extern "C" int dram_bn_bwd_reduce_bf16(const void* dz, const void* z, const void* y, const float* mean,
+                                       const float* invstd, const float* scale, const float* shift, float* partial,
+                                       long long rows, int C, int relu, dram_stream_t stream) {
+  return bn_bwd_reduce_impl<bf16_t>((const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, invstd, scale, shift,
+                                    partial, rows, C, relu, stream);
+}
 
-extern "C" int dram_colsum(const float* a, float* partial, long long rows, int C, dram_stream_t stream) {
+template <typename T>
+static int colsum_impl(const T* a, float* partial, long long rows, int C, dram_stream_t stream) {
   if (!a || !partial || rows < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
   const int rpb = rows_per_block(rows);
   const int nparts = (int)((rows + rpb - 1) / rpb);
-  DramProf prof(DRAM_FAM_BN, 4, 0.0, 4.0 * (double)rows * C, (hipStream_t)stream);
-  hipLaunchKernelGGL((colreduce_kernel<0>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, a, nullptr, nullptr,
-                     nullptr, nullptr, partial, (long)rows, C, rpb, 0);
+  DramProf prof(DRAM_FAM_BN, 4, 0.0, (double)sizeof(T) * (double)rows * C, (hipStream_t)stream);
+  hipLaunchKernelGGL((colreduce_kernel<0, T>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, a, (const T*)nullptr,
+                     (const T*)nullptr, nullptr, nullptr, partial, (long)rows, C, rpb, 0);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
+}
+extern "C" int dram_colsum(const float* a, float* partial, long long rows, int C, dram_stream_t stream) {
+  return colsum_impl<float>(a, partial, rows, C, stream);
+}
+extern "C" int dram_colsum_bf16(const void* a, float* partial, long long rows, int C, dram_stream_t stream) {
+  return colsum_impl<bf16_t>((const bf16_t*)a, partial, rows, C, stream);
 }
 
 // rows of colsum_partial written by dram_bn_bwd_apply, or DRAM_ERR_UNSUPPORTED when a thread's channel quad is
@@ -381,22 +414,37 @@ extern "C" int dram_bn_bwd_apply_nparts(long long rows, int C) {
   return ew_grid((long)rows * (C >> 2));
 }
 
-extern "C" int dram_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* mean,
-                                 const float* invstd, const float* gamma, const float* scale, const float* shift,
-                                 const double* sums, double count, const double* count_dev, float* dy,
-                                 float* colsum_partial, long long rows, int C, int relu, dram_stream_t stream) {
+template <typename T>
+static int bn_bwd_apply_impl(const T* dz, const T* z, const T* y, const float* mean, const float* invstd,
+                             const float* gamma, const float* scale, const float* shift, const double* sums,
+                             double count, const double* count_dev, T* dy, float* colsum_partial, long long rows, int C,
+                             int relu, dram_stream_t stream) {
   if (!dz || !y || !mean || !invstd || !gamma || !sums || !dy || rows < 1 || C < 4 || (C & 3) ||
       (!count_dev && count <= 0.0))
     return DRAM_ERR_BAD_ARG;
   if (relu && !z && !(scale && shift)) return DRAM_ERR_BAD_ARG;
   if (colsum_partial && dram_bn_bwd_apply_nparts(rows, C) < 1) return DRAM_ERR_UNSUPPORTED;
   const long total4 = (long)rows * (C >> 2);
-  DramProf prof(DRAM_FAM_BN, 5, 0.0, 16.0 * (double)total4 * (relu && z ? 4.0 : 3.0), (hipStream_t)stream);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream,
-                     (const float4*)dz, (const float4*)z, (const float4*)y, mean, invstd, gamma, sums,
-                     count_dev ? 0.0 : 1.0 / count, count_dev, (float4*)dy, C, total4, relu, scale, shift, colsum_partial);
+  DramProf prof(DRAM_FAM_BN, 5, 0.0, 4.0 * sizeof(T) * (double)total4 * (relu && z ? 4.0 : 3.0), (hipStream_t)stream);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dz, z, y, mean,
+                     invstd, gamma, sums, count_dev ? 0.0 : 1.0 / count, count_dev, dy, C, total4, relu, scale, shift,
+                     colsum_partial);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
+}
+extern "C" int dram_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* mean,
+                                 const float* invstd, const float* gamma, const float* scale, const float* shift,
+                                 const double* sums, double count, const double* count_dev, float* dy,
+                                 float* colsum_partial, long long rows, int C, int relu, dram_stream_t stream) {
+  return bn_bwd_apply_impl<float>(dz, z, y, mean, invstd, gamma, scale, shift, sums, count, count_dev, dy,
+                                  colsum_partial, rows, C, relu, stream);
+}
+extern "C" int dram_bn_bwd_apply_bf16(const void* dz, const void* z, const void* y, const float* mean,
+                                      const float* invstd, const float* gamma, const float* scale, const float* shift,
+                                      const double* sums, double count, const double* count_dev, void* dy,
+                                      float* colsum_partial, long long rows, int C, int relu, dram_stream_t stream) {
+  return bn_bwd_apply_impl<bf16_t>((const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, invstd, gamma, scale,
+                                   shift, sums, count, count_dev, (bf16_t*)dy, colsum_partial, rows, C, relu, stream);
 }
 
 extern "C" int dram_add(const float* a, const float* b, float* out, long long n, dram_stream_t stream) {

@@ -32,6 +32,46 @@ struct DramProf {
   DramProf(const DramProf&) = delete;
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// Storage types of activation-sized tensors: float (the default path: the reference's arithmetic) or bf16
+// (`--precision bf16` of the reference's Lightning trainer, train.py:46; BASELINE configs[2], [4]).  The
+// element-wise kernels are templates over the storage type T and do all arithmetic in fp32: ld4 / st4 move
+// four channels of one voxel (16 B as float4, 8 B as four bf16), offsets in ELEMENTS, multiples of 4.
+typedef unsigned short bf16_t;   // raw bits; conversions below (round to nearest even, NaN stays NaN)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  bf16x2_t v;                                  // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack2_bf16(f, 0.f) & 0xffffu); }
+
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p, long off);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p, long off) {
+  return *reinterpret_cast<const float4*>(p + off);
+}
+template <> __device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t* p, long off) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p + off);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, long off, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, long off, float4 v) {
+  *reinterpret_cast<float4*>(p + off) = v;
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, long off, float4 v) {
+  *reinterpret_cast<uint2*>(p + off) = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
+}
+template <typename T> __device__ __forceinline__ float ld1(const T* p, long off);
+template <> __device__ __forceinline__ float ld1<float>(const float* p, long off) { return p[off]; }
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p, long off) { return bf16_to_f32(p[off]); }
+template <typename T> __device__ __forceinline__ void st1(T* p, long off, float v);
+template <> __device__ __forceinline__ void st1<float>(float* p, long off, float v) { p[off] = v; }
+template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, long off, float v) { p[off] = f32_to_bf16(v); }
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // XCD-aware bijective remap of the linear workgroup id (8 XCDs, round-robin

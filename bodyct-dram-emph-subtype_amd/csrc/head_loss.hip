@@ -24,8 +24,8 @@ __device__ __forceinline__ long near_index(const NearGeom& n, long b, int z, int
 }
 
 // ----------------------------------------------------------------------------- head fwd
-template <int NOT>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int NOT, typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, const float* __restrict__ lungs,
                                                        NearGeom ng, float* __restrict__ dense,
                                                        float* __restrict__ partial, int D, int H, int W, int NO,
@@ -42,10 +42,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 #pragma unroll
   for (int c = 0; c <= NOT; ++c) acc[c] = 0.f;
   for (long v = blockIdx.x * 256L + tid; v < vps; v += (long)gridDim.x * 256L) {
-    const float4* xr = reinterpret_cast<const float4*>(x + (b * vps + v) * 32);
     float4 xv[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) xv[k] = xr[k];
+    for (int k = 0; k < 8; ++k) xv[k] = ld4<T>(x, (b * vps + v) * 32 + 4 * k);
     float L = 1.f;
     if (lungs) {
       long r = v;
@@ -83,11 +82,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 }
 
 // ----------------------------------------------------------------------------- head bwd
-template <int NOT>
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int NOT, typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ dense, const float* __restrict__ gdense,
                                                        const float* __restrict__ gpool, const float* __restrict__ lungs,
-                                                       NearGeom ng, float* __restrict__ dx, float* __restrict__ wpartial,
+                                                       NearGeom ng, T* __restrict__ dx, float* __restrict__ wpartial,
                                                        int D, int H, int W, int NO, int sigmoid, int nblk) {
   constexpr int SLOTS = (NOT * 33 + 255) / 256;
   __shared__ float wl[NOT * 32];
@@ -115,9 +114,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < 8; ++k) xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok) {
-      const float4* xr = reinterpret_cast<const float4*>(x + (b * vps + v) * 32);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) xv[k] = xr[k];
+      for (int k = 0; k < 8; ++k) xv[k] = ld4<T>(x, (b * vps + v) * 32 + 4 * k);
       float L = 1.f;
       if (lungs) {
         long r = v;
@@ -153,9 +151,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
           }
         }
       }
-      float4* dr = reinterpret_cast<float4*>(dx + (b * vps + v) * 32);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) dr[k] = o[k];
+      for (int k = 0; k < 8; ++k) st4<T>(dx, (b * vps + v) * 32 + 4 * k, o[k]);
     }
     __syncthreads();  // previous tile's LDS consumers are done
 #pragma unroll
@@ -279,9 +276,10 @@ inline int head_blocks(long long vps) {
 extern "C" int dram_head_nblk(long long voxels_per_sample) { return head_blocks(voxels_per_sample); }
 extern "C" int dram_head_bwd_nparts(long long voxels_per_sample) { return head_blocks(voxels_per_sample); }
 
-extern "C" int dram_head_fwd(const float* x, const float* w, const float* bias, const float* lungs, int Dl, int Hl,
-                             int Wl, float* dense, float* partial, int B, int D, int H, int W, int NO, int sigmoid,
-                             dram_stream_t stream) {
+template <typename T>
+static int head_fwd_impl(const T* x, const float* w, const float* bias, const float* lungs, int Dl, int Hl, int Wl,
+                         float* dense, float* partial, int B, int D, int H, int W, int NO, int sigmoid,
+                         dram_stream_t stream) {
   if (!x || !w || !bias || !dense || !partial || B < 1 || D < 1 || H < 1 || W < 1 || NO < 1 || NO > 16)
     return DRAM_ERR_BAD_ARG;
   if (lungs && (Dl < 1 || Hl < 1 || Wl < 1)) return DRAM_ERR_BAD_ARG;
@@ -290,20 +288,32 @@ extern "C" int dram_head_fwd(const float* x, const float* w, const float* bias, 
   const NearGeom ng = make_near(lungs ? Dl : 1, lungs ? Hl : 1, lungs ? Wl : 1, D, H, W);
   dim3 grid(nblk, B), block(256);
   hipStream_t s = (hipStream_t)stream;
-  DramProf prof(DRAM_FAM_HEAD_LOSS, 0, 0.0, 4.0 * (double)B * vps * (32.0 + NO + (lungs ? 0.125 : 0.0)), s);
+  DramProf prof(DRAM_FAM_HEAD_LOSS, 0, 0.0, (double)B * vps * (32.0 * sizeof(T) + 4.0 * (NO + (lungs ? 0.125 : 0.0))), s);
   if (NO <= 2)
-    hipLaunchKernelGGL((head_fwd_kernel<2>), grid, block, 0, s, x, w, bias, lungs, ng, dense, partial, D, H, W, NO, sigmoid, nblk);
+    hipLaunchKernelGGL((head_fwd_kernel<2, T>), grid, block, 0, s, x, w, bias, lungs, ng, dense, partial, D, H, W, NO, sigmoid, nblk);
   else if (NO <= 9)
-    hipLaunchKernelGGL((head_fwd_kernel<9>), grid, block, 0, s, x, w, bias, lungs, ng, dense, partial, D, H, W, NO, sigmoid, nblk);
+    hipLaunchKernelGGL((head_fwd_kernel<9, T>), grid, block, 0, s, x, w, bias, lungs, ng, dense, partial, D, H, W, NO, sigmoid, nblk);
   else
-    hipLaunchKernelGGL((head_fwd_kernel<16>), grid, block, 0, s, x, w, bias, lungs, ng, dense, partial, D, H, W, NO, sigmoid, nblk);
+    hipLaunchKernelGGL((head_fwd_kernel<16, T>), grid, block, 0, s, x, w, bias, lungs, ng, dense, partial, D, H, W, NO, sigmoid, nblk);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
+extern "C" int dram_head_fwd(const float* x, const float* w, const float* bias, const float* lungs, int Dl, int Hl,
+                             int Wl, float* dense, float* partial, int B, int D, int H, int W, int NO, int sigmoid,
+                             dram_stream_t stream) {
+  return head_fwd_impl<float>(x, w, bias, lungs, Dl, Hl, Wl, dense, partial, B, D, H, W, NO, sigmoid, stream);
+}
+extern "C" int dram_head_fwd_bf16(const void* x, const float* w, const float* bias, const float* lungs, int Dl, int Hl,
+                                  int Wl, float* dense, float* partial, int B, int D, int H, int W, int NO, int sigmoid,
+                                  dram_stream_t stream) {
+  return head_fwd_impl<bf16_t>((const bf16_t*)x, w, bias, lungs, Dl, Hl, Wl, dense, partial, B, D, H, W, NO, sigmoid,
+                               stream);
+}
 
-extern "C" int dram_head_bwd(const float* x, const float* w, const float* dense, const float* gdense,
-                             const float* gpool, const float* lungs, int Dl, int Hl, int Wl, float* dx,
-                             float* wpartial, int B, int D, int H, int W, int NO, int sigmoid, dram_stream_t stream) {
+template <typename T>
+static int head_bwd_impl(const T* x, const float* w, const float* dense, const float* gdense, const float* gpool,
+                         const float* lungs, int Dl, int Hl, int Wl, T* dx, float* wpartial, int B, int D, int H, int W,
+                         int NO, int sigmoid, dram_stream_t stream) {
   if (!x || !w || !gpool || !dx || !wpartial || B < 1 || D < 1 || H < 1 || W < 1 || NO < 1 || NO > 16)
     return DRAM_ERR_BAD_ARG;
   if (sigmoid && !dense) return DRAM_ERR_BAD_ARG;
@@ -314,15 +324,26 @@ extern "C" int dram_head_bwd(const float* x, const float* w, const float* dense,
   dim3 grid(nblk, B), block(256);
   hipStream_t s = (hipStream_t)stream;
   DramProf prof(DRAM_FAM_HEAD_LOSS, 1, 0.0,
-                4.0 * (double)B * vps * (64.0 + (dense ? NO : 0) + (gdense ? NO : 0) + (lungs ? 0.125 : 0.0)), s);
+                (double)B * vps * (64.0 * sizeof(T) + 4.0 * ((dense ? NO : 0) + (gdense ? NO : 0) + (lungs ? 0.125 : 0.0))), s);
   if (NO <= 2)
-    hipLaunchKernelGGL((head_bwd_kernel<2>), grid, block, 0, s, x, w, dense, gdense, gpool, lungs, ng, dx, wpartial, D, H, W, NO, sigmoid, nblk);
+    hipLaunchKernelGGL((head_bwd_kernel<2, T>), grid, block, 0, s, x, w, dense, gdense, gpool, lungs, ng, dx, wpartial, D, H, W, NO, sigmoid, nblk);
   else if (NO <= 9)
-    hipLaunchKernelGGL((head_bwd_kernel<9>), grid, block, 0, s, x, w, dense, gdense, gpool, lungs, ng, dx, wpartial, D, H, W, NO, sigmoid, nblk);
+    hipLaunchKernelGGL((head_bwd_kernel<9, T>), grid, block, 0, s, x, w, dense, gdense, gpool, lungs, ng, dx, wpartial, D, H, W, NO, sigmoid, nblk);
   else
-    hipLaunchKernelGGL((head_bwd_kernel<16>), grid, block, 0, s, x, w, dense, gdense, gpool, lungs, ng, dx, wpartial, D, H, W, NO, sigmoid, nblk);
+    hipLaunchKernelGGL((head_bwd_kernel<16, T>), grid, block, 0, s, x, w, dense, gdense, gpool, lungs, ng, dx, wpartial, D, H, W, NO, sigmoid, nblk);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
+}
+extern "C" int dram_head_bwd(const float* x, const float* w, const float* dense, const float* gdense,
+                             const float* gpool, const float* lungs, int Dl, int Hl, int Wl, float* dx,
+                             float* wpartial, int B, int D, int H, int W, int NO, int sigmoid, dram_stream_t stream) {
+  return head_bwd_impl<float>(x, w, dense, gdense, gpool, lungs, Dl, Hl, Wl, dx, wpartial, B, D, H, W, NO, sigmoid, stream);
+}
+extern "C" int dram_head_bwd_bf16(const void* x, const float* w, const float* dense, const float* gdense,
+                                  const float* gpool, const float* lungs, int Dl, int Hl, int Wl, void* dx,
+                                  float* wpartial, int B, int D, int H, int W, int NO, int sigmoid, dram_stream_t stream) {
+  return head_bwd_impl<bf16_t>((const bf16_t*)x, w, dense, gdense, gpool, lungs, Dl, Hl, Wl, (bf16_t*)dx, wpartial, B, D, H,
+                               W, NO, sigmoid, stream);
 }
 
 extern "C" int dram_segloss_nblk(long long voxels_total) {

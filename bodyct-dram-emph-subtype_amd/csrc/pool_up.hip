@@ -14,7 +14,8 @@ inline int ew_grid(long total) {
 }
 
 // ------------------------------------------------------------------ max pool
-__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                    uint8_t* __restrict__ amax, int D, int H, int W, int C, int Do, int Ho, int Wo,
                                    long total4) {
   const int Q = C >> 2;
@@ -43,7 +44,7 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
           const int yi = 2 * yo - 1 + ky, xi = 2 * xo - 1 + kx;
           ok[ky][kx] = (yi >= 0) & (yi < H) & (xi >= 0) & (xi < W);
           const int yc = yi < 0 ? 0 : (yi >= H ? H - 1 : yi), xc = xi < 0 ? 0 : (xi >= W ? W - 1 : xi);
-          t[ky][kx] = *reinterpret_cast<const float4*>(x + ((((b * D + zi) * H + yc) * W + xc) * (long)C + 4 * q));
+          t[ky][kx] = ld4<T>(x, (((b * D + zi) * H + yc) * W + xc) * (long)C + 4 * q);
         }
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
@@ -59,14 +60,15 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
           first = false;
         }
     }
-    reinterpret_cast<float4*>(y)[i] = m;
+    st4<T>(y, 4 * i, m);
     reinterpret_cast<uchar4*>(amax)[i] = make_uchar4((unsigned char)ax, (unsigned char)ay, (unsigned char)az,
                                                      (unsigned char)aw);
   }
 }
 
-__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ amax,
-                                   const float* __restrict__ add, int add_stride, float* __restrict__ dx, int D, int H,
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ amax,
+                                   const T* __restrict__ add, int add_stride, T* __restrict__ dx, int D, int H,
                                    int W, int C, int Do, int Ho, int Wo, long total4) {
   const int Q = C >> 2;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
@@ -77,8 +79,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
     const int zi = (int)(v % D);
     const long b = v / D;
     // add: a tensor shaped like dx, or a channel slice of a wider one (add_stride floats per voxel)
-    float4 s = add ? *reinterpret_cast<const float4*>(add + (i / Q) * (long)add_stride + 4 * q)
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s = add ? ld4<T>(add, (i / Q) * (long)add_stride + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     // windows containing zi: zo with 2zo-1 <= zi <= 2zo+1
     const int zlo = zi >> 1, zhi = (zi + 1) >> 1;  // ceil((zi-1)/2) == zi>>1 for zi>=0
     const int ylo = yi >> 1, yhi = (yi + 1) >> 1;
@@ -96,7 +97,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
           const int zo = min(zlo + dz, Do - 1), yo = min(ylo + dy_, Ho - 1), xo = min(xlo + dx_, Wo - 1);
           const long o = ((((b * Do + zo) * Ho + yo) * Wo + xo) * (long)Q + q);
           am[dz][dy_][dx_] = reinterpret_cast<const uchar4*>(amax)[o];
-          gg[dz][dy_][dx_] = reinterpret_cast<const float4*>(dy)[o];
+          gg[dz][dy_][dx_] = ld4<T>(dy, 4 * o);
         }
 #pragma unroll
     for (int dz = 0; dz < 2; ++dz)
@@ -115,7 +116,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
           if (a.z == tap) s.z += g.z;
           if (a.w == tap) s.w += g.w;
         }
-    reinterpret_cast<float4*>(dx)[i] = s;
+    st4<T>(dx, 4 * i, s);
   }
 }
 
@@ -132,8 +133,9 @@ __device__ __forceinline__ void lin_src(int dst, float scale, int in, int& i0, i
   w0 = 1.f - w1;
 }
 
-__global__ void upcat_fwd_kernel(const float* __restrict__ src, const float* __restrict__ skip,
-                                 float* __restrict__ cat, int Ds, int Hs, int Ws, int Cu, int Dk, int Hk, int Wk,
+template <typename T>
+__global__ void upcat_fwd_kernel(const T* __restrict__ src, const T* __restrict__ skip,
+                                 T* __restrict__ cat, int Ds, int Hs, int Ws, int Cu, int Dk, int Hk, int Wk,
                                  int Ck, int oz, int oy, int ox, float sz, float sy, float sx, long total4) {
   const int Do = 2 * Ds, Ho = 2 * Hs, Wo = 2 * Ws;
   const int Ct = Cu + Ck, Q = Ct >> 2, Qu = Cu >> 2;
@@ -154,7 +156,7 @@ __global__ void upcat_fwd_kernel(const float* __restrict__ src, const float* __r
       o = make_float4(0.f, 0.f, 0.f, 0.f);
 #define UP_ACC(zz, yy, xx, ww)                                                                                   \
   {                                                                                                              \
-    const float4 t = *reinterpret_cast<const float4*>(src + ((((b * Ds + zz) * Hs + yy) * Ws + xx) * (long)Cu + 4 * q)); \
+    const float4 t = ld4<T>(src, (((b * Ds + zz) * Hs + yy) * Ws + xx) * (long)Cu + 4 * q);                     \
     const float w_ = (ww);                                                                                       \
     o.x += w_ * t.x; o.y += w_ * t.y; o.z += w_ * t.z; o.w += w_ * t.w;                                          \
   }
@@ -165,10 +167,9 @@ __global__ void upcat_fwd_kernel(const float* __restrict__ src, const float* __r
       UP_ACC(z1, y1, x0, wz1 * wy1 * wx0) UP_ACC(z1, y1, x1, wz1 * wy1 * wx1)
 #undef UP_ACC
     } else {
-      o = *reinterpret_cast<const float4*>(
-          skip + ((((b * Dk + zo + oz) * Hk + yo + oy) * Wk + xo + ox) * (long)Ck + 4 * (q - Qu)));
+      o = ld4<T>(skip, (((b * Dk + zo + oz) * Hk + yo + oy) * Wk + xo + ox) * (long)Ck + 4 * (q - Qu));
     }
-    reinterpret_cast<float4*>(cat)[i] = o;
+    st4<T>(cat, 4 * i, o);
   }
 }
 
@@ -179,8 +180,9 @@ __global__ void upcat_fwd_kernel(const float* __restrict__ src, const float* __r
 // most 5 past the first output's floor) are loaded once per 64-channel block into LDS instead of
 // being gathered eight times per output from L2 / MALL (8 x the output bytes: the untiled kernel ran at 2.5 TB/s).
 // Same corner order and weights as upcat_fwd_kernel.
-__global__ __launch_bounds__(256) void upcat_fwd_tiled_kernel(const float* __restrict__ src, const float* __restrict__ skip,
-                                                              float* __restrict__ cat, int Ds, int Hs, int Ws, int Cu,
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_fwd_tiled_kernel(const T* __restrict__ src, const T* __restrict__ skip,
+                                                              T* __restrict__ cat, int Ds, int Hs, int Ws, int Cu,
                                                               int Dk, int Hk, int Wk, int Ck, int oz, int oy, int ox,
                                                               float sz, float sy, float sx, int tz_n, int ty_n,
                                                               int tx_n) {
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void upcat_fwd_tiled_kernel(const float* __res
       const int qq = e & 15, v = e >> 4;
       const int lx = v % 6, ly = (v / 6) % 6, lz = v / 36;
       const int zz = min(zb + lz, Ds - 1), yy = min(yb + ly, Hs - 1), xx = min(xb + lx, Ws - 1);
-      tile[e] = *reinterpret_cast<const float4*>(src + ((((b * Ds + zz) * Hs + yy) * Ws + xx) * (long)Cu + 4 * (cb + qq)));
+      tile[e] = ld4<T>(src, (((b * Ds + zz) * Hs + yy) * Ws + xx) * (long)Cu + 4 * (cb + qq));
     }
     __syncthreads();
     for (int v = vs; v < 512; v += 16) {
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void upcat_fwd_tiled_kernel(const float* __res
       UPT_ACC(zc, yc, xa, wz1 * wy1 * wx0) UPT_ACC(zc, yc, xc, wz1 * wy1 * wx1)
 #undef UPT_ACC
       const long vox = ((b * Do + zo) * Ho + yo) * (long)Wo + xo;
-      reinterpret_cast<float4*>(cat)[vox * Q + cb + q] = o;
+      st4<T>(cat, 4 * (vox * Q + cb + q), o);
     }
   }
   // centre-cropped skip connection -> channels Cu .. Ct - 1
@@ -240,8 +242,8 @@ __global__ __launch_bounds__(256) void upcat_fwd_tiled_kernel(const float* __res
     const int zo = z0 + (v >> 6), yo = y0 + ((v >> 3) & 7), xo = x0 + (v & 7);
     if (zo >= Do || yo >= Ho || xo >= Wo) continue;
     const long vox = ((b * Do + zo) * Ho + yo) * (long)Wo + xo;
-    reinterpret_cast<float4*>(cat)[vox * Q + Qu + qq] = *reinterpret_cast<const float4*>(
-        skip + ((((b * Dk + zo + oz) * Hk + yo + oy) * Wk + xo + ox) * (long)Ck + 4 * qq));
+    st4<T>(cat, 4 * (vox * Q + Qu + qq),
+           ld4<T>(skip, (((b * Dk + zo + oz) * Hk + yo + oy) * Wk + xo + ox) * (long)Ck + 4 * qq));
   }
 }
 
@@ -283,7 +285,8 @@ __device__ __forceinline__ UpAxis up_axis(int s, float scale, int in, int out) {
 // separable and channel-independent: three 6-entry tables (18 lin_src evaluations; the first version re-derived them
 // inside a 7x7x7 candidate loop with three levels of data-dependent `continue`, one load in flight: 1.3 TB/s), then
 // rows of 6 predicated loads issued together.
-__global__ void upcat_bwd_src_kernel(const float* __restrict__ dcat, float* __restrict__ dsrc, int Ds, int Hs, int Ws,
+template <typename T>
+__global__ void upcat_bwd_src_kernel(const T* __restrict__ dcat, T* __restrict__ dsrc, int Ds, int Hs, int Ws,
                                      int Cu, int Ct, float sz, float sy, float sx, long total4) {
   const int Do = 2 * Ds, Ho = 2 * Hs, Wo = 2 * Ws;
   const int Qu = Cu >> 2;
@@ -303,11 +306,11 @@ __global__ void upcat_bwd_src_kernel(const float* __restrict__ dcat, float* __re
       for (int jy = 0; jy < 6; ++jy) {
         const float wzy = tz.w[jz] * ty.w[jy];
         if (wzy == 0.f) continue;
-        const float* row = dcat + (((b * Do + tz.lo + jz) * Ho + ty.lo + jy) * (long)Wo + tx.lo) * (long)Ct + 4 * q;
+        const T* row = dcat + (((b * Do + tz.lo + jz) * Ho + ty.lo + jy) * (long)Wo + tx.lo) * (long)Ct + 4 * q;
         float4 g[6];
 #pragma unroll
         for (int jx = 0; jx < 6; ++jx)      // clamped address + zero weight instead of a branch per load
-          g[jx] = *reinterpret_cast<const float4*>(row + (long)(tx.w[jx] != 0.f ? jx : 0) * Ct);
+          g[jx] = ld4<T>(row, (long)(tx.w[jx] != 0.f ? jx : 0) * Ct);
 #pragma unroll
         for (int jx = 0; jx < 6; ++jx) {
           const float w_ = wzy * tx.w[jx];
@@ -315,11 +318,12 @@ __global__ void upcat_bwd_src_kernel(const float* __restrict__ dcat, float* __re
         }
       }
     }
-    reinterpret_cast<float4*>(dsrc)[i] = acc;
+    st4<T>(dsrc, 4 * i, acc);
   }
 }
 
-__global__ void upcat_bwd_skip_kernel(const float* __restrict__ dcat, float* __restrict__ dskip, int Do, int Ho,
+template <typename T>
+__global__ void upcat_bwd_skip_kernel(const T* __restrict__ dcat, T* __restrict__ dskip, int Do, int Ho,
                                       int Wo, int Cu, int Dk, int Hk, int Wk, int Ck, int oz, int oy, int ox,
                                       long total4) {
   const int Qk = Ck >> 2;
@@ -334,8 +338,8 @@ __global__ void upcat_bwd_skip_kernel(const float* __restrict__ dcat, float* __r
     const int zo = zk - oz, yo = yk - oy, xo = xk - ox;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (zo >= 0 && zo < Do && yo >= 0 && yo < Ho && xo >= 0 && xo < Wo)
-      o = *reinterpret_cast<const float4*>(dcat + ((((b * Do + zo) * Ho + yo) * Wo + xo) * (long)Ct + Cu + 4 * q));
-    reinterpret_cast<float4*>(dskip)[i] = o;
+      o = ld4<T>(dcat, (((b * Do + zo) * Ho + yo) * Wo + xo) * (long)Ct + Cu + 4 * q);
+    st4<T>(dskip, 4 * i, o);
   }
 }
 
@@ -376,34 +380,55 @@ inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (flo
 
 }  // namespace
 
-extern "C" int dram_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int B, int D, int H, int W, int C,
-                                dram_stream_t stream) {
+template <typename T>
+static int maxpool_fwd_impl(const T* x, T* y, uint8_t* argmax, int B, int D, int H, int W, int C, dram_stream_t stream) {
   if (!x || !y || !argmax || B < 1 || D < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
   const int Do = (D + 2 - 3) / 2 + 1, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long total4 = (long)B * Do * Ho * Wo * (C >> 2);
-  DramProf prof(DRAM_FAM_POOL_UP, 0, 0.0, 4.0 * (double)B * D * H * W * C + 5.0 * 4.0 * total4, (hipStream_t)stream);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, D, H,
+  DramProf prof(DRAM_FAM_POOL_UP, 0, 0.0, (double)sizeof(T) * ((double)B * D * H * W * C + 4.0 * total4) + 4.0 * total4,
+                (hipStream_t)stream);
+  hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, D, H,
                      W, C, Do, Ho, Wo, total4);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
+extern "C" int dram_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int B, int D, int H, int W, int C,
+                                dram_stream_t stream) {
+  return maxpool_fwd_impl<float>(x, y, argmax, B, D, H, W, C, stream);
+}
+extern "C" int dram_maxpool_fwd_bf16(const void* x, void* y, uint8_t* argmax, int B, int D, int H, int W, int C,
+                                     dram_stream_t stream) {
+  return maxpool_fwd_impl<bf16_t>((const bf16_t*)x, (bf16_t*)y, argmax, B, D, H, W, C, stream);
+}
 
-extern "C" int dram_maxpool_bwd(const float* dy, const uint8_t* argmax, const float* add, int add_stride, float* dx,
-                                int B, int D, int H, int W, int C, dram_stream_t stream) {
+template <typename T>
+static int maxpool_bwd_impl(const T* dy, const uint8_t* argmax, const T* add, int add_stride, T* dx, int B, int D, int H,
+                            int W, int C, dram_stream_t stream) {
   if (!dy || !dx || !argmax || B < 1 || D < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
-  if (add && (add_stride < C || (add_stride & 3) || ((uintptr_t)add & 15))) return DRAM_ERR_BAD_ARG;
+  if (add && (add_stride < C || (add_stride & 3) || ((uintptr_t)add & (4 * sizeof(T) - 1)))) return DRAM_ERR_BAD_ARG;
   const int Do = (D + 2 - 3) / 2 + 1, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long total4 = (long)B * D * H * W * (C >> 2);
   DramProf prof(DRAM_FAM_POOL_UP, 1, 0.0,
-                4.0 * 4.0 * total4 * (1.0 + (add ? 1 : 0)) + 5.0 * (double)B * Do * Ho * Wo * C, (hipStream_t)stream);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, argmax, add,
+                (double)sizeof(T) * 4.0 * total4 * (1.0 + (add ? 1 : 0)) + (1.0 + sizeof(T)) * (double)B * Do * Ho * Wo * C,
+                (hipStream_t)stream);
+  hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, argmax, add,
                      add_stride, dx, D, H, W, C, Do, Ho, Wo, total4);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
+extern "C" int dram_maxpool_bwd(const float* dy, const uint8_t* argmax, const float* add, int add_stride, float* dx,
+                                int B, int D, int H, int W, int C, dram_stream_t stream) {
+  return maxpool_bwd_impl<float>(dy, argmax, add, add_stride, dx, B, D, H, W, C, stream);
+}
+extern "C" int dram_maxpool_bwd_bf16(const void* dy, const uint8_t* argmax, const void* add, int add_stride, void* dx,
+                                     int B, int D, int H, int W, int C, dram_stream_t stream) {
+  return maxpool_bwd_impl<bf16_t>((const bf16_t*)dy, argmax, (const bf16_t*)add, add_stride, (bf16_t*)dx, B, D, H, W, C,
+                                  stream);
+}
 
-extern "C" int dram_upcat_fwd(const float* src, const float* skip, float* cat, int B, int Ds, int Hs, int Ws, int Cu,
-                              int Dk, int Hk, int Wk, int Ck, dram_stream_t stream) {
+template <typename T>
+static int upcat_fwd_impl(const T* src, const T* skip, T* cat, int B, int Ds, int Hs, int Ws, int Cu, int Dk, int Hk,
+                          int Wk, int Ck, dram_stream_t stream) {
   if (!src || !skip || !cat || B < 1 || Cu < 4 || Ck < 4 || (Cu & 3) || (Ck & 3)) return DRAM_ERR_BAD_ARG;
   const int Do = 2 * Ds, Ho = 2 * Hs, Wo = 2 * Ws;
   if (Dk < Do || Hk < Ho || Wk < Wo) return DRAM_ERR_BAD_ARG;  // crop_concat_5d assumes t1 <= t2
@@ -411,23 +436,34 @@ extern "C" int dram_upcat_fwd(const float* src, const float* skip, float* cat, i
   const long total4 = (long)B * Do * Ho * Wo * ((Cu + Ck) >> 2);
   const long tiles = (long)B * ((Do + 7) / 8) * ((Ho + 7) / 8) * ((Wo + 7) / 8);
   DramProf prof(DRAM_FAM_POOL_UP, 2, 0.0,
-                4.0 * ((double)B * Ds * Hs * Ws * Cu + (double)B * Do * Ho * Wo * Ck + 4.0 * total4), (hipStream_t)stream);
+                (double)sizeof(T) * ((double)B * Ds * Hs * Ws * Cu + (double)B * Do * Ho * Wo * Ck + 4.0 * total4),
+                (hipStream_t)stream);
   if (Cu % 64 == 0 && tiles >= 512 && tiles < (1L << 31) && !getenv("DRAM_UPCAT_UNTILED")) {
-    hipLaunchKernelGGL(upcat_fwd_tiled_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, src, skip, cat, Ds,
-                       Hs, Ws, Cu, Dk, Hk, Wk, Ck, oz, oy, ox, ac_scale(Ds, Do), ac_scale(Hs, Ho), ac_scale(Ws, Wo),
+    hipLaunchKernelGGL((upcat_fwd_tiled_kernel<T>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, src, skip, cat,
+                       Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck, oz, oy, ox, ac_scale(Ds, Do), ac_scale(Hs, Ho), ac_scale(Ws, Wo),
                        (Do + 7) / 8, (Ho + 7) / 8, (Wo + 7) / 8);
     DRAM_LAUNCH_CHECK();
     return DRAM_OK;
   }
-  hipLaunchKernelGGL(upcat_fwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, src, skip, cat, Ds,
+  hipLaunchKernelGGL((upcat_fwd_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, src, skip, cat, Ds,
                      Hs, Ws, Cu, Dk, Hk, Wk, Ck, oz, oy, ox, ac_scale(Ds, Do), ac_scale(Hs, Ho), ac_scale(Ws, Wo),
                      total4);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
-
-extern "C" int dram_upcat_bwd(const float* dcat, float* dsrc, float* dskip, int B, int Ds, int Hs, int Ws, int Cu,
+extern "C" int dram_upcat_fwd(const float* src, const float* skip, float* cat, int B, int Ds, int Hs, int Ws, int Cu,
                               int Dk, int Hk, int Wk, int Ck, dram_stream_t stream) {
+  return upcat_fwd_impl<float>(src, skip, cat, B, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck, stream);
+}
+extern "C" int dram_upcat_fwd_bf16(const void* src, const void* skip, void* cat, int B, int Ds, int Hs, int Ws, int Cu,
+                                   int Dk, int Hk, int Wk, int Ck, dram_stream_t stream) {
+  return upcat_fwd_impl<bf16_t>((const bf16_t*)src, (const bf16_t*)skip, (bf16_t*)cat, B, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck,
+                                stream);
+}
+
+template <typename T>
+static int upcat_bwd_impl(const T* dcat, T* dsrc, T* dskip, int B, int Ds, int Hs, int Ws, int Cu, int Dk, int Hk, int Wk,
+                          int Ck, dram_stream_t stream) {
   if (!dcat || (!dsrc && !dskip) || B < 1 || Cu < 4 || Ck < 4 || (Cu & 3) || (Ck & 3)) return DRAM_ERR_BAD_ARG;
   const int Do = 2 * Ds, Ho = 2 * Hs, Wo = 2 * Ws;
   if (Dk < Do || Hk < Ho || Wk < Wo) return DRAM_ERR_BAD_ARG;
@@ -435,19 +471,28 @@ extern "C" int dram_upcat_bwd(const float* dcat, float* dsrc, float* dskip, int 
   hipStream_t s = (hipStream_t)stream;
   if (dsrc) {
     const long total4 = (long)B * Ds * Hs * Ws * (Cu >> 2);
-    DramProf prof(DRAM_FAM_POOL_UP, 3, 0.0, 4.0 * ((double)B * Do * Ho * Wo * Cu + 4.0 * total4), s);
-    hipLaunchKernelGGL(upcat_bwd_src_kernel, dim3(ew_grid(total4)), dim3(256), 0, s, dcat, dsrc, Ds, Hs, Ws, Cu,
+    DramProf prof(DRAM_FAM_POOL_UP, 3, 0.0, (double)sizeof(T) * ((double)B * Do * Ho * Wo * Cu + 4.0 * total4), s);
+    hipLaunchKernelGGL((upcat_bwd_src_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, s, dcat, dsrc, Ds, Hs, Ws, Cu,
                        Cu + Ck, ac_scale(Ds, Do), ac_scale(Hs, Ho), ac_scale(Ws, Wo), total4);
     DRAM_LAUNCH_CHECK();
   }
   if (dskip) {
     const long total4 = (long)B * Dk * Hk * Wk * (Ck >> 2);
-    DramProf prof(DRAM_FAM_POOL_UP, 4, 0.0, 4.0 * ((double)B * Do * Ho * Wo * Ck + 4.0 * total4), s);
-    hipLaunchKernelGGL(upcat_bwd_skip_kernel, dim3(ew_grid(total4)), dim3(256), 0, s, dcat, dskip, Do, Ho, Wo, Cu, Dk,
+    DramProf prof(DRAM_FAM_POOL_UP, 4, 0.0, (double)sizeof(T) * ((double)B * Do * Ho * Wo * Ck + 4.0 * total4), s);
+    hipLaunchKernelGGL((upcat_bwd_skip_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, s, dcat, dskip, Do, Ho, Wo, Cu, Dk,
                        Hk, Wk, Ck, oz, oy, ox, total4);
     DRAM_LAUNCH_CHECK();
   }
   return DRAM_OK;
+}
+extern "C" int dram_upcat_bwd(const float* dcat, float* dsrc, float* dskip, int B, int Ds, int Hs, int Ws, int Cu,
+                              int Dk, int Hk, int Wk, int Ck, dram_stream_t stream) {
+  return upcat_bwd_impl<float>(dcat, dsrc, dskip, B, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck, stream);
+}
+extern "C" int dram_upcat_bwd_bf16(const void* dcat, void* dsrc, void* dskip, int B, int Ds, int Hs, int Ws, int Cu,
+                                   int Dk, int Hk, int Wk, int Ck, dram_stream_t stream) {
+  return upcat_bwd_impl<bf16_t>((const bf16_t*)dcat, (bf16_t*)dsrc, (bf16_t*)dskip, B, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck,
+                                stream);
 }
 
 extern "C" int dram_upproject_nblk(long long vps) {

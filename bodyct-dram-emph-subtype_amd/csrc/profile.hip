@@ -29,8 +29,9 @@ unsigned g_gen = 0;
 
 const char* const kNames[DRAM_FAM_COUNT] = {
     "conv_wino2d", "wino_in", "wino_gemm_nn", "wino_out", "wino_gemm_tn", "wino_wgrad_out", "weight_pack",
-    "conv_wgrad_w2d", "conv_igemm", "conv_wgrad", "stem", "bn_elementwise", "pool_up", "head_loss", "optim", "prep"};
-const int kMfma[DRAM_FAM_COUNT] = {1, 0, 1, 0, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+    "conv_wgrad_w2d", "conv_igemm", "conv_wgrad", "stem", "bn_elementwise", "pool_up", "head_loss", "optim", "prep",
+    "conv_bf16", "wgrad_bf16"};
+const int kMfma[DRAM_FAM_COUNT] = {1, 0, 1, 0, 1, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1, 1};
 }  // namespace
 
 void dram_prof_begin(int family, int variant, double mfma_flops, double hbm_bytes, double alg_flops, hipStream_t s) {

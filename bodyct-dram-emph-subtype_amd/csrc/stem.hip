@@ -31,9 +31,10 @@ struct StemGeom {
   int nz, ny, nx, tiles_per_b, nblk;
 };
 
+template <typename T>   // T: storage type of the output y (float | bf16_t); the BN sums are taken from the fp32 accumulators
 __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ w,
-                                                          float* __restrict__ y, float* __restrict__ stats,
+                                                          T* __restrict__ y, float* __restrict__ stats,
                                                           const StemGeom g) {
   __shared__ __attribute__((aligned(16))) float lds[PATCHP + KT * WLP];
   float* patch = lds;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const float* __restric
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
           const float v = acc[mi][nj][e];
-          y[o + nj * 32] = v;
+          st1<T>(y, o + nj * 32, v);
           s1[nj] += v;
           s2[nj] += v * v;
         }
@@ -172,8 +173,9 @@ struct StemWGeom {
   int total;       // B*Do*ny*nx
 };
 
+template <typename T>   // T: storage type of dy
 __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const float* __restrict__ x,
-                                                            const float* __restrict__ dy,
+                                                            const T* __restrict__ dy,
                                                             float* __restrict__ slab, const StemWGeom g) {
   __shared__ __attribute__((aligned(16))) float lds[GPATCHP + 3 + 64 * GLDY];
   float* patch = lds;
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const float* __restr
       const int yo = y0 + (v >> 3), xo = x0 + (v & 7);
       const bool ok = (yo < g.Ho) & (xo < g.Wo);
       const long o = ((((long)b * g.Do + zo) * g.Ho + yo) * g.Wo + xo) * 64 + c4 * 4;
-      rd[p] = ok ? *reinterpret_cast<const float4*>(dy + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rd[p] = ok ? ld4<T>(dy, o) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto store_tile = [&]() {
@@ -301,8 +303,9 @@ extern "C" int dram_stem_num_tiles(int B, int Do, int Ho, int Wo) {
   return B * ((Do + 3) / 4) * ((Ho + 7) / 8) * ((Wo + 7) / 8);
 }
 
-extern "C" int dram_stem_fwd(const float* x, const float* w, float* y, float* stats_partial, int B, int D,
-                             int H, int W, dram_stream_t stream) {
+template <typename T>
+static int stem_fwd_impl(const float* x, const float* w, T* y, float* stats_partial, int B, int D, int H, int W,
+                         dram_stream_t stream) {
   if (!x || !w || !y || B < 1 || D < 1 || H < 1 || W < 1) return DRAM_ERR_BAD_ARG;
   StemGeom g{};
   g.B = B; g.D = D; g.H = H; g.W = W;
@@ -312,11 +315,19 @@ extern "C" int dram_stem_fwd(const float* x, const float* w, float* y, float* st
   g.tiles_per_b = g.nz * g.ny * g.nx;
   g.nblk = B * g.tiles_per_b;
   const double vo = (double)B * g.Do * g.Ho * g.Wo;
-  DramProf prof(DRAM_FAM_STEM, 0, 2.0 * vo * 64.0 * 343.0, 4.0 * ((double)B * D * H * W + vo * 64.0 + 64.0 * 343.0),
-                (hipStream_t)stream);
-  hipLaunchKernelGGL(stem_fwd_kernel, dim3(g.nblk), dim3(256), 0, (hipStream_t)stream, x, w, y, stats_partial, g);
+  DramProf prof(DRAM_FAM_STEM, 0, 2.0 * vo * 64.0 * 343.0,
+                4.0 * ((double)B * D * H * W + 64.0 * 343.0) + sizeof(T) * vo * 64.0, (hipStream_t)stream);
+  hipLaunchKernelGGL((stem_fwd_kernel<T>), dim3(g.nblk), dim3(256), 0, (hipStream_t)stream, x, w, y, stats_partial, g);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
+}
+extern "C" int dram_stem_fwd(const float* x, const float* w, float* y, float* stats_partial, int B, int D,
+                             int H, int W, dram_stream_t stream) {
+  return stem_fwd_impl<float>(x, w, y, stats_partial, B, D, H, W, stream);
+}
+extern "C" int dram_stem_fwd_bf16(const float* x, const float* w, void* y, float* stats_partial, int B, int D,
+                                  int H, int W, dram_stream_t stream) {
+  return stem_fwd_impl<bf16_t>(x, w, (bf16_t*)y, stats_partial, B, D, H, W, stream);
 }
 
 extern "C" size_t dram_stem_bwd_weight_workspace(int B, int D, int H, int W) {
@@ -325,8 +336,9 @@ extern "C" size_t dram_stem_bwd_weight_workspace(int B, int D, int H, int W) {
   return (size_t)stem_wgrad_blocks(total) * 64 * NTAP * sizeof(float);
 }
 
-extern "C" int dram_stem_bwd_weight(const float* x, const float* dy, float* dw, int B, int D, int H, int W,
-                                    void* workspace, size_t workspace_bytes, dram_stream_t stream) {
+template <typename T>
+static int stem_bwd_weight_impl(const float* x, const T* dy, float* dw, int B, int D, int H, int W, void* workspace,
+                                size_t workspace_bytes, dram_stream_t stream) {
   if (!x || !dy || !dw || B < 1 || D < 1 || H < 1 || W < 1) return DRAM_ERR_BAD_ARG;
   StemWGeom g{};
   g.B = B; g.D = D; g.H = H; g.W = W;
@@ -337,11 +349,20 @@ extern "C" int dram_stem_bwd_weight(const float* x, const float* dy, float* dw, 
   if (!workspace || workspace_bytes < (size_t)nblk * 64 * NTAP * sizeof(float)) return DRAM_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const double vo = (double)B * g.Do * g.Ho * g.Wo;
-  DramProf prof(DRAM_FAM_STEM, 1, 2.0 * vo * 64.0 * 343.0, 4.0 * ((double)B * D * H * W + vo * 64.0 + 64.0 * 343.0), s);
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, s, x, dy, (float*)workspace, g);
+  DramProf prof(DRAM_FAM_STEM, 1, 2.0 * vo * 64.0 * 343.0,
+                4.0 * ((double)B * D * H * W + 64.0 * 343.0) + sizeof(T) * vo * 64.0, s);
+  hipLaunchKernelGGL((stem_wgrad_kernel<T>), dim3(nblk), dim3(256), 0, s, x, dy, (float*)workspace, g);
   DRAM_LAUNCH_CHECK();
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * NTAP + 255) / 256), dim3(256), 0, s,
                      (const float*)workspace, dw, nblk);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
+}
+extern "C" int dram_stem_bwd_weight(const float* x, const float* dy, float* dw, int B, int D, int H, int W,
+                                    void* workspace, size_t workspace_bytes, dram_stream_t stream) {
+  return stem_bwd_weight_impl<float>(x, dy, dw, B, D, H, W, workspace, workspace_bytes, stream);
+}
+extern "C" int dram_stem_bwd_weight_bf16(const float* x, const void* dy, float* dw, int B, int D, int H, int W,
+                                         void* workspace, size_t workspace_bytes, dram_stream_t stream) {
+  return stem_bwd_weight_impl<bf16_t>(x, (const bf16_t*)dy, dw, B, D, H, W, workspace, workspace_bytes, stream);
 }

@@ -37,8 +37,10 @@ BN_MOMENTUM = 0.1
 class _State:
     """Per-call state: parameter/buffer dicts, flags, saved contexts, gradient sink."""
 
-    def __init__(self, P: Dict[str, Tensor], training: bool, need_grad: bool, dist=None, recompute: bool = False):
+    def __init__(self, P: Dict[str, Tensor], training: bool, need_grad: bool, dist=None, recompute: bool = False,
+                 storage=torch.float32):
         self.P = P
+        self.storage = storage        # storage type of the activations: float32, or bfloat16 (`--precision bf16`)
         self.training = training
         self.need_grad = need_grad
         self.dist = dist
@@ -133,9 +135,9 @@ class Engine:
                     st.packed_ready = None
                 wf, wb = pre[0], pre[1]
             else:
-                wf, wb = ops.pack_conv_weight(w, True, True, g)
+                wf, wb = ops.pack_conv_weight(w, True, True, g, st.storage)
         else:                                           # inference: packed / transformed once per weight version
-            wf, wb = ops.packed_forward_weight(w, g), None
+            wf, wb = ops.packed_forward_weight(w, g, st.storage), None
         y, sp, v = ops.conv3d_fwd_keep(x, wf, st.P[bname] if bname else None, g, st.training,
                                        st.need_grad and not st.recompute)
         z, mean, invstd, count, ss = self._bn_fwd(st, y, sp, bnp, residual, rs)
@@ -269,12 +271,17 @@ class Engine:
 
     # ------------------------------------------------------------------ whole network
     def forward(self, P: Dict[str, Tensor], x: Tensor, lungs: Optional[Tensor], training: bool, need_grad: bool,
-                dist=None, recompute: bool = False):
+                dist=None, recompute: bool = False, storage=torch.float32):
         """x [B,1,D,H,W] (NCDHW == NDHW for C=1), lungs None or [B,1,D,H,W] float.
         Returns (dense_list, outs_list, saved-or-None).  Every kernel is launched on x's device (its
-        current stream); operands on any other device are rejected before launch."""
+        current stream); operands on any other device are rejected before launch.
+        storage: float32 (the reference's default arithmetic) or bfloat16 -- activations and saved tensors in bf16,
+        products of bf16 operands accumulated in fp32, statistics / parameters / weight gradients / dense head
+        outputs in fp32 (the reference under `--precision bf16`, train.py:46)."""
+        if storage not in (torch.float32, torch.bfloat16):
+            raise NotImplementedError(f"activation storage type {storage}")
         with ops.launch_scope(x.device):
-            return self._forward(P, x, lungs, training, need_grad, dist, recompute)
+            return self._forward(P, x, lungs, training, need_grad, dist, recompute, storage)
 
     def backward(self, saved: dict, g_dense: List[Optional[Tensor]], g_outs: List[Optional[Tensor]]):
         with ops.launch_scope(saved["dense"].device):
@@ -292,25 +299,25 @@ class Engine:
         side.wait_stream(main)                         # the optimizer's update of the weights precedes the packing
         with ops.on_stream(side):
             for wname, g in plan:
-                wf, wb = ops.pack_conv_weight(st.P[wname], True, True, g)
+                wf, wb = ops.pack_conv_weight(st.P[wname], True, True, g, st.storage)
                 wf.record_stream(main)
                 wb.record_stream(main)
                 st.packed[wname] = (wf, wb, g)
             st.packed_ready = torch.cuda.Event()
             st.packed_ready.record(side)
 
-    def _forward(self, P, x, lungs, training, need_grad, dist, recompute=False):
+    def _forward(self, P, x, lungs, training, need_grad, dist, recompute=False, storage=torch.float32):
         if need_grad and not training:
             raise NotImplementedError("gradients through eval-mode BatchNorm are not part of the hot path")
-        st = _State(P, training, need_grad, dist, recompute)
+        st = _State(P, training, need_grad, dist, recompute, storage)
         B, _, D, H, W = x.shape
-        shape_key = (tuple(x.shape), x.device.index)
+        shape_key = (tuple(x.shape), storage, x.device.index)
         if need_grad:
             self._prepack(st, shape_key)
         x4 = x.reshape(B, D, H, W)
         lungs4 = None if lungs is None else lungs.reshape(B, *lungs.shape[-3:]).contiguous()
 
-        y0, sp0 = ops.stem_fwd(x4, P["conv1.weight"], training)
+        y0, sp0 = ops.stem_fwd(x4, P["conv1.weight"], training, storage)
         xs, mean0, invstd0, count0, ss0 = self._bn_fwd(st, y0, sp0, "bn1", None, 1)
         xp, amax = ops.maxpool_fwd(xs)
 
@@ -450,5 +457,5 @@ def forward_decisions(saved: dict) -> Dict[str, Tensor]:
             out[c["bn"]] = mask(c["z"])
         else:                               # activation recompute: z was not kept; same fma as bn_apply_kernel
             sc, sh = c["ss"]
-            out[c["bn"]] = (torch.addcmul(sh, c["y"], sc) > 0).permute(0, 4, 1, 2, 3).contiguous()
+            out[c["bn"]] = (torch.addcmul(sh, c["y"].float(), sc) > 0).permute(0, 4, 1, 2, 3).contiguous()
     return out

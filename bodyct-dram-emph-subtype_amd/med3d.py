@@ -90,7 +90,7 @@ class _Med3DFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         P = module._tensor_dict()
         dense, outs, saved = module._engine.forward(P, x, lungs, module.training, True, module._dist,
-                                                    module.activation_recompute)
+                                                    module.activation_recompute, module._storage_now())
         ctx.saved_state = saved
         ctx.module = module
         return dense[0], dense[1], outs[0], outs[1]
@@ -154,6 +154,11 @@ class _ResNetSeg(nn.Module):
         # keeping them.  Same kernels on the same inputs: gradients are bit-identical, peak HBM drops, the step
         # gets ~7 % longer.  Default from the environment (DRAM_RECOMPUTE=1).
         self.activation_recompute = os.environ.get("DRAM_RECOMPUTE", "0") == "1"
+        # Storage type of the activations.  float32 = the reference's default arithmetic.  bfloat16 = what the
+        # reference runs under Lightning's `--precision bf16` (train.py:46 -> torch.autocast(bfloat16)): selected
+        # automatically inside an autocast(bfloat16) region, or explicitly (module.storage_dtype = torch.bfloat16 /
+        # DRAM_STORAGE=bf16).  Parameters, BatchNorm statistics, gradients and the returned tensors stay float32.
+        self.storage_dtype = torch.bfloat16 if os.environ.get("DRAM_STORAGE", "f32") == "bf16" else torch.float32
 
     def _make_layer(self, block, planes, blocks, stride=1, dilation=1):
         ds = stride != 1 or self.inplanes != planes * block.expansion  # med3d.py:244
@@ -165,6 +170,11 @@ class _ResNetSeg(nn.Module):
 
     def get_target_layer(self):
         return self.us3
+
+    def _storage_now(self):
+        if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+            return torch.bfloat16
+        return self.storage_dtype
 
     def _tensor_dict(self):
         d = dict(self.named_parameters())
@@ -189,7 +199,8 @@ class _ResNetSeg(nn.Module):
             d0, d1, o0, o1 = _Med3DFunction.apply(self, x, lungs, *params)
             return [d0, d1], [o0, o1]
         with torch.no_grad():
-            dense, outs, _ = self._engine.forward(self._tensor_dict(), x, lungs, self.training, False, self._dist)
+            dense, outs, _ = self._engine.forward(self._tensor_dict(), x, lungs, self.training, False, self._dist,
+                                                  storage=self._storage_now())
         return dense, outs
 
 

@@ -113,6 +113,39 @@ def _req(t: Tensor, name: str, dtype=torch.float32, shape=None):
     return t
 
 
+BF16 = torch.bfloat16
+
+
+def _act(t: Tensor, name: str, shape=None, like: Optional[Tensor] = None) -> str:
+    """Validate an ACTIVATION tensor (float32, or bfloat16 on the bf16-storage path) and return the entry-point
+    suffix of its storage type ("" | "_bf16").  `like`: another activation of the same call, whose type it must share."""
+    if not isinstance(t, Tensor) or t.dtype not in (torch.float32, BF16):
+        raise TypeError(f"{name}: expected a float32 or bfloat16 device tensor, got {getattr(t, 'dtype', type(t))}")
+    _req(t, name, t.dtype, shape)
+    if like is not None and like.dtype != t.dtype:
+        raise TypeError(f"{name}: {t.dtype} but the call's other activations are {like.dtype}")
+    return "_bf16" if t.dtype == BF16 else ""
+
+
+def _fn(name: str, sfx: str):
+    return getattr(_L(), name + sfx)
+
+
+def cast(t: Tensor, dtype) -> Tensor:
+    """float32 <-> bfloat16 copy of an activation tensor (round to nearest even) with the library's cast kernels."""
+    if t.dtype == dtype:
+        return t
+    _act(t, "t")
+    out = torch.empty(t.shape, device=t.device, dtype=dtype)
+    if dtype == BF16:
+        _chk(_L().dram_cast_f32_to_bf16(_p(t), _p(out), t.numel(), _stream()), "dram_cast_f32_to_bf16")
+    elif dtype == torch.float32:
+        _chk(_L().dram_cast_bf16_to_f32(_p(t), _p(out), t.numel(), _stream()), "dram_cast_bf16_to_f32")
+    else:
+        raise TypeError(f"cast: unsupported target {dtype}")
+    return out
+
+
 class KernelTimeline:
     """The library's own kernel timeline (dram_profile_*): every kernel launch bracketed by two
     hipEvents on its launch stream, tagged with family / executed MFMA FLOPs / direct-convolution FLOPs
@@ -303,7 +336,7 @@ class ConvPlan:
     dimensions, statistic rows, workspace sizes, cached-transform size -- ~12 host calls into the library
     (each of which re-derives tilings and reads the environment) instead of that many per launch."""
     __slots__ = ("desc", "dref", "algo", "walgo", "taps_f", "taps_b", "stat_rows", "ws_fwd", "ws_bwd", "ws_wgrad",
-                 "v_elems", "ws_direct_wgrad")
+                 "v_elems", "ws_direct_wgrad", "bf16", "bf16_stat_rows", "bf16_ws_wgrad")
 
     def __init__(self, g: "ConvGeom"):
         L = _L()
@@ -324,6 +357,11 @@ class ConvPlan:
                          2: lambda: int(L.dram_wgrad_w2d_workspace(d)),
                          1: lambda: int(L.dram_wino_workspace(d, 2))}.get(self.walgo, lambda: 0)()
         self.ws_direct_wgrad = int(L.dram_conv3d_bwd_weight_workspace(d)) if (self.walgo == 0 or self.ws_wgrad == 0) else 0
+        # bf16-storage path: the direct bf16-MFMA kernels take the 3x3x3 stride-1 convolutions; the rest (the one
+        # stride-2 convolution per network, 1x1x1) runs on the fp32 kernels above around cast passes
+        self.bf16 = bool(L.dram_conv_bf16_supported(d))
+        self.bf16_stat_rows = int(L.dram_conv_bf16_num_stat_rows(d)) if self.bf16 else 0
+        self.bf16_ws_wgrad = int(L.dram_conv3d_bwd_weight_bf16_workspace(d)) if self.bf16 else 0
 
 
 _PLANS: Dict[tuple, ConvPlan] = {}
@@ -355,13 +393,20 @@ def packed_taps(g: "ConvGeom", bwd: bool = False) -> int:
     return p.taps_b if bwd else p.taps_f
 
 
-def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True, g: Optional["ConvGeom"] = None
+def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True, g: Optional["ConvGeom"] = None, dtype=torch.float32
                      ) -> Tuple[Optional[Tensor], Optional[Tensor]]:
     """[Cout,Cin,k,k,k] -> wf [taps,Cout,Cin], wb [taps,Cin,Cout]; for a geometry the library plans
-    on the Winograd path the packed copies are the transformed weights (64 'taps', wb tap-flipped)."""
+    on the Winograd path the packed copies are the transformed weights (64 'taps', wb tap-flipped).
+    dtype=bfloat16 (bf16-storage path): bf16 copies for the geometries the bf16 kernels take, the fp32 packing
+    otherwise (the convolution then runs on the fp32 kernels around casts; the consumer looks at wf.dtype)."""
     _req(w, "w")
     Cout, Cin = w.shape[0], w.shape[1]
     taps = w.shape[2] * w.shape[3] * w.shape[4]
+    if dtype == BF16 and g is not None and conv_plan(g).bf16:
+        wf = torch.empty((taps, Cout, Cin), device=w.device, dtype=BF16) if want_fwd else None
+        wb = torch.empty((taps, Cin, Cout), device=w.device, dtype=BF16) if want_bwd else None
+        _chk(_L().dram_pack_conv_weight_bf16(_p(w), _p(wf), _p(wb), Cout, Cin, taps, _stream()), "dram_pack_conv_weight_bf16")
+        return wf, wb
     plan = conv_plan(g) if g is not None else None
     algo = plan.algo if plan else 0
     pt = plan.taps_f if plan else taps
@@ -396,18 +441,18 @@ def weights_changed():
     WEIGHT_EPOCH += 1
 
 
-def packed_forward_weight(w: Tensor, g: "ConvGeom") -> Tensor:
+def packed_forward_weight(w: Tensor, g: "ConvGeom", dtype=torch.float32) -> Tensor:
     slot = _PACKED.get(id(w))
     if slot is None or slot[0]() is not w:          # identity, never tensor ==
         wid = id(w)
         slot = _PACKED[wid] = (weakref.ref(w, lambda _r, wid=wid: _PACKED.pop(wid, None)), {})
     per = slot[1]
-    key = (g,) + tuple(os.environ.get(k) for k in _PLAN_ENV)
+    key = (g, dtype) + tuple(os.environ.get(k) for k in _PLAN_ENV)
     ent = per.get(key)
     st = w.untyped_storage()
     if ent is not None and ent[0].data_ptr() == st.data_ptr() and ent[1] == (w.data_ptr(), w._version, WEIGHT_EPOCH):
         return ent[2]
-    wf = pack_conv_weight(w, True, False, g)[0]
+    wf = pack_conv_weight(w, True, False, g, dtype)[0]
     per[key] = (st, (w.data_ptr(), w._version, WEIGHT_EPOCH), wf)
     return wf
 
@@ -420,8 +465,21 @@ def conv3d_fwd(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, want_
 def conv3d_fwd_keep(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, want_stats: bool, keep: bool):
     """Forward conv; with keep=True on the Winograd path also returns the transformed input V
     (reused by conv3d_bwd_weight instead of transforming x again), else None."""
-    _req(x, "x", shape=g.in_shape)
     plan = conv_plan(g)
+    if _act(x, "x", g.in_shape):                       # bf16 storage
+        if bias is not None:
+            _req(bias, "bias", shape=(g.Cout,))
+        if wf.dtype == BF16:
+            _req(wf, "wf", BF16, (g.taps, g.Cout, g.Cin))
+            y = torch.empty(g.out_shape, device=x.device, dtype=BF16)
+            stats = torch.empty((plan.bf16_stat_rows, 2, g.Cout), device=x.device, dtype=torch.float32) if want_stats else None
+            with _span("conv3_bf16_kernel", g.flops, f"fwd {g}"):
+                _chk(_L().dram_conv3d_fwd_bf16(_p(x), _p(wf), _p(bias), _p(y), _p(stats), plan.dref, _stream()),
+                     f"dram_conv3d_fwd_bf16{g}")
+            return y, stats, None
+        # geometry outside the bf16 kernels: fp32 kernels around casts (statistics of the fp32 result)
+        y32, stats, _ = conv3d_fwd_keep(cast(x, torch.float32), wf, bias, g, want_stats, False)
+        return cast(y32, BF16), stats, None
     algo, d = plan.algo, plan.dref
     _req(wf, "wf", shape=(plan.taps_f, g.Cout, g.Cin))
     if bias is not None:
@@ -460,8 +518,22 @@ def conv3d_fwd_keep(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, 
 
 def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] = None,
                     gate: Optional[Tensor] = None) -> Tensor:
-    _req(dy, "dy", shape=g.out_shape)
     plan = conv_plan(g)
+    if _act(dy, "dy", g.out_shape):                    # bf16 storage
+        if add is not None:
+            _act(add, "add", g.in_shape, like=dy)
+        if gate is not None:
+            _act(gate, "gate", g.in_shape, like=dy)
+        if wb.dtype == BF16:
+            _req(wb, "wb", BF16, (g.taps, g.Cin, g.Cout))
+            dx = torch.empty(g.in_shape, device=dy.device, dtype=BF16)
+            with _span("conv3_bf16_kernel", g.flops, f"dgrad {g}"):
+                _chk(_L().dram_conv3d_bwd_data_bf16(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), plan.dref, _stream()),
+                     f"dram_conv3d_bwd_data_bf16{g}")
+            return dx
+        f32 = torch.float32
+        return cast(conv3d_bwd_data(cast(dy, f32), wb, g, None if add is None else cast(add, f32),
+                                    None if gate is None else cast(gate, f32)), BF16)
     algo, d = plan.algo, plan.dref
     _req(wb, "wb", shape=(plan.taps_b, g.Cin, g.Cout))
     if add is not None:
@@ -494,13 +566,23 @@ def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] =
 
 def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] = None,
                       v_cache: Optional[Tensor] = None) -> Tensor:
-    _req(x, "x", shape=g.in_shape)
-    _req(dy, "dy", shape=g.out_shape)
     plan = conv_plan(g)
     d, walgo = plan.dref, plan.walgo
     shape = (g.Cout, g.Cin, g.k, g.k, g.k)
     dw = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
     _req(dw, "dw", shape=shape)
+    if _act(x, "x", g.in_shape):                       # bf16 storage: the gradient itself is fp32
+        _act(dy, "dy", g.out_shape, like=x)
+        if plan.bf16:
+            nbytes = plan.bf16_ws_wgrad
+            ws = _workspace(nbytes, x.device)
+            with _span("wgrad3_bf16_kernel+reduce", g.flops, f"wgrad {g}"):
+                _chk(_L().dram_conv3d_bwd_weight_bf16(_p(x), _p(dy), _p(dw), d, _p(ws), nbytes, _stream()),
+                     f"dram_conv3d_bwd_weight_bf16{g}")
+            return dw
+        return conv3d_bwd_weight(cast(x, torch.float32), cast(dy, torch.float32), g, out=dw)
+    _req(x, "x", shape=g.in_shape)
+    _req(dy, "dy", shape=g.out_shape)
     if walgo == 3:
         nbytes = plan.ws_wgrad
         ws = _workspace(max(nbytes, 4), x.device)
@@ -540,34 +622,37 @@ def stem_out(n: int) -> int:
     return (n + 6 - 7) // 2 + 1
 
 
-def stem_fwd(x: Tensor, w: Tensor, want_stats: bool):
-    """x [B,D,H,W] (C=1), w [64,1,7,7,7] -> y [B,Do,Ho,Wo,64]."""
+def stem_fwd(x: Tensor, w: Tensor, want_stats: bool, out_dtype=torch.float32):
+    """x [B,D,H,W] (C=1), w [64,1,7,7,7] -> y [B,Do,Ho,Wo,64] (fp32 arithmetic; y stored as out_dtype)."""
     _req(x, "x")
     if x.dim() != 4:
         raise ValueError("stem_fwd: x must be [B,D,H,W]")
     _req(w, "w", shape=(64, 1, 7, 7, 7))
     B, D, H, W = x.shape
     Do, Ho, Wo = stem_out(D), stem_out(H), stem_out(W)
-    y = torch.empty((B, Do, Ho, Wo, 64), device=x.device, dtype=torch.float32)
+    if out_dtype not in (torch.float32, BF16):
+        raise TypeError(f"stem_fwd: unsupported storage type {out_dtype}")
+    y = torch.empty((B, Do, Ho, Wo, 64), device=x.device, dtype=out_dtype)
     stats = None
     if want_stats:
         nt = _L().dram_stem_num_tiles(B, Do, Ho, Wo)
         stats = torch.empty((nt, 2, 64), device=x.device, dtype=torch.float32)
     with _span("stem_fwd_kernel", 2.0 * B * Do * Ho * Wo * 64 * 343):
-        _chk(_L().dram_stem_fwd(_p(x), _p(w), _p(y), _p(stats), B, D, H, W, _stream()), "dram_stem_fwd")
+        _chk(_fn("dram_stem_fwd", "_bf16" if out_dtype == BF16 else "")(_p(x), _p(w), _p(y), _p(stats), B, D, H, W, _stream()),
+             "dram_stem_fwd")
     return y, stats
 
 
 def stem_bwd_weight(x: Tensor, dy: Tensor, out: Optional[Tensor] = None) -> Tensor:
     _req(x, "x")
     B, D, H, W = x.shape
-    _req(dy, "dy", shape=(B, stem_out(D), stem_out(H), stem_out(W), 64))
+    sfx = _act(dy, "dy", (B, stem_out(D), stem_out(H), stem_out(W), 64))
     nbytes = _L().dram_stem_bwd_weight_workspace(B, D, H, W)
     ws = torch.empty(((nbytes + 3) // 4,), device=x.device, dtype=torch.float32)
     dw = out if out is not None else torch.empty((64, 1, 7, 7, 7), device=x.device, dtype=torch.float32)
     _req(dw, "dw", shape=(64, 1, 7, 7, 7))
     with _span("stem_wgrad_kernel+reduce", 2.0 * dy.numel() * 343):
-        _chk(_L().dram_stem_bwd_weight(_p(x), _p(dy), _p(dw), B, D, H, W, _p(ws), nbytes, _stream()),
+        _chk(_fn("dram_stem_bwd_weight", sfx)(_p(x), _p(dy), _p(dw), B, D, H, W, _p(ws), nbytes, _stream()),
              "dram_stem_bwd_weight")
     return dw
 
@@ -614,13 +699,13 @@ def bn_finalize(sums: Optional[Tensor], count: float, gamma: Tensor, beta: Tenso
 
 
 def bn_apply(y: Tensor, scale: Tensor, shift: Tensor, residual: Optional[Tensor], rs: int, relu: bool) -> Tensor:
-    _req(y, "y")
+    sfx = _act(y, "y")
     B, D, H, W, C = y.shape
     _req(scale, "scale", shape=(C,))
     _req(shift, "shift", shape=(C,))
     Dr = Hr = Wr = Cr = 0
     if residual is not None:
-        _req(residual, "residual")
+        _act(residual, "residual", like=y)
         if residual.shape[0] != B:
             raise ValueError("bn_apply: residual batch mismatch")
         _, Dr, Hr, Wr, Cr = residual.shape
@@ -630,8 +715,8 @@ def bn_apply(y: Tensor, scale: Tensor, shift: Tensor, residual: Optional[Tensor]
         if ((Dr - 1) // rs + 1, (Hr - 1) // rs + 1, (Wr - 1) // rs + 1) != (D, H, W):
             raise ValueError("bn_apply: strided residual does not match the output grid")
     z = torch.empty_like(y)
-    _chk(_L().dram_bn_apply(_p(y), _p(scale), _p(shift), _p(residual), Dr, Hr, Wr, Cr, rs, _p(z), B, D, H, W, C,
-                            int(relu), _stream()), "dram_bn_apply")
+    _chk(_fn("dram_bn_apply", sfx)(_p(y), _p(scale), _p(shift), _p(residual), Dr, Hr, Wr, Cr, rs, _p(z), B, D, H, W, C,
+                                   int(relu), _stream()), "dram_bn_apply")
     return z
 
 
@@ -644,7 +729,7 @@ def _mask_args(z, y, scale, shift, relu):
     re-derive it from y."""
     C = y.shape[-1]
     if relu and z is not None:
-        _req(z, "z", shape=y.shape)
+        _act(z, "z", y.shape, like=y)
     elif relu:
         if scale is None or shift is None:
             raise ValueError("BN backward with ReLU needs z, or scale and shift")
@@ -654,8 +739,8 @@ def _mask_args(z, y, scale, shift, relu):
 
 def bn_bwd_reduce(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, invstd: Tensor, relu: bool,
                   scale: Optional[Tensor] = None, shift: Optional[Tensor] = None) -> Tensor:
-    _req(dz, "dz", shape=y.shape)
-    _req(y, "y")
+    sfx = _act(y, "y")
+    _act(dz, "dz", y.shape, like=y)
     _mask_args(z, y, scale, shift, relu)
     C = y.shape[-1]
     _req(mean, "mean", shape=(C,))
@@ -663,8 +748,8 @@ def bn_bwd_reduce(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, invs
     rows = _rows(y)
     nparts = _L().dram_colsum_nparts(rows, C)
     partial = torch.empty((nparts, 2, C), device=y.device, dtype=torch.float32)
-    _chk(_L().dram_bn_bwd_reduce(_p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(scale), _p(shift), _p(partial), rows, C,
-                                 int(relu), _stream()), "dram_bn_bwd_reduce")
+    _chk(_fn("dram_bn_bwd_reduce", sfx)(_p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(scale), _p(shift), _p(partial), rows, C,
+                                        int(relu), _stream()), "dram_bn_bwd_reduce")
     return partial
 
 
@@ -675,7 +760,8 @@ def bn_bwd_apply(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, invst
     C = y.shape[-1]
     if count_dev is not None:
         _req(count_dev, "count_dev", dtype=torch.float64, shape=(1,))
-    _req(dz, "dz", shape=y.shape)
+    sfx = _act(y, "y")
+    _act(dz, "dz", y.shape, like=y)
     _mask_args(z, y, scale, shift, relu)
     colpart = None
     if want_colsum:
@@ -685,20 +771,20 @@ def bn_bwd_apply(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, invst
     _req(sums, "sums", dtype=torch.float64, shape=(2, C))
     _req(gamma, "gamma", shape=(C,))
     dy = torch.empty_like(y)
-    _chk(_L().dram_bn_bwd_apply(_p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(scale), _p(shift), _p(sums),
-                                float(count), _p(count_dev), _p(dy), _p(colpart), _rows(y), C, int(relu), _stream()),
+    _chk(_fn("dram_bn_bwd_apply", sfx)(_p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(scale), _p(shift), _p(sums),
+                                       float(count), _p(count_dev), _p(dy), _p(colpart), _rows(y), C, int(relu), _stream()),
          "dram_bn_bwd_apply")
     return (dy, colpart) if want_colsum else dy
 
 
 def colsum(a: Tensor) -> Tensor:
     """[..., C] -> partial [P,1,C]."""
-    _req(a, "a")
+    sfx = _act(a, "a")
     C = a.shape[-1]
     rows = _rows(a)
     nparts = _L().dram_colsum_nparts(rows, C)
     partial = torch.empty((nparts, 1, C), device=a.device, dtype=torch.float32)
-    _chk(_L().dram_colsum(_p(a), _p(partial), rows, C, _stream()), "dram_colsum")
+    _chk(_fn("dram_colsum", sfx)(_p(a), _p(partial), rows, C, _stream()), "dram_colsum")
     return partial
 
 
@@ -716,45 +802,45 @@ def pool_out(n: int) -> int:
 
 
 def maxpool_fwd(x: Tensor):
-    _req(x, "x")
+    sfx = _act(x, "x")
     B, D, H, W, C = x.shape
     shape = (B, pool_out(D), pool_out(H), pool_out(W), C)
-    y = torch.empty(shape, device=x.device, dtype=torch.float32)
+    y = torch.empty(shape, device=x.device, dtype=x.dtype)
     am = torch.empty(shape, device=x.device, dtype=torch.uint8)
-    _chk(_L().dram_maxpool_fwd(_p(x), _p(y), _p(am), B, D, H, W, C, _stream()), "dram_maxpool_fwd")
+    _chk(_fn("dram_maxpool_fwd", sfx)(_p(x), _p(y), _p(am), B, D, H, W, C, _stream()), "dram_maxpool_fwd")
     return y, am
 
 
 def maxpool_bwd(dy: Tensor, argmax: Tensor, in_shape, add_: Optional[Tensor] = None) -> Tensor:
     B, D, H, W, C = in_shape
     oshape = (B, pool_out(D), pool_out(H), pool_out(W), C)
-    _req(dy, "dy", shape=oshape)
+    sfx = _act(dy, "dy", oshape)
     _req(argmax, "argmax", dtype=torch.uint8, shape=oshape)
     add_stride = C
     if add_ is not None:
         # a dense tensor shaped like dx, or a channel slice [..., c0:c0+C] of a dense wider tensor (read in place)
-        if (not add_.is_cuda or add_.dtype != torch.float32 or tuple(add_.shape) != tuple(in_shape)
+        if (not add_.is_cuda or add_.dtype != dy.dtype or tuple(add_.shape) != tuple(in_shape)
                 or add_.stride(-1) != 1):
-            raise ValueError("maxpool_bwd: add must be an fp32 device tensor shaped like the pooled input")
+            raise ValueError("maxpool_bwd: add must be a device tensor of dy's type shaped like the pooled input")
         add_stride = add_.stride(3)
         want = (D * H * W * add_stride, H * W * add_stride, W * add_stride, add_stride, 1)
-        if tuple(add_.stride()) != want or add_stride % 4 or add_.data_ptr() % 16:
-            raise ValueError("maxpool_bwd: add must be dense or a 16-byte aligned channel slice of a dense tensor")
-    dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
-    _chk(_L().dram_maxpool_bwd(_p(dy), _p(argmax), _p(add_), add_stride, _p(dx),
-                               B, D, H, W, C, _stream()), "dram_maxpool_bwd")
+        if tuple(add_.stride()) != want or add_stride % 4 or add_.data_ptr() % (4 * add_.element_size()):
+            raise ValueError("maxpool_bwd: add must be dense or an aligned channel slice of a dense tensor")
+    dx = torch.empty(in_shape, device=dy.device, dtype=dy.dtype)
+    _chk(_fn("dram_maxpool_bwd", sfx)(_p(dy), _p(argmax), _p(add_), add_stride, _p(dx),
+                                      B, D, H, W, C, _stream()), "dram_maxpool_bwd")
     return dx
 
 
 def upcat_fwd(src: Tensor, skip: Tensor) -> Tensor:
-    _req(src, "src")
-    _req(skip, "skip")
+    sfx = _act(src, "src")
+    _act(skip, "skip", like=src)
     B, Ds, Hs, Ws, Cu = src.shape
     Bk, Dk, Hk, Wk, Ck = skip.shape
     if Bk != B or Dk < 2 * Ds or Hk < 2 * Hs or Wk < 2 * Ws:
         raise ValueError(f"upcat_fwd: skip {tuple(skip.shape)} smaller than upsampled {tuple(src.shape)}")
-    cat = torch.empty((B, 2 * Ds, 2 * Hs, 2 * Ws, Cu + Ck), device=src.device, dtype=torch.float32)
-    _chk(_L().dram_upcat_fwd(_p(src), _p(skip), _p(cat), B, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck, _stream()),
+    cat = torch.empty((B, 2 * Ds, 2 * Hs, 2 * Ws, Cu + Ck), device=src.device, dtype=src.dtype)
+    _chk(_fn("dram_upcat_fwd", sfx)(_p(src), _p(skip), _p(cat), B, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck, _stream()),
          "dram_upcat_fwd")
     return cat
 
@@ -762,10 +848,10 @@ def upcat_fwd(src: Tensor, skip: Tensor) -> Tensor:
 def upcat_bwd(dcat: Tensor, src_shape, skip_shape, need_src=True, need_skip=True):
     B, Ds, Hs, Ws, Cu = src_shape
     _, Dk, Hk, Wk, Ck = skip_shape
-    _req(dcat, "dcat", shape=(B, 2 * Ds, 2 * Hs, 2 * Ws, Cu + Ck))
-    dsrc = torch.empty(src_shape, device=dcat.device, dtype=torch.float32) if need_src else None
-    dskip = torch.empty(skip_shape, device=dcat.device, dtype=torch.float32) if need_skip else None
-    _chk(_L().dram_upcat_bwd(_p(dcat), _p(dsrc), _p(dskip), B, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck, _stream()),
+    sfx = _act(dcat, "dcat", (B, 2 * Ds, 2 * Hs, 2 * Ws, Cu + Ck))
+    dsrc = torch.empty(src_shape, device=dcat.device, dtype=dcat.dtype) if need_src else None
+    dskip = torch.empty(skip_shape, device=dcat.device, dtype=dcat.dtype) if need_skip else None
+    _chk(_fn("dram_upcat_bwd", sfx)(_p(dcat), _p(dsrc), _p(dskip), B, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck, _stream()),
          "dram_upcat_bwd")
     return dsrc, dskip
 
@@ -786,8 +872,9 @@ def upproject(dense: Tensor, ess: Tensor, size):
 
 # --------------------------------------------------------------------------- heads / losses
 def head_fwd(x: Tensor, w: Tensor, bias: Tensor, lungs: Optional[Tensor], sigmoid: bool):
-    """x [B,D,H,W,32]; w [NO,32]; lungs None or [B,Dl,Hl,Wl] full-res mask."""
-    _req(x, "x")
+    """x [B,D,H,W,32] (float32 or bfloat16); w [NO,32]; lungs None or [B,Dl,Hl,Wl] full-res mask.  The dense maps
+    and the pooling partial sums are float32 on both storage paths."""
+    sfx = _act(x, "x")
     B, D, H, W, C = x.shape
     if C != 32:
         raise ValueError("head_fwd: the head consumes the 32-channel us3 output")
@@ -803,14 +890,14 @@ def head_fwd(x: Tensor, w: Tensor, bias: Tensor, lungs: Optional[Tensor], sigmoi
     nblk = _L().dram_head_nblk(D * H * W)
     dense = torch.empty((B, NO, D, H, W), device=x.device, dtype=torch.float32)
     partial = torch.empty((B, nblk, NO + 1), device=x.device, dtype=torch.float32)
-    _chk(_L().dram_head_fwd(_p(x), _p(w), _p(bias), _p(lungs), Dl, Hl, Wl, _p(dense), _p(partial), B, D, H, W, NO,
-                            int(sigmoid), _stream()), "dram_head_fwd")
+    _chk(_fn("dram_head_fwd", sfx)(_p(x), _p(w), _p(bias), _p(lungs), Dl, Hl, Wl, _p(dense), _p(partial), B, D, H, W, NO,
+                                   int(sigmoid), _stream()), "dram_head_fwd")
     return dense, partial
 
 
 def head_bwd(x: Tensor, w: Tensor, dense: Optional[Tensor], gdense: Optional[Tensor], gpool: Tensor,
              lungs: Optional[Tensor], sigmoid: bool):
-    _req(x, "x")
+    sfx = _act(x, "x")
     B, D, H, W, C = x.shape
     NO = w.shape[0]
     _req(w, "w", shape=(NO, 32))
@@ -826,8 +913,8 @@ def head_bwd(x: Tensor, w: Tensor, dense: Optional[Tensor], gdense: Optional[Ten
     nparts = _L().dram_head_bwd_nparts(D * H * W)
     dx = torch.empty_like(x)
     wpartial = torch.empty((B * nparts, NO, 33), device=x.device, dtype=torch.float32)
-    _chk(_L().dram_head_bwd(_p(x), _p(w), _p(dense), _p(gdense), _p(gpool), _p(lungs), Dl, Hl, Wl, _p(dx),
-                            _p(wpartial), B, D, H, W, NO, int(sigmoid), _stream()), "dram_head_bwd")
+    _chk(_fn("dram_head_bwd", sfx)(_p(x), _p(w), _p(dense), _p(gdense), _p(gpool), _p(lungs), Dl, Hl, Wl, _p(dx),
+                                   _p(wpartial), B, D, H, W, NO, int(sigmoid), _stream()), "dram_head_bwd")
     return dx, wpartial
 
 

@@ -35,7 +35,7 @@ typedef void* dram_stream_t; /* hipStream_t */
 #define DRAM_ERR_UNSUPPORTED (-2)
 #define DRAM_ERR_WORKSPACE (-3)
 
-#define DRAM_ABI_VERSION 2
+#define DRAM_ABI_VERSION 3
 int dram_version(void);
 /* static string: "gfx950" build tag */
 const char* dram_build_info(void);
@@ -73,6 +73,8 @@ enum {
   DRAM_FAM_HEAD_LOSS,       /* heads, dRAM losses                                 (hbm)  */
   DRAM_FAM_OPTIM,           /* fused Adam / SGD                                   (hbm)  */
   DRAM_FAM_PREP,            /* input transforms                                   (hbm)  */
+  DRAM_FAM_CONV_BF16,       /* bf16-storage direct conv, fwd + dgrad (bf16 MFMA)  (mfma) */
+  DRAM_FAM_WGRAD_BF16,      /* bf16-storage weight gradient (+ reduce)            (mfma) */
   DRAM_FAM_COUNT
 };
 typedef struct DramProfRecord {
@@ -441,6 +443,63 @@ int dram_augment_mask(const float* mask, float* out, int D, int H, int W, const 
 
 /* out[i] = a[i] + b[i]  (gradient accumulation where two consumers meet) */
 int dram_add(const float* a, const float* b, float* out, long long n, dram_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* bf16 STORAGE path -- the reference's `--precision bf16` (train.py:46: Lightning wraps the step in
+ * torch.autocast(bfloat16); BASELINE configs[2], [4]).  Activation-sized tensors (x, y, z, dy, dx, residuals,
+ * concat buffers) are bf16 NDHWC (`void*`, 2 bytes per element, same offsets); everything else keeps the types of
+ * the fp32 entry points: BatchNorm statistics / scale / shift, biases, the dense head outputs and every weight
+ * GRADIENT are fp32, statistic folds are double.  Arithmetic: products of bf16 operands accumulated in fp32
+ * (v_mfma_f32_32x32x16_bf16), element-wise math in fp32, one rounding (to nearest even) on store.
+ * The *_bf16 element-wise entry points take exactly the arguments of their fp32 namesakes. */
+int dram_cast_f32_to_bf16(const float* src, void* dst, long long n, dram_stream_t stream);
+int dram_cast_bf16_to_f32(const void* src, float* dst, long long n, dram_stream_t stream);
+/* 1 when the bf16 direct kernels take this geometry: 3x3x3, stride 1, pad == dilation, Cin % 32 == Cout % 32 == 0
+ * (everything else is run by the host on the fp32 kernels around cast passes) */
+int dram_conv_bf16_supported(const DramConvDesc* d);
+int dram_conv_bf16_num_stat_rows(const DramConvDesc* d);
+/* w [Cout][Cin][k^3] fp32 -> wf [taps][Cout][Cin] bf16 (forward operand), wb [taps][Cin][Cout] bf16 with the taps
+ * flipped (data-gradient operand); either may be NULL */
+int dram_pack_conv_weight_bf16(const float* w, void* wf, void* wb, int Cout, int Cin, int taps, dram_stream_t stream);
+/* nn.Conv3d forward (med3d.py:11,121,123,...) / its data gradient / its weight gradient on bf16 tensors.
+ * stats_partial [dram_conv_bf16_num_stat_rows][2][Cout] fp32: per-tile sums of y and y^2 (of the ROUNDED values the
+ * BatchNorm pass reads back), or NULL.  bwd_data: dx = conv_transpose(dy) (+ add * (gate > 0), both bf16, optional). */
+int dram_conv3d_fwd_bf16(const void* x, const void* wf, const float* bias, void* y, float* stats_partial,
+                         const DramConvDesc* d, dram_stream_t stream);
+int dram_conv3d_bwd_data_bf16(const void* dy, const void* wb, void* dx, const void* add, const void* gate,
+                              const DramConvDesc* d, dram_stream_t stream);
+size_t dram_conv3d_bwd_weight_bf16_workspace(const DramConvDesc* d);
+int dram_conv3d_bwd_weight_bf16(const void* x, const void* dy, float* dw, const DramConvDesc* d, void* workspace,
+                                size_t workspace_bytes, dram_stream_t stream);
+int dram_stem_fwd_bf16(const float* x, const float* w, void* y, float* stats_partial, int B, int D, int H, int W,
+                       dram_stream_t stream);
+int dram_stem_bwd_weight_bf16(const float* x, const void* dy, float* dw, int B, int D, int H, int W, void* workspace,
+                              size_t workspace_bytes, dram_stream_t stream);
+int dram_bn_apply_bf16(const void* y, const float* scale, const float* shift, const void* residual, int Dr, int Hr,
+                       int Wr, int Cr, int rs, void* z, int B, int D, int H, int W, int C, int relu,
+                       dram_stream_t stream);
+int dram_bn_bwd_reduce_bf16(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
+                            const float* scale, const float* shift, float* partial, long long rows, int C, int relu,
+                            dram_stream_t stream);
+int dram_bn_bwd_apply_bf16(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
+                           const float* gamma, const float* scale, const float* shift, const double* sums, double count,
+                           const double* count_dev, void* dy, float* colsum_partial, long long rows, int C, int relu,
+                           dram_stream_t stream);
+int dram_colsum_bf16(const void* a, float* partial, long long rows, int C, dram_stream_t stream);
+int dram_maxpool_fwd_bf16(const void* x, void* y, uint8_t* argmax, int B, int D, int H, int W, int C,
+                          dram_stream_t stream);
+int dram_maxpool_bwd_bf16(const void* dy, const uint8_t* argmax, const void* add, int add_stride, void* dx, int B, int D,
+                          int H, int W, int C, dram_stream_t stream);
+int dram_upcat_fwd_bf16(const void* src, const void* skip, void* cat, int B, int Ds, int Hs, int Ws, int Cu, int Dk,
+                        int Hk, int Wk, int Ck, dram_stream_t stream);
+int dram_upcat_bwd_bf16(const void* dcat, void* dsrc, void* dskip, int B, int Ds, int Hs, int Ws, int Cu, int Dk, int Hk,
+                        int Wk, int Ck, dram_stream_t stream);
+int dram_head_fwd_bf16(const void* x, const float* w, const float* bias, const float* lungs, int Dl, int Hl, int Wl,
+                       float* dense, float* partial, int B, int D, int H, int W, int NO, int sigmoid,
+                       dram_stream_t stream);
+int dram_head_bwd_bf16(const void* x, const float* w, const float* dense, const float* gdense, const float* gpool,
+                       const float* lungs, int Dl, int Hl, int Wl, void* dx, float* wpartial, int B, int D, int H, int W,
+                       int NO, int sigmoid, dram_stream_t stream);
 
 #ifdef __cplusplus
 }

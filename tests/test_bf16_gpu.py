@@ -1,0 +1,301 @@
+"""GPU: the bf16-STORAGE path (reference: Lightning `--precision bf16`, train.py:46 -> torch.autocast(bfloat16);
+BASELINE configs[2] / [4]) through the C ABI.
+
+Contract of the path (include/dram_hip.h, "bf16 STORAGE path"): activation tensors are bf16 in HBM, every product
+is a product of bf16 operands accumulated in fp32, element-wise math is fp32, ONE rounding (nearest even) per store;
+statistics, parameters, weight gradients and the dense head outputs are fp32.
+
+Tolerances, stated up front (SURVEY.md section 7 prescribes stating them; bf16 has 8 significant bits, 2^-9 = 2e-3
+per rounding):
+  * convolution kernels vs the fp64 convolution of the SAME bf16 operands: output relative L2 <= 2e-3 (its one output
+    rounding: 2^-9 / sqrt(3) = 1.1e-3 expected); weight gradient (fp32 result) <= 2e-5.
+  * element-wise kernels: BIT-IDENTICAL to the fp32 kernel of the same op run on the up-cast operands and rounded
+    once -- same arithmetic, same order, only the storage type differs.
+  * whole network vs the fp32 oracle: pooled scores / logits max-relative <= 3e-3, dense maps relative L2 <= 2e-2,
+    loss <= 3e-3; gradients vs the fp64 oracle pinned to the bf16 forward's own ReLU / max-pool decisions relative
+    L2 <= 5e-2 per tensor.  For scale, the reference's own arithmetic under CPU autocast(bfloat16) sits 1.0-1.4e-3
+    (pooled), 2e-2 (dense) and 10-33 % (gradients, decisions free) from its fp32 self on the same fixtures
+    (measured with the oracle, tools/bf16_reference_distance.py); the HIP path must be no further from fp32 than
+    that on the forward quantities.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+from oracle import med3d_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from bodyct_dram_emph_subtype_amd import ops as o
+    import bodyct_dram_emph_subtype_amd as pkg
+    pkg.load_library()
+    return o
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def r16(t):
+    """values representable in bf16, kept as float32"""
+    return t.to(BF).float()
+
+
+def nd(t):   # NCDHW cpu fp32 (bf16-representable) -> NDHWC gpu bf16
+    return t.permute(0, 2, 3, 4, 1).contiguous().to(DEV).to(BF)
+
+
+def nc(t):   # NDHWC gpu -> NCDHW cpu fp32
+    return t.float().permute(0, 4, 1, 2, 3).contiguous().cpu()
+
+
+CASES = [
+    # B, D, H, W, Cin, Cout, dil
+    (1, 8, 8, 8, 64, 64, 1),
+    (2, 7, 10, 9, 64, 128, 1),          # ragged extents
+    (1, 9, 12, 10, 128, 64, 2),         # dilation lattice, ragged residues
+    (1, 8, 16, 16, 256, 256, 4),        # layer3/4-like
+    (1, 6, 9, 11, 64, 32, 1),           # us3: 32 output columns (NB = 1); its data gradient has ONE 32-channel chunk
+    (1, 4, 8, 8, 576, 64, 1),           # us1.0: 18 chunks
+    (2, 4, 5, 6, 32, 96, 1),            # channel counts that are only multiples of 32
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=str)
+def test_conv3_bf16_fwd_dgrad_wgrad(ops, case):
+    B, D, H, W, Cin, Cout, dil = case
+    x = r16(rnd(B, Cin, D, H, W, seed=1)).requires_grad_(True)
+    w32 = rnd(Cout, Cin, 3, 3, 3, seed=2) * 0.1
+    w = r16(w32).requires_grad_(True)
+    bias = rnd(Cout, seed=3)
+    y_ref = F.conv3d(x.double(), w.double(), bias.double(), 1, dil, dil)
+    gy = r16(rnd(*y_ref.shape, seed=4))
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, [x, w], gy.double())
+    g = ops.ConvGeom(B, D, H, W, Cin, Cout, 3, 1, dil, dil)
+    assert ops.conv_plan(g).bf16
+    wf, wb = ops.pack_conv_weight(w32.to(DEV), True, True, g, BF)
+    assert wf.dtype == BF and tuple(wf.shape) == (27, Cout, Cin) and tuple(wb.shape) == (27, Cin, Cout)
+    assert torch.equal(wf.float().cpu(), w.detach().permute(2, 3, 4, 0, 1).reshape(27, Cout, Cin))     # RNE packing
+    y, stats, _ = ops.conv3d_fwd_keep(nd(x.detach()), wf, bias.to(DEV), g, True, False)
+    assert y.dtype == BF
+    assert rel_l2(nc(y), y_ref.detach()) < 2e-3
+    # the BatchNorm sums are those of the values the next pass reads: the rounded outputs
+    s = ops.reduce_partials(stats).cpu()
+    yr = nc(y).double()
+    assert torch.allclose(s[0], yr.sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[1], (yr * yr).sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    dx = ops.conv3d_bwd_data(nd(gy), wb, g)
+    assert dx.dtype == BF and rel_l2(nc(dx), gx_ref) < 2e-3
+    add = r16(rnd(B, Cin, D, H, W, seed=5))
+    gate = r16(rnd(B, Cin, D, H, W, seed=6))
+    dx2 = ops.conv3d_bwd_data(nd(gy), wb, g, nd(add), nd(gate))
+    assert rel_l2(nc(dx2), gx_ref + (add * (gate > 0).float()).double()) < 2e-3
+    dw = ops.conv3d_bwd_weight(nd(x.detach()), nd(gy), g)
+    assert dw.dtype == torch.float32 and rel_l2(dw.cpu(), gw_ref) < 2e-5
+    # deterministic (fixed-order slab reduce, no atomics)
+    assert torch.equal(dw, ops.conv3d_bwd_weight(nd(x.detach()), nd(gy), g))
+
+
+@pytest.mark.parametrize("case", [(1, 8, 12, 10, 64, 128, 3, 2, 1), (2, 4, 6, 5, 128, 64, 1, 1, 1)], ids=str)
+def test_conv_bf16_fallback_geometries(ops, case):
+    """stride 2 and 1x1x1: outside the bf16 kernels -> fp32 kernels around cast passes, bf16 in / bf16 out."""
+    B, D, H, W, Cin, Cout, k, stride, dil = case
+    pad = dil * (k - 1) // 2
+    x = r16(rnd(B, Cin, D, H, W, seed=1)).requires_grad_(True)
+    w = (rnd(Cout, Cin, k, k, k, seed=2) * 0.1).requires_grad_(True)
+    y_ref = F.conv3d(x, w, None, stride, pad, dil)
+    gy = r16(rnd(*y_ref.shape, seed=4))
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, [x, w], gy)
+    g = ops.ConvGeom(B, D, H, W, Cin, Cout, k, stride, pad, dil)
+    assert not ops.conv_plan(g).bf16
+    wf, wb = ops.pack_conv_weight(w.detach().to(DEV), True, True, g, BF)
+    assert wf.dtype == torch.float32
+    y, stats, _ = ops.conv3d_fwd_keep(nd(x.detach()), wf, None, g, True, False)
+    assert y.dtype == BF and rel_l2(nc(y), y_ref.detach()) < 2e-3 and stats is not None
+    dx = ops.conv3d_bwd_data(nd(gy), wb, g)
+    assert dx.dtype == BF and rel_l2(nc(dx), gx_ref) < 2e-3
+    dw = ops.conv3d_bwd_weight(nd(x.detach()), nd(gy), g)
+    assert rel_l2(dw.cpu(), gw_ref) < 2e-5
+
+
+def test_elementwise_bf16_kernels_equal_fp32_kernels_on_upcast_operands(ops):
+    """Every element-wise kernel of the bf16 path is the SAME template as its fp32 form with a different storage
+    type: run on bf16 tensors it must give, bit for bit, the fp32 kernel's result on the up-cast tensors rounded
+    once to bf16 (fp32 outputs -- partial sums, dense maps -- must be bit-identical outright)."""
+    B, D, H, W, C = 2, 6, 8, 10, 64
+    y = rnd(B, D, H, W, C, seed=1).to(DEV).to(BF)
+    res = rnd(B, D, H, W, C, seed=2).to(DEV).to(BF)
+    dz = rnd(B, D, H, W, C, seed=3).to(DEV).to(BF)
+    scale, shift = (rnd(C, seed=4).abs() + 0.5).to(DEV), rnd(C, seed=5).to(DEV)
+    mean, invstd, gamma = rnd(C, seed=6).to(DEV), (rnd(C, seed=7).abs() + 0.5).to(DEV), rnd(C, seed=8).to(DEV)
+    f = lambda t: t.float()
+    # BN apply: plain, identity residual, shortcut A (stride 2, 32 of 64 channels)
+    assert torch.equal(ops.bn_apply(y, scale, shift, None, 1, True), ops.bn_apply(f(y), scale, shift, None, 1, True).to(BF))
+    assert torch.equal(ops.bn_apply(y, scale, shift, res, 1, True), ops.bn_apply(f(y), scale, shift, f(res), 1, True).to(BF))
+    big = rnd(B, 2 * D, 2 * H, 2 * W, 32, seed=9).to(DEV).to(BF)
+    assert torch.equal(ops.bn_apply(y, scale, shift, big, 2, True), ops.bn_apply(f(y), scale, shift, f(big), 2, True).to(BF))
+    # BN backward: reduce (fp32 partials), apply (+ column sums)
+    z = ops.bn_apply(y, scale, shift, res, 1, True)
+    for zz, sc, sh in ((z, None, None), (None, scale, shift)):
+        p16 = ops.bn_bwd_reduce(dz, zz, y, mean, invstd, True, sc, sh)
+        p32 = ops.bn_bwd_reduce(f(dz), None if zz is None else f(zz), f(y), mean, invstd, True, sc, sh)
+        assert torch.equal(p16, p32)
+        sums = ops.reduce_partials(p16)
+        d16, c16 = ops.bn_bwd_apply(dz, zz, y, mean, invstd, gamma, sums, float(B * D * H * W), True, sc, sh, want_colsum=True)
+        d32, c32 = ops.bn_bwd_apply(f(dz), None if zz is None else f(zz), f(y), mean, invstd, gamma, sums, float(B * D * H * W),
+                                    True, sc, sh, want_colsum=True)
+        assert torch.equal(d16, d32.to(BF)) and torch.equal(c16, c32)
+    assert torch.equal(ops.colsum(dz), ops.colsum(f(dz)))
+    # max pool forward / backward (+ skip-gradient add)
+    p16, a16 = ops.maxpool_fwd(y)
+    p32, a32 = ops.maxpool_fwd(f(y))
+    assert torch.equal(p16, p32.to(BF)) and torch.equal(a16, a32)
+    gp = rnd(*p16.shape, seed=10).to(DEV).to(BF)
+    assert torch.equal(ops.maxpool_bwd(gp, a16, tuple(y.shape), res), ops.maxpool_bwd(f(gp), a32, tuple(y.shape), f(res)).to(BF))
+    # upsample + concat forward (tiled and untiled forms) / backward
+    for sshape, kshape in (((1, 3, 4, 5, 64), (1, 7, 9, 10, 32)), ((1, 32, 32, 32, 64), (1, 64, 64, 64, 64))):
+        src, skip = rnd(*sshape, seed=11).to(DEV).to(BF), rnd(*kshape, seed=12).to(DEV).to(BF)
+        c16 = ops.upcat_fwd(src, skip)
+        assert torch.equal(c16, ops.upcat_fwd(f(src), f(skip)).to(BF))
+        gc = rnd(*c16.shape, seed=13).to(DEV).to(BF)
+        s16, k16 = ops.upcat_bwd(gc, sshape, kshape)
+        s32, k32 = ops.upcat_bwd(f(gc), sshape, kshape)
+        assert torch.equal(s16, s32.to(BF)) and torch.equal(k16, k32.to(BF))
+    # heads: dense maps / pooling sums are fp32 on both paths
+    xh = rnd(2, 4, 6, 8, 32, seed=14).to(DEV).to(BF)
+    lungs = (rnd(2, 8, 12, 16, seed=15) > 0).float().to(DEV)
+    for NO, sig in ((2, True), (9, False)):
+        hw, hb = rnd(NO, 32, seed=16).to(DEV), rnd(NO, seed=17).to(DEV)
+        d16, q16 = ops.head_fwd(xh, hw, hb, lungs if sig else None, sig)
+        d32, q32 = ops.head_fwd(f(xh), hw, hb, lungs if sig else None, sig)
+        assert torch.equal(d16, d32) and torch.equal(q16, q32)
+        gd, gpool = rnd(*d16.shape, seed=18).to(DEV), rnd(2, NO, seed=19).to(DEV)
+        x16, w16 = ops.head_bwd(xh, hw, d16 if sig else None, gd, gpool, lungs if sig else None, sig)
+        x32, w32 = ops.head_bwd(f(xh), hw, d32 if sig else None, gd, gpool, lungs if sig else None, sig)
+        assert torch.equal(x16, x32.to(BF)) and torch.equal(w16, w32)
+    # stem: fp32 arithmetic, bf16 store; weight gradient from a bf16 dy
+    xs, ws = rnd(1, 16, 24, 24, seed=20).to(DEV), (rnd(64, 1, 7, 7, 7, seed=21) * 0.05).to(DEV)
+    y16, st16 = ops.stem_fwd(xs, ws, True, BF)
+    y32, st32 = ops.stem_fwd(xs, ws, True)
+    assert torch.equal(y16, y32.to(BF)) and torch.equal(st16, st32)
+    gy = rnd(*y16.shape, seed=22).to(DEV).to(BF)
+    assert torch.equal(ops.stem_bwd_weight(xs, gy), ops.stem_bwd_weight(xs, f(gy)))
+    # casts round to nearest even and are exact back
+    t = rnd(1000, seed=23).to(DEV)
+    assert torch.equal(ops.cast(t, BF), t.to(BF)) and torch.equal(ops.cast(t.to(BF), torch.float32), t.to(BF).float())
+
+
+def _build(factory, seed):
+    from bodyct_dram_emph_subtype_amd import med3d
+    torch.manual_seed(seed)
+    kw = dict(n_classes=[6, 3]) if factory.endswith("cls") else {}
+    return getattr(med3d, factory)(**kw)
+
+
+def _loss(dense, outs, cls):
+    if cls:
+        return outs[0].float().square().sum() + outs[1].float().sum()
+    return outs[0].float().sum() * 0.7 - outs[1].float().sum() * 1.3 + 0.1 * (dense[0].float() * dense[1].float()).mean()
+
+
+@pytest.mark.parametrize("factory,shape,mode", [("resnet18segreg", (2, 1, 32, 64, 64), "attr"),
+                                                ("resnet18segcls", (1, 1, 24, 48, 40), "autocast"),
+                                                ("resnet50segreg", (1, 1, 16, 64, 64), "attr")])
+def test_network_train_step_bf16_storage(factory, shape, mode):
+    """One train step with bf16 activations (selected by module.storage_dtype, or -- as Lightning's `--precision bf16`
+    does -- by running inside torch.autocast(bfloat16)) against the fp32 oracle, the reference's own autocast
+    arithmetic, and the fp64 oracle pinned to the bf16 forward's decisions."""
+    from bodyct_dram_emph_subtype_amd.engine import forward_decisions
+    cls = factory.endswith("cls")
+    m = _build(factory, 3)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    names = [n for n, _ in m.named_parameters()]
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(*shape, generator=g)
+    lungs = (torch.rand(*shape, generator=g) > 0.3).float()
+    m = m.to(DEV).train()
+    if mode == "attr":
+        m.storage_dtype = BF
+        dense, outs = m(x.to(DEV), lungs.to(DEV))
+    else:
+        with torch.autocast("cuda", dtype=BF):
+            dense, outs = m(x.to(DEV), lungs.to(DEV))
+    saved = dense[0].grad_fn.saved_state
+    assert saved["xs"].dtype == BF and saved["xup3"].dtype == BF and dense[0].dtype == torch.float32
+    pins = {k: v.cpu() for k, v in forward_decisions(saved).items()}
+    _loss(dense, outs, cls).backward()
+    torch.cuda.synchronize()
+    # forward quantities vs the fp32 oracle, next to the reference arithmetic under CPU autocast(bfloat16)
+    with torch.no_grad():
+        d32, o32 = orc.forward(dict(sd0), x, lungs, factory, train=True)
+        with torch.autocast("cpu", dtype=BF):
+            dac, oac = orc.forward(dict(sd0), x, lungs, factory, train=True)
+    for a, b, r in zip(outs, o32, oac):
+        e = float((a.detach().cpu() - b).abs().max() / b.abs().max())
+        e_ref = float((r.float() - b).abs().max() / b.abs().max())
+        print(f"[{factory} bf16] pooled: hip {e:.2e}, reference autocast {e_ref:.2e}")
+        assert e <= 3e-3 and e <= max(2.0 * e_ref, 1e-3)
+    for a, b, r in zip(dense, d32, dac):
+        e, e_ref = rel_l2(a.detach().cpu(), b), rel_l2(r.float(), b)
+        print(f"[{factory} bf16] dense: hip {e:.2e}, reference autocast {e_ref:.2e}")
+        assert e <= 2e-2 and e <= max(1.5 * e_ref, 5e-3)
+    # BN running statistics follow the same batch statistics
+    ns = {}
+    orc.forward(dict(sd0), x, lungs, factory, train=True, new_stats=ns)
+    sd = m.state_dict()
+    for k in ("bn1.running_mean", "bn1.running_var", "us3.1.running_var"):
+        assert np.allclose(sd[k].cpu().numpy(), ns[k].numpy(), rtol=2e-2, atol=2e-3), k
+    # gradients (fp32 tensors) vs the fp64 oracle on the bf16 forward's own decisions
+    lv = {k: (v.clone().double().requires_grad_(True) if k in names else (v.clone().double() if v.is_floating_point() else v.clone()))
+          for k, v in sd0.items()}
+    d, o = orc.forward(lv, x.double(), lungs.double(), factory, train=True, pins=pins)
+    _loss(d, o, cls).backward()
+    worst = (0.0, "")
+    for n, p in m.named_parameters():
+        assert p.grad.dtype == torch.float32
+        if n.endswith(".0.bias") and n.startswith("us"):
+            continue
+        e = rel_l2(p.grad.cpu(), lv[n].grad)
+        worst = max(worst, (e, n))
+        assert e <= 5e-2, f"{n}: bf16-storage gradient vs decision-pinned fp64 oracle {e:.2e}"
+    print(f"[{factory} bf16] worst gradient vs decision-pinned fp64 oracle: {worst}")
+
+
+def test_bf16_eval_forward_and_train_steps_run_the_optimizer():
+    """eval-mode forward (packed-weight cache keyed by storage type) and three optimizer steps: the loss of a fixed
+    batch goes down, parameters stay fp32."""
+    from bodyct_dram_emph_subtype_amd.models import cls_train_loss
+    from bodyct_dram_emph_subtype_amd.optim import FusedAdam
+    m = _build("resnet18segcls", 5).to(DEV)
+    m.storage_dtype = BF
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 1, 16, 32, 32, generator=g).to(DEV)
+    lungs = (torch.rand(2, 1, 16, 32, 32, generator=g) > 0.3).float().to(DEV)
+    cle, pse = torch.tensor([1, 4]).to(DEV), torch.tensor([0, 2]).to(DEV)
+    cw, pw = torch.full((6,), 1 / 6, device=DEV), torch.full((3,), 1 / 3, device=DEV)
+    m.eval()
+    with torch.no_grad():
+        d_bf, o_bf = m(x, lungs)
+        m.storage_dtype = torch.float32
+        d_32, o_32 = m(x, lungs)
+        m.storage_dtype = BF
+    assert float((o_bf[0] - o_32[0]).abs().max() / o_32[0].abs().max()) < 5e-3
+    m.train()
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad(set_to_none=True)
+        loss = cls_train_loss(m(x, lungs)[1], cle, pse, cw, pw)[0]
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0], losses
+    assert all(p.dtype == torch.float32 for p in m.parameters())

@@ -65,8 +65,8 @@ def pinned_decisions(out):
     return {k: v.cpu() for k, v in forward_decisions(out.grad_fn.saved_state).items()}
 
 
-FLIP_FRAC = 2e-4         # share of ReLU decisions that may differ from the free-running fp32 oracle's
-FLIP_MARGIN = 2e-4       # ... and only where the oracle's pre-activation is this close to zero (x the layer's max |value|)
+FLIP_FRAC = 2e-5         # share of ReLU decisions that may differ from the free-running fp32 oracle's
+FLIP_MARGIN = 5e-5       # ... and only where the oracle's pre-activation is this close to zero (x the layer's max |value|)
 
 
 def audit_decisions(pins_hip, sd0, x, lungs, factory):
@@ -74,7 +74,8 @@ def audit_decisions(pins_hip, sd0, x, lungs, factory):
     max-pool decisions; a kernel that produced wrong activations would pin the oracle to its own mistake.  So
     the free-running fp32 oracle (its own decisions, the reference's arithmetic) is evaluated too, and every ReLU
     decision the HIP forward took differently must sit on an oracle pre-activation within FLIP_MARGIN x max|value|
-    of zero -- a rounding tie, not a wrong value -- and such ties must be rare (<= FLIP_FRAC of all decisions).
+    of zero -- a rounding tie, not a wrong value -- and such ties must be rare (<= FLIP_FRAC of all decisions;
+    measured on the 8 golden networks: 0-9 of 0.2-2.5 million, margins <= 1.2e-5).
     Max-pool taps may differ only where the two candidate values are equally close.  Returns (flipped ReLU
     decisions, ReLU decisions, differing max-pool taps, max-pool outputs, worst flip margin)."""
     rec = {"__record__": "pre"}
@@ -189,7 +190,8 @@ def test_train_step_matches_reference_golden(path, algo, monkeypatch):
                 if k.startswith("grad:") and not is_noise_param(k[5:]):
                     e = rel_l2(dict(m.named_parameters())[k[5:]].grad.cpu(), g[k])
                     gold_worst = max(gold_worst, (e, k[5:]))
-                    bar = grad_tol(rel_l2(g32[k[5:]], g64[k[5:]])) if (flips[0] == 0 and flips[2] == 0) else NORM_TOL
+                    # (measured: 2e-5 ... 5e-5 with no flip; 1e-3 ... 3.5e-2 with 1-9 flipped ties of ~1e6 decisions)
+                    bar = grad_tol(rel_l2(g32[k[5:]], g64[k[5:]])) if (flips[0] == 0 and flips[2] == 0) else 2 * NORM_TOL
                     assert e <= bar, f"{k[5:]}: hip vs the reference's recorded gradient {e:.2e} > {bar:.1e} (flips {flips[:4]})"
             print(f"[{factory}{' ' + algo if algo else ''}] worst gradient error vs decision-pinned fp64 oracle "
                   f"(hip, cpu-fp32, tensor): {worst}; vs the reference's recorded gradients {gold_worst}; "
