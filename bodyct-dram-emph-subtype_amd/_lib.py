@@ -150,7 +150,7 @@ SIGNATURES = {
 }
 
 OPT_CHUNK = 16384
-ABI_VERSION = 2
+ABI_VERSION = 3
 _LIB = None
 
 
