@@ -7,6 +7,7 @@
 // (conv_igemm.hip / stem.hip); dram_reduce_partials folds them in double precision, the
 // caller may all-reduce the [2][C] doubles across ranks (SyncBatchNorm), then
 // dram_bn_finalize produces mean / invstd / fused scale+shift and the running-stat update.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -84,6 +85,43 @@ __global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict
     }
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     st4<T>(z, 4 * i, o);
+  }
+}
+
+// The same pass for channel counts whose quad count divides the block size (every network width but 576): a
+// thread's channel quad is then fixed across its grid-stride loop (no 64-bit modulo, scale / shift in registers),
+// and U independent 16-byte (bf16: 8-byte) loads per tensor are issued before the first use -- the plain loop has
+// one load per thread in flight, ~8 MB chip-wide, less than the HBM latency-bandwidth product.
+template <int RES, typename T, int U>
+__global__ __launch_bounds__(256) void bn_apply_fast_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const T* __restrict__ res,
+                                                            T* __restrict__ z, int Q, long total4, int relu) {
+  const int q = threadIdx.x % Q;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + 4 * q);
+  const float4 sh = *reinterpret_cast<const float4*>(shift + 4 * q);
+  const long stride = (long)gridDim.x * 256;
+  for (long i0 = blockIdx.x * 256L + threadIdx.x; i0 < total4; i0 += U * stride) {
+    float4 v[U], rr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = i0 + u * stride;
+      if (i < total4) {
+        v[u] = ld4<T>(y, 4 * i);
+        if (RES == 1) rr[u] = ld4<T>(res, 4 * i);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = i0 + u * stride;
+      if (i < total4) {
+        float4 o;
+        o.x = __builtin_fmaf(v[u].x, sc.x, sh.x); o.y = __builtin_fmaf(v[u].y, sc.y, sh.y);
+        o.z = __builtin_fmaf(v[u].z, sc.z, sh.z); o.w = __builtin_fmaf(v[u].w, sc.w, sh.w);
+        if (RES == 1) { o.x += rr[u].x; o.y += rr[u].y; o.z += rr[u].z; o.w += rr[u].w; }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        st4<T>(z, 4 * i, o);
+      }
+    }
   }
 }
 
@@ -327,10 +365,21 @@ static int bn_apply_impl(const T* y, const float* scale, const float* shift, con
   // y read, z written, residual read (identity: full size; shortcut A: 1/rs^3 of Cr/C of it)
   const double res_frac = !residual ? 0.0 : ((double)Cr / C) / ((double)rs * rs * rs);
   DramProf prof(DRAM_FAM_BN, 2, 0.0, 4.0 * sizeof(T) * (double)total4 * (2.0 + res_frac), s);
-  if (!residual) {
+  const int Q = C >> 2;
+  const bool identity = residual && rs == 1 && Cr == C && Dr == D && Hr == H && Wr == W;
+  static const int ew_u = getenv("DRAM_EW_U") ? atoi(getenv("DRAM_EW_U")) : 4;      // A/B switch (tools/ew_bench.py)
+  if ((!residual || identity) && 256 % Q == 0 && ew_u > 0) {
+    const long per = (total4 + 255) / 256;
+    const int g2 = (int)((per + ew_u - 1) / ew_u < 8192 ? ((per + ew_u - 1) / ew_u < 1 ? 1 : (per + ew_u - 1) / ew_u) : 8192);
+#define BN_FAST_(RES_, U_) hipLaunchKernelGGL((bn_apply_fast_kernel<RES_, T, U_>), dim3(g2), dim3(256), 0, s, y, scale, shift, \
+                                              residual, z, Q, total4, relu)
+    if (!residual) { if (ew_u >= 4) BN_FAST_(0, 4); else if (ew_u >= 2) BN_FAST_(0, 2); else BN_FAST_(0, 1); }
+    else           { if (ew_u >= 4) BN_FAST_(1, 4); else if (ew_u >= 2) BN_FAST_(1, 2); else BN_FAST_(1, 1); }
+#undef BN_FAST_
+  } else if (!residual) {
     hipLaunchKernelGGL((bn_apply_kernel<0, T>), dim3(grid), dim3(256), 0, s, y, scale, shift, (const T*)nullptr, 0,
                        1, z, D, H, W, C, total4, relu);
-  } else if (rs == 1 && Cr == C && Dr == D && Hr == H && Wr == W) {
+  } else if (identity) {
     hipLaunchKernelGGL((bn_apply_kernel<1, T>), dim3(grid), dim3(256), 0, s, y, scale, shift, residual,
                        Cr, 1, z, D, H, W, C, total4, relu);
   } else {

@@ -11,7 +11,7 @@
 //                                epilogue = the identity-shortcut gradient).  One workgroup (4 waves) = a 4x8x8 block
 //                                of the dilation lattice x 32*NB output channels.  Per 32-channel chunk the 6x10x10
 //                                input halo (38 KB) is brought into LDS ONCE by LDS-DMA and serves all 27 taps; the
-//                                weights stream through two small LDS buffers, three taps (one kx row) at a time.
+//                                weights stream through a 3-slot LDS ring, three taps (one kx row) per slot, two slots ahead.
 //                                Both images are XOR-swizzled in 16-B slots so that every ds_read_b128 operand fetch
 //                                is conflict-free for the four lane groups of that instruction.
 //   wgrad3_bf16_kernel           weight gradient dW[tap][co][ci] = sum_v dy[v][co] x[v + tap][ci]: the contraction runs
@@ -23,6 +23,8 @@
 //
 // Geometries outside this (the one stride-2 convolution per network, the 1x1x1 convolutions of the Bottleneck
 // blocks) are run by the host on the fp32 kernels around cast passes (ops.py) -- a few per cent of the FLOPs.
+#include <stdlib.h>
+#include <string.h>
 #include "common.h"
 
 namespace {
@@ -58,21 +60,41 @@ __device__ __forceinline__ void decode_tile(int t, const CGeom& g, int& b, int& 
 
 constexpr int HALO_GRAN = 2560;   // 6 x 10 x 10 voxels x 4 slots = 2400 16-B granules, padded to 10 x 256
 
+// LDS-DMA through a buffer descriptor: the per-lane source is a 32-bit BYTE offset held in a register for the whole
+// kernel, an out-of-range offset (0xFFFFFFFF = zero padding of the halo / unused lanes of a piece) reads zeros in
+// hardware, and the chunk / tap-group base moves by scalar arithmetic on the descriptor -- one instruction per piece
+// instead of a 64-bit select + add per piece.
+#define BUFLDS16(rsrc_, voff_, dst_)                                                                               \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc_), (__attribute__((address_space(3))) void*)(dst_), 16, (voff_), 0, 0, 0)
+constexpr int BUF_FLAGS = 0x00020000;   // raw buffer, 32-bit data format
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long off_bytes, long total_bytes) {
+  const long left = total_bytes - off_bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + off_bytes, 0,
+                                           (int)(left > 0xffffffffL ? 0xffffffffL : left), BUF_FLAGS);
+}
+
 // ---------------------------------------------------------------------------------------------------------
-// forward / data gradient
-template <int NB, int EPI>
-__global__ __launch_bounds__(256, 2) void conv3_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                            const float* __restrict__ bias,
-                                                            const bf16_t* __restrict__ add,
-                                                            const bf16_t* __restrict__ gate, bf16_t* __restrict__ y,
-                                                            float* __restrict__ stats, const CGeom g) {
+// forward / data gradient.  NW waves = NW z-slices of 8 x 8 voxels (NW = 4: 256 voxels, two workgroups per CU;
+// NW = 8: 512 voxels, one workgroup per CU -- half the DMA pieces per MFMA, for lattices at least 8 deep).
+template <int NB, int EPI, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv3_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                                const float* __restrict__ bias,
+                                                                const bf16_t* __restrict__ add,
+                                                                const bf16_t* __restrict__ gate, bf16_t* __restrict__ y,
+                                                                float* __restrict__ stats, const CGeom g) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the launch stub: the buffer-descriptor builtins in
+                                      // this TEMPLATE's body made it drop the stub's definition)
+  constexpr int NT = 64 * NW;                              // threads
+  constexpr int HV = (NW + 2) * 100;                       // halo voxels
+  constexpr int HROUNDS = (HV * 4 + NT - 1) / NT;          // DMA rounds of the halo (pieces per wave)
   constexpr int WROWS = 3 * 32 * NB;                       // weight rows (kx, co) per group
-  constexpr int WROUNDS = (WROWS * 4 + 255) / 256;         // DMA rounds per group
+  constexpr int WROUNDS = (WROWS * 4 + NT - 1) / NT;       // DMA rounds per group
   // one LDS object per buffer: the wait-count pass only keeps a pending DMA out of the way of reads that provably
   // touch another object
-  __shared__ __attribute__((aligned(1024))) unsigned char halo[HALO_GRAN * 16];
-  __shared__ __attribute__((aligned(1024))) unsigned char wb0[WROUNDS * 4096];
-  __shared__ __attribute__((aligned(1024))) unsigned char wb1[WROUNDS * 4096];
+  __shared__ __attribute__((aligned(1024))) unsigned char halo[HROUNDS * NT * 16];
+  __shared__ __attribute__((aligned(1024))) unsigned char wb0[WROUNDS * NT * 16];   // weight ring: group g lives in
+  __shared__ __attribute__((aligned(1024))) unsigned char wb1[WROUNDS * NT * 16];   // slot g % 3 and is fetched two
+  __shared__ __attribute__((aligned(1024))) unsigned char wb2[WROUNDS * NT * 16];   // groups ahead of its use
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,44 +103,41 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16_kernel(const bf16_t* __rest
   const int nt = L % g.n_tiles;
   int b, rz, ry, rx, lz0, ly0, lx0;
   decode_tile(L / g.n_tiles, g, b, rz, ry, rx, lz0, ly0, lx0);
+  lz0 = (lz0 / 4) * NW;
   const int co0 = nt * 32 * NB;
-  const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_zero_page);
+  const long xbytes = (long)g.B * g.D * g.H * g.W * g.Cin * 2, wbytes = 27L * g.Cout * g.Cin * 2;
 
-  // halo DMA sources: granule p = round * 256 + tid -> voxel p / 4, physical slot p % 4 holding the logical slot
+  // halo DMA sources: granule p = round * NT + tid -> voxel p / 4, physical slot p % 4 holding the logical slot
   // (p % 4) ^ ((hx >> 1) & 3)
-  int hoff[10];
+  unsigned hoff[HROUNDS];
 #pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    const int p = i * 256 + tid;
+  for (int i = 0; i < HROUNDS; ++i) {
+    const int p = i * NT + tid;
     const int hv = p >> 2, ps = p & 3;
     const int hz = hv / 100, hy = (hv / 10) % 10, hx = hv % 10;
     const int gz = rz + g.d * (lz0 + hz - 1), gy = ry + g.d * (ly0 + hy - 1), gx = rx + g.d * (lx0 + hx - 1);
-    const bool ok = (hv < 600) & (gz >= 0) & (gz < g.D) & (gy >= 0) & (gy < g.H) & (gx >= 0) & (gx < g.W);
-    hoff[i] = ok ? (int)(((((long)b * g.D + gz) * g.H + gy) * g.W + gx) * g.Cin) + (ps ^ ((hx >> 1) & 3)) * 8 : -1;
+    const bool ok = (hv < HV) & (gz >= 0) & (gz < g.D) & (gy >= 0) & (gy < g.H) & (gx >= 0) & (gx < g.W);
+    const long e = ((((long)b * g.D + gz) * g.H + gy) * g.W + gx) * g.Cin + (ps ^ ((hx >> 1) & 3)) * 8;
+    hoff[i] = ok ? (unsigned)(e * 2) : 0xffffffffu;
   }
   // weight DMA sources: granule q -> row q / 4 = kx * 32 NB + co, physical slot q % 4 = logical ^ ((co >> 2) & 3)
-  int woff[WROUNDS];
+  unsigned woff[WROUNDS];
 #pragma unroll
   for (int r = 0; r < WROUNDS; ++r) {
-    const int q = r * 256 + tid;
+    const int q = r * NT + tid;
     const int row = q >> 2, ps = q & 3;
     const int kx = row / (32 * NB), co = row % (32 * NB);
-    woff[r] = row < WROWS ? (kx * g.Cout + co0 + co) * g.Cin + (ps ^ ((co >> 2) & 3)) * 8 : -1;
+    woff[r] = row < WROWS ? (unsigned)((((long)kx * g.Cout + co0 + co) * g.Cin + (ps ^ ((co >> 2) & 3)) * 8) * 2) : 0xffffffffu;
   }
   auto issue_halo = [&](int c) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(x, (long)c * 64, xbytes);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      const unsigned char* src = hoff[i] >= 0 ? reinterpret_cast<const unsigned char*>(x + hoff[i] + c * 32) : zero;
-      GLDS16(src, halo + i * 4096 + wave * 1024);
-    }
+    for (int i = 0; i < HROUNDS; ++i) BUFLDS16(rs, hoff[i], halo + i * (NT * 16) + wave * 1024);
   };
   auto issue_w = [&](int c, int gi, unsigned char* buf) __attribute__((always_inline)) {
-    const bf16_t* wg = w + (long)(3 * gi) * g.Cout * g.Cin + c * 32;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(w, ((long)(3 * gi) * g.Cout * g.Cin + c * 32) * 2, wbytes);
 #pragma unroll
-    for (int r = 0; r < WROUNDS; ++r) {
-      const unsigned char* src = woff[r] >= 0 ? reinterpret_cast<const unsigned char*>(wg + woff[r]) : zero;
-      GLDS16(src, buf + r * 4096 + wave * 1024);
-    }
+    for (int r = 0; r < WROUNDS; ++r) BUFLDS16(rs, woff[r], buf + r * (NT * 16) + wave * 1024);
   };
 
   f32x16 acc[2][NB];
@@ -138,36 +157,64 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16_kernel(const bf16_t* __rest
   for (int kx = 0; kx < 3; ++kx) akey[kx] = ((xl + kx) >> 1) & 3;
   const int bkey = (li >> 2) & 3;
 
+  // Schedule.  The weights of tap group gi (3 taps = one kx row) are issued TWO groups ahead of their use into a
+  // 3-slot ring.  A wave's DMAs land in issue order: before group gi all but the newest WROUNDS (group gi + 1's)
+  // must have landed.  The halo is single-buffered.
   const int nchunk = g.Cin / 32;
+  // (named arrays, never a pointer table: the wait-count pass must see which LDS object a pending DMA targets)
+#define RING_(i_) ((i_) % 3 == 0 ? wb0 : ((i_) % 3 == 1 ? wb1 : wb2))
+  issue_w(0, 0, wb0);
+  issue_w(0, 1, wb1);
   for (int c = 0; c < nchunk; ++c) {
-    __syncthreads();                       // every wave is done with the halo and both weight buffers of the last chunk
+    const bool last = c + 1 == nchunk;
+    __builtin_amdgcn_s_barrier();          // every wave is done with the halo of the last chunk
     issue_halo(c);
-    issue_w(c, 0, wb0);
 #pragma unroll
     for (int gi = 0; gi < 9; ++gi) {
-      __syncthreads();                     // group gi's weights (gi == 0: and the halo) have landed; buffer (gi+1)&1 is free
-      if (gi < 8) issue_w(c, gi + 1, ((gi + 1) & 1) ? wb1 : wb0);
-      const unsigned char* wl = (gi & 1) ? wb1 : wb0;
+      if (gi == 0 || (gi == 8 && last)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WROUNDS) : "memory");
+      __builtin_amdgcn_s_barrier();        // group gi's weights (gi == 0: and the halo) are in LDS for every wave;
+                                           // slot (gi + 2) % 3, read during group gi - 1, is free
+      // (group 0 refills at its END instead: the wait-count pass, which does not see the hand-placed wait, guards
+      // the first halo read with its own vmcnt(0) and would wait for a refill issued in front of it)
+      if (gi != 0) {
+        if (gi + 2 < 9) issue_w(c, gi + 2, RING_(gi + 2));
+        else if (!last) issue_w(c + 1, gi + 2 - 9, RING_(gi + 2));
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the refill is issued HERE, two groups ahead, not sunk behind the MFMAs
+      const unsigned char* wl = RING_(gi);
       const int tapo = ((gi / 3) * 100 + (gi % 3) * 10) * 64;
+      // six (kx, k16) steps; the operand fragments of step s + 1 are read while the MFMAs of step s run
+      bf16x8 af[2][2], bfr[2][NB];
+      auto frag = [&](int st, int buf) __attribute__((always_inline)) {
+        const int kx = st >> 1, j = st & 1;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
+        for (int mi = 0; mi < 2; ++mi)
+          af[buf][mi] = *reinterpret_cast<const bf16x8*>(halo + abase[mi] + tapo + kx * 64 + (((2 * j + lh) ^ akey[kx]) << 4));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          bf16x8 af[2], bfr[NB];
+        for (int nb = 0; nb < NB; ++nb)
+          bfr[buf][nb] = *reinterpret_cast<const bf16x8*>(wl + ((kx * 32 * NB + nb * 32 + li) << 6) + (((2 * j + lh) ^ bkey) << 4));
+      };
+      frag(0, 0);
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-            af[mi] = *reinterpret_cast<const bf16x8*>(halo + abase[mi] + tapo + kx * 64 + (((2 * j + lh) ^ akey[kx]) << 4));
+      for (int st = 0; st < 6; ++st) {
+        if (st + 1 < 6) frag(st + 1, (st + 1) & 1);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            bfr[nb] = *reinterpret_cast<const bf16x8*>(wl + ((kx * 32 * NB + nb * 32 + li) << 6) + (((2 * j + lh) ^ bkey) << 4));
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-              acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[nb], acc[mi][nb], 0, 0, 0);
-        }
+            acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st & 1][mi], bfr[st & 1][nb], acc[mi][nb], 0, 0, 0);
+        if (st + 1 < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2 + NB, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NB, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (gi == 0) {
+        issue_w(c, 2, wb2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
+#undef RING_
 
   // epilogue: D[row][col]: col = li (channel), row = (e & 3) + 8 (e >> 2) + 4 lh within the 32-row block
   float s1[NB], s2[NB], bv[NB];
@@ -205,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16_kernel(const bf16_t* __rest
     }
   if (EPI == 0 && stats) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(halo);   // [4 waves][2][32 NB]
+    float* red = reinterpret_cast<float*>(halo);   // [NW waves][2][32 NB]
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const float t1 = s1[nb] + __shfl_xor(s1[nb], 32, 64);
@@ -220,10 +267,11 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16_kernel(const bf16_t* __rest
       const int which = tid / (32 * NB), cc = tid % (32 * NB);
       float v = 0.f;
 #pragma unroll
-      for (int wv = 0; wv < 4; ++wv) v += red[(wv * 2 + which) * 32 * NB + cc];
+      for (int wv = 0; wv < NW; ++wv) v += red[(wv * 2 + which) * 32 * NB + cc];
       stats[((long)(L / g.n_tiles) * 2 + which) * g.Cout + co0 + cc] = v;
     }
   }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -362,19 +410,191 @@ __global__ __launch_bounds__(512) void wgrad3_bf16_kernel(const bf16_t* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// weight gradient, z-walking form (Cin % 64 == 0).  The tile kernel above loads 72 KB per 864 MFMAs (83 B per MFMA:
+// at the full matrix rate that is 6 TB/s into LDS -- it ran at 0.28 of the pipe, bound by exactly that).  Here a
+// workgroup owns a 64 x 64 (co, ci) block and WALKS an 8 x 8 column of the dilation lattice along z: per step ONE new
+// 10 x 10 halo plane of x (12.5 KB) and ONE 8 x 8 plane of dy (8 KB) arrive by LDS-DMA into plane rings (4 / 2 slots)
+// and serve 432 MFMAs (all 27 taps x 4 channel-block pairs x 4 k16 steps): 48 B per MFMA, no z halo re-reads.
+// 8 waves; wave = (32-channel half ib of the ci block) x (taps t0, t0 + 4, ...) x both co halves: 14 (12)
+// accumulators.  Each 32-channel half of a plane is its own [voxel][64 B] image, so the four voxel rows of a
+// transposed read are 256 contiguous bytes (conflict-free without a swizzle) and tap offsets are address constants.
+struct ZGeom {
+  int B, D, H, W, Cin, Cout, d;
+  int Ty, Tx;            // in-plane lattice tiles
+  int Lz, nzs, lseg;     // lattice depth, z segments per column, planes per segment
+  int ncol;              // columns = B * d^3 * Ty * Tx * nzs
+  int nsplit;            // slabs
+  int ci_blocks, co_blocks, npairs;
+  int nblk;
+};
+
+__global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                           float* __restrict__ slab, const ZGeom g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char xr0[16384];   // x plane ring: [2 ib][100 voxels][64 B], padded
+  __shared__ __attribute__((aligned(1024))) unsigned char xr1[16384];
+  __shared__ __attribute__((aligned(1024))) unsigned char xr2[16384];
+  __shared__ __attribute__((aligned(1024))) unsigned char xr3[16384];
+  __shared__ __attribute__((aligned(1024))) unsigned char dr0[8192];    // dy plane ring: [2 cb][64 voxels][64 B]
+  __shared__ __attribute__((aligned(1024))) unsigned char dr1[8192];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = xcd_remap(blockIdx.x, g.nblk);
+  const int pair = L % g.npairs, split = L / g.npairs;
+  const int cib = pair % g.ci_blocks, cob = pair / g.ci_blocks;
+  const long plane_x = (long)g.H * g.W * g.Cin * 2, plane_dy = (long)g.H * g.W * g.Cout * 2;     // bytes per z plane
+
+  const int ib = wave & 1, t0 = wave >> 1;
+  const int ntap = t0 < 3 ? 7 : 6;
+  f32x16 acc[7][2];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][cb][e] = 0.f;
+
+  // transposed-read lane addresses (see wgrad3_bf16_kernel): row q of the group's block, 8-byte piece p
+  const int g4 = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3, h = g4 >> 1;
+  const int cpiece = ((g4 & 1) * 2 + (p4 >> 1)) * 16 + (p4 & 1) * 8;
+  int a_lane[2], b_lane[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    a_lane[s] = (h * 8 + 4 * s + q) * 64 + cpiece;                       // dy voxel (2 ks + h, 4 s + q), + cb * 4096
+    b_lane[s] = ib * 6400 + (h * 10 + 4 * s + q) * 64 + cpiece;          // x halo voxel (2 ks + h + ky, 4 s + q + kx)
+  }
+  int tapoff[7], tapkz[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = (t0 + 4 * i) < 27 ? t0 + 4 * i : 0;
+    tapkz[i] = tap / 9;
+    tapoff[i] = (((tap / 3) % 3) * 10 + tap % 3) * 64;
+  }
+  auto tr8 = [&](const unsigned char* base, int o0, int o1) __attribute__((always_inline)) {
+    const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o0));
+    const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o1));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+#define XRING_(i_) (((i_) & 3) == 0 ? xr0 : (((i_) & 3) == 1 ? xr1 : (((i_) & 3) == 2 ? xr2 : xr3)))
+#define DRING_(i_) (((i_) & 1) == 0 ? dr0 : dr1)
+
+  for (int col = split; col < g.ncol; col += g.nsplit) {
+    int t = col;
+    const int seg = t % g.nzs; t /= g.nzs;
+    const int txi = t % g.Tx; t /= g.Tx;
+    const int tyi = t % g.Ty; t /= g.Ty;
+    const int rx = t % g.d; t /= g.d;
+    const int ry = t % g.d; t /= g.d;
+    const int rz = t % g.d;
+    const int b = t / g.d;
+    const int lzr = (g.D - rz + g.d - 1) / g.d;                          // lattice planes of this residue class
+    const int z0 = seg * g.lseg, z1 = (z0 + g.lseg < lzr) ? z0 + g.lseg : lzr;
+    if (z0 >= z1) continue;                                              // (uniform)
+    // per-lane DMA sources inside a plane: x granule pp -> (ib, halo voxel, slot); dy granule tid -> (cb, voxel, slot)
+    unsigned xoff[2], doff;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int pp = r * 512 + tid;
+      const int ibb = pp / 400, rr = pp % 400, hv = rr >> 2, sl = rr & 3;
+      const int gy = ry + g.d * (tyi * 8 + hv / 10 - 1), gx = rx + g.d * (txi * 8 + hv % 10 - 1);
+      const bool ok = (pp < 800) & (gy >= 0) & (gy < g.H) & (gx >= 0) & (gx < g.W);
+      xoff[r] = ok ? (unsigned)((((long)gy * g.W + gx) * g.Cin + cib * 64 + ibb * 32 + sl * 8) * 2) : 0xffffffffu;
+    }
+    {
+      const int cbb = tid >> 8, rr = tid & 255, v = rr >> 2, sl = rr & 3;
+      const int gy = ry + g.d * (tyi * 8 + (v >> 3)), gx = rx + g.d * (txi * 8 + (v & 7));
+      const int ch = cob * 64 + cbb * 32 + sl * 8;
+      const bool ok = (gy < g.H) & (gx < g.W) & (ch < g.Cout);
+      doff = ok ? (unsigned)((((long)gy * g.W + gx) * g.Cout + ch) * 2) : 0xffffffffu;
+    }
+    // plane zl of the lattice (any integer): a descriptor over that plane alone, EMPTY (-> zeros) outside the volume
+    auto issue_x = [&](int zl, unsigned char* dst) __attribute__((always_inline)) {
+      const int gz = rz + g.d * zl;
+      const bool in = (zl >= 0) & (gz < g.D);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(x)) + ((long)b * g.D + (in ? gz : 0)) * plane_x, 0,
+          in ? (int)plane_x : 0, BUF_FLAGS);
+      BUFLDS16(rs, xoff[0], dst + wave * 1024);
+      BUFLDS16(rs, xoff[1], dst + 8192 + wave * 1024);
+    };
+    auto issue_d = [&](int zl, unsigned char* dst) __attribute__((always_inline)) {
+      const int gz = rz + g.d * zl;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(dy)) + ((long)b * g.D + gz) * plane_dy, 0, (int)plane_dy, BUF_FLAGS);
+      BUFLDS16(rs, doff, dst + wave * 1024);
+    };
+    __builtin_amdgcn_s_barrier();                        // every wave is done with the rings of the last column
+    // ring slots are indexed by (plane - z0 + 1) for x and (plane - z0) for dy: the same named slots for every column
+    issue_x(z0 - 1, xr0);
+    issue_x(z0, xr1);
+    issue_x(z0 + 1, xr2);
+    issue_d(z0, dr0);
+    for (int zz = 0; zz < z1 - z0; zz += 4) {            // four steps per trip: ring slots are compile-time names
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int z = zz + u;                            // relative plane
+        if (z < z1 - z0) {                               // (uniform)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();                  // planes z - 1 .. z + 1 of x and plane z of dy are in LDS
+          issue_x(z0 + z + 2, XRING_(u + 3));            // relative plane z + 2 -> slot (z + 3) & 3 = (u + 3) & 3
+          if (z + 1 < z1 - z0) issue_d(z0 + z + 1, DRING_(u + 1));
+          __builtin_amdgcn_sched_barrier(0);
+          const unsigned char* dl = DRING_(u);
+#pragma unroll 1
+          for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 a0 = tr8(dl + ks * 1024, a_lane[0], a_lane[1]);
+            const bf16x8 a1 = tr8(dl + 4096 + ks * 1024, a_lane[0], a_lane[1]);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+              if (i < ntap) {
+                // x plane z + kz - 1 lives in slot (z + kz) & 3 = (u + kz) & 3
+                const unsigned char* xl = tapkz[i] == 0 ? XRING_(u) : (tapkz[i] == 1 ? XRING_(u + 1) : XRING_(u + 2));
+                const bf16x8 bfr = tr8(xl + ks * 1280 + tapoff[i], b_lane[0], b_lane[1]);
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr, acc[i][1], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the look-ahead plane of the last step: drained before reuse
+  }
+#undef XRING_
+#undef DRING_
+
+  // slab[split][pair][tap][co 64][ci 64]
+  const int li = lane & 31, lh = lane >> 5;
+  float* sb = slab + ((long)split * g.npairs + pair) * 27 * 4096;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    if (i < ntap) {
+      const int tap = t0 + 4 * i;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+          sb[(tap * 64 + cb * 32 + row) * 64 + ib * 32 + li] = acc[i][cb][e];
+        }
+    }
+  }
+}
+
 // dw[co][ci][tap] = sum_split slab[split][pair(co / 64, ci / 32)][tap][co % 64][ci % 32], fixed order
 __global__ void wgrad3_bf16_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin,
-                                          int ci_blocks, int npairs, int nsplit) {
+                                          int ci_blocks, int npairs, int nsplit, int cw /* ci block width: 32 | 64 */) {
   const long n = (long)Cout * Cin * 27;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int ci = (int)(i % Cin);
     long r = i / Cin;
     const int co = (int)(r % Cout);
     const int tap = (int)(r / Cout);
-    const int pair = (co >> 6) * ci_blocks + (ci >> 5);
-    const float* s = slab + ((long)pair * 27 + tap) * 2048 + (co & 63) * 32 + (ci & 31);
+    const int pair = (co >> 6) * ci_blocks + ci / cw;
+    const float* s = slab + ((long)pair * 27 + tap) * 64 * cw + (co & 63) * cw + ci % cw;
     float a = 0.f;
-    for (int k = 0; k < nsplit; ++k) a += s[(long)k * npairs * 27 * 2048];
+    for (int k = 0; k < nsplit; ++k) a += s[(long)k * npairs * 27 * 64 * cw];
     dw[((long)co * Cin + ci) * 27 + tap] = a;
   }
 }
@@ -427,11 +647,24 @@ bool geom_ok(const DramConvDesc* d) {
   return true;
 }
 
-// forward-sense descriptor -> lattice tiling of a tensor with the spatial extent (D, H, W)
-void fill_tiles(const DramConvDesc* d, int& Tz, int& Ty, int& Tx, long long& ntile) {
+// forward-sense descriptor -> lattice tiling (tz x 8 x 8 voxels per tile) of a tensor with the spatial extent (D, H, W)
+void fill_tiles(const DramConvDesc* d, int& Tz, int& Ty, int& Tx, long long& ntile, int tz = 4) {
   auto tiles = [&](int n, int per) { return ((n + d->dil - 1) / d->dil + per - 1) / per; };
-  Tz = tiles(d->D, 4); Ty = tiles(d->H, 8); Tx = tiles(d->W, 8);
+  Tz = tiles(d->D, tz); Ty = tiles(d->H, 8); Tx = tiles(d->W, 8);
   ntile = (long long)d->B * d->dil * d->dil * d->dil * Tz * Ty * Tx;
+}
+
+// Tile depth of the forward / data-gradient kernel: 4 z-slices (256 voxels, two workgroups per CU).  The 8-slice
+// form (512 voxels, 8 waves, one workgroup per CU: half the LDS-DMA pieces per MFMA) measured 0-5 % SLOWER on every
+// layer of config 2 -- two independent workgroups hide each other's barriers and halo refills better than the
+// larger tile saves -- and is kept behind DRAM_BF16_NW=8 (tests run it).
+int pick_nw(const DramConvDesc* d, int n_tiles) {
+  (void)d; (void)n_tiles;
+  if (const char* e = getenv("DRAM_BF16_NW")) {
+    const int v = atoi(e);
+    if (v == 4 || v == 8) return v;
+  }
+  return 4;
 }
 
 // N tile: 64 columns (2 blocks); 32 when the channel count is not a multiple of 64
@@ -442,21 +675,25 @@ int launch_conv(const bf16_t* x, const bf16_t* w, const float* bias, const bf16_
   CGeom g{};
   g.B = d->B; g.D = d->D; g.H = d->H; g.W = d->W; g.Cin = cin; g.Cout = cout; g.d = d->dil;
   long long ntile;
-  fill_tiles(d, g.Tz, g.Ty, g.Tx, ntile);
   const int nb = pick_nb(cout);
   g.n_tiles = cout / (32 * nb);
+  const int nw = pick_nw(d, g.n_tiles);
+  fill_tiles(d, g.Tz, g.Ty, g.Tx, ntile, nw);
   const long long nblk = ntile * g.n_tiles;
   if (nblk >= (1LL << 31)) return DRAM_ERR_UNSUPPORTED;
   g.nblk = (int)nblk;
   const double vox = (double)d->B * d->D * d->H * d->W;
-  const double flops = 2.0 * (double)ntile * 256.0 * 27.0 * cin * cout;      // executed, padded tiles included
-  DramProf prof(DRAM_FAM_CONV_BF16, epi * 2 + (nb - 1), flops,
+  const double flops = 2.0 * (double)ntile * 64.0 * nw * 27.0 * cin * cout;      // executed, padded tiles included
+  DramProf prof(DRAM_FAM_CONV_BF16, epi * 4 + (nw == 8 ? 2 : 0) + (nb - 1), flops,
                 2.0 * (vox * (cin + cout * (1.0 + (add ? 1 : 0) + (gate ? 1 : 0))) + 27.0 * cin * cout), s,
                 2.0 * vox * 27.0 * cin * cout);
-#define LAUNCH_(NB_, EPI_)                                                                                         \
-  hipLaunchKernelGGL((conv3_bf16_kernel<NB_, EPI_>), dim3(g.nblk), dim3(256), 0, s, x, w, bias, add, gate, y, stats, g)
-  if (epi == 0) { if (nb == 2) LAUNCH_(2, 0); else LAUNCH_(1, 0); }
-  else          { if (nb == 2) LAUNCH_(2, 1); else LAUNCH_(1, 1); }
+#define LAUNCH_(NB_, EPI_, NW_)                                                                                    \
+  hipLaunchKernelGGL((conv3_bf16_kernel<NB_, EPI_, NW_>), dim3(g.nblk), dim3(64 * NW_), 0, s, x, w, bias, add, gate, y, \
+                     stats, g)
+#define LAUNCH_NW_(NB_, EPI_) do { if (nw == 8) LAUNCH_(NB_, EPI_, 8); else LAUNCH_(NB_, EPI_, 4); } while (0)
+  if (epi == 0) { if (nb == 2) LAUNCH_NW_(2, 0); else LAUNCH_NW_(1, 0); }
+  else          { if (nb == 2) LAUNCH_NW_(2, 1); else LAUNCH_NW_(1, 1); }
+#undef LAUNCH_NW_
 #undef LAUNCH_
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
@@ -479,6 +716,44 @@ void plan_wgrad(const DramConvDesc* d, WGeom& g) {
   g.nblk = g.npairs * g.nsplit;
 }
 
+// Weight-gradient form.  Measured on config 2's layers (tools/conv_bf16_bench.py, ms tile / z-walk): 64->64 @ 64x128x128
+// 0.60 / 0.47, 128->64 @ 64x128x128 1.11 / 0.94, 64->32 0.58 / 0.46, 64->64 @ 32x64x64 0.157 / 0.141 -- but
+// 576->64 @ 32x64x64 0.79 / 1.10 (nine ci blocks re-read every dy plane) and the 16x32x32 stages 0.076-0.70 /
+// 0.12-0.76 (columns of 4-16 planes: the walk never leaves its prologue).  So: walk deep lattices with few
+// channel-block pairs, tile the rest.  DRAM_BF16_WGRAD = tile | zwalk forces one (A/B, tests).
+bool use_zwalk(const DramConvDesc* d) {
+  if (d->Cin % 64 != 0) return false;
+  const char* e = getenv("DRAM_BF16_WGRAD");
+  if (e && !strcmp(e, "tile")) return false;
+  if (e && !strcmp(e, "zwalk")) return true;
+  const int lz = (d->D + d->dil - 1) / d->dil;
+  const int npairs = (d->Cin / 64) * ((d->Cout + 63) / 64);
+  return lz >= 32 && npairs <= 4;
+}
+
+void plan_zwalk(const DramConvDesc* d, ZGeom& g) {
+  g.B = d->B; g.D = d->D; g.H = d->H; g.W = d->W; g.Cin = d->Cin; g.Cout = d->Cout; g.d = d->dil;
+  auto tiles = [&](int n, int per) { return ((n + d->dil - 1) / d->dil + per - 1) / per; };
+  g.Ty = tiles(d->H, 8); g.Tx = tiles(d->W, 8);
+  g.Lz = (d->D + d->dil - 1) / d->dil;
+  g.ci_blocks = d->Cin / 64;
+  g.co_blocks = (d->Cout + 63) / 64;
+  g.npairs = g.ci_blocks * g.co_blocks;
+  const long long cols = (long long)d->B * d->dil * d->dil * d->dil * g.Ty * g.Tx;
+  // z segments: enough workgroups for two per CU, never shorter than 4 planes (each segment re-reads 2 halo planes)
+  int nzs = 1;
+  while (cols * nzs * g.npairs < 512 && g.Lz / (nzs * 2) >= 4) nzs *= 2;
+  g.nzs = nzs;
+  g.lseg = (g.Lz + nzs - 1) / nzs;
+  g.ncol = (int)(cols * nzs);
+  int ns = (1024 + g.npairs - 1) / g.npairs;
+  if (ns > g.ncol) ns = g.ncol;
+  if (ns > 256) ns = 256;
+  if (ns < 1) ns = 1;
+  g.nsplit = ns;
+  g.nblk = g.npairs * g.nsplit;
+}
+
 }  // namespace
 
 extern "C" int dram_conv_bf16_supported(const DramConvDesc* d) { return geom_ok(d) ? 1 : 0; }
@@ -487,7 +762,7 @@ extern "C" int dram_conv_bf16_num_stat_rows(const DramConvDesc* d) {
   if (!geom_ok(d)) return DRAM_ERR_UNSUPPORTED;
   int Tz, Ty, Tx;
   long long ntile;
-  fill_tiles(d, Tz, Ty, Tx, ntile);
+  fill_tiles(d, Tz, Ty, Tx, ntile, pick_nw(d, d->Cout / (32 * pick_nb(d->Cout))));    // the forward launch's tiling
   return ntile < (1LL << 31) ? (int)ntile : DRAM_ERR_UNSUPPORTED;
 }
 
@@ -540,6 +815,11 @@ extern "C" int dram_conv3d_bwd_data_bf16(const void* dy, const void* wb, void* d
 
 extern "C" size_t dram_conv3d_bwd_weight_bf16_workspace(const DramConvDesc* d) {
   if (!geom_ok(d)) return 0;
+  if (use_zwalk(d)) {
+    ZGeom z{};
+    plan_zwalk(d, z);
+    return (size_t)z.nsplit * z.npairs * 27 * 4096 * sizeof(float);
+  }
   WGeom g{};
   plan_wgrad(d, g);
   return (size_t)g.nsplit * g.npairs * 27 * 2048 * sizeof(float);
@@ -549,6 +829,27 @@ extern "C" int dram_conv3d_bwd_weight_bf16(const void* x, const void* dy, float*
                                            void* workspace, size_t workspace_bytes, dram_stream_t stream) {
   if (!x || !dy || !dw) return DRAM_ERR_BAD_ARG;
   if (!geom_ok(d)) return DRAM_ERR_UNSUPPORTED;
+  if (use_zwalk(d)) {
+    ZGeom z{};
+    plan_zwalk(d, z);
+    const size_t needz = (size_t)z.nsplit * z.npairs * 27 * 4096 * sizeof(float);
+    if (!workspace || workspace_bytes < needz) return DRAM_ERR_WORKSPACE;
+    hipStream_t sz = (hipStream_t)stream;
+    const double voxz = (double)d->B * d->D * d->H * d->W;
+    {
+      DramProf prof(DRAM_FAM_WGRAD_BF16, 2, 2.0 * voxz * 27.0 * d->Cin * z.co_blocks * 64.0,
+                    2.0 * voxz * (d->Cin + d->Cout) + 4.0 * 27.0 * d->Cin * d->Cout, sz, 2.0 * voxz * 27.0 * d->Cin * d->Cout);
+      hipLaunchKernelGGL(wgrad3z_bf16_kernel, dim3(z.nblk), dim3(512), 0, sz, (const bf16_t*)x, (const bf16_t*)dy,
+                         (float*)workspace, z);
+      DRAM_LAUNCH_CHECK();
+    }
+    const long nz = (long)d->Cout * d->Cin * 27;
+    DramProf prof(DRAM_FAM_WGRAD_BF16, 3, 0.0, 4.0 * (double)nz * (z.nsplit + 1), sz);
+    hipLaunchKernelGGL(wgrad3_bf16_reduce_kernel, dim3(ew_grid(nz)), dim3(256), 0, sz, (const float*)workspace, dw, d->Cout,
+                       d->Cin, z.ci_blocks, z.npairs, z.nsplit, 64);
+    DRAM_LAUNCH_CHECK();
+    return DRAM_OK;
+  }
   WGeom g{};
   plan_wgrad(d, g);
   const size_t need = (size_t)g.nsplit * g.npairs * 27 * 2048 * sizeof(float);
@@ -565,7 +866,7 @@ extern "C" int dram_conv3d_bwd_weight_bf16(const void* x, const void* dy, float*
   const long n = (long)d->Cout * d->Cin * 27;
   DramProf prof(DRAM_FAM_WGRAD_BF16, 1, 0.0, 4.0 * (double)n * (g.nsplit + 1), s);
   hipLaunchKernelGGL(wgrad3_bf16_reduce_kernel, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)workspace, dw, d->Cout,
-                     d->Cin, g.ci_blocks, g.npairs, g.nsplit);
+                     d->Cin, g.ci_blocks, g.npairs, g.nsplit, 32);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

@@ -68,11 +68,20 @@ CASES = [
     (1, 6, 9, 11, 64, 32, 1),           # us3: 32 output columns (NB = 1); its data gradient has ONE 32-channel chunk
     (1, 4, 8, 8, 576, 64, 1),           # us1.0: 18 chunks
     (2, 4, 5, 6, 32, 96, 1),            # channel counts that are only multiples of 32
+    (1, 16, 16, 24, 64, 64, 1),         # 16 planes: the 8-wave (512-voxel) tiles, a long z walk
+    (2, 19, 9, 8, 128, 64, 2),          # ragged depth on a dilation lattice, two ci blocks
 ]
+# kernel variants: forward / data-gradient tile depth (4 or 8 waves), weight gradient z-walking or tiled
+VARIANTS = [("", ""), ("4", "tile"), ("8", "zwalk")]
 
 
+@pytest.mark.parametrize("nw,wg", VARIANTS, ids=["plan", "nw4-tile", "nw8-zwalk"])
 @pytest.mark.parametrize("case", CASES, ids=str)
-def test_conv3_bf16_fwd_dgrad_wgrad(ops, case):
+def test_conv3_bf16_fwd_dgrad_wgrad(ops, monkeypatch, case, nw, wg):
+    if nw:
+        monkeypatch.setenv("DRAM_BF16_NW", nw)
+    if wg:
+        monkeypatch.setenv("DRAM_BF16_WGRAD", wg)
     B, D, H, W, Cin, Cout, dil = case
     x = r16(rnd(B, Cin, D, H, W, seed=1)).requires_grad_(True)
     w32 = rnd(Cout, Cin, 3, 3, 3, seed=2) * 0.1
