@@ -307,6 +307,8 @@ def main():
     module = getattr(med3d, factory)(**kw).to(device).train()
     if args.dtype == "bf16":
         module.storage_dtype = torch.bfloat16
+    if args.config == 4:                     # BASELINE configs[4]: "... with activation checkpointing"
+        module.activation_recompute = True
     dctx = None
     if use_dist:
         from bodyct_dram_emph_subtype_amd import distributed as ddist

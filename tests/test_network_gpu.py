@@ -470,10 +470,12 @@ def test_inference_weight_cache_tracks_weight_identity_and_updates():
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("recompute", [False, True], ids=["keep", "recompute"])
-def test_config4_geometry_train_step_properties(recompute):
-    """BASELINE configs[4] geometry (resnet50segreg, 1x1x256x512x512 -- 8x the voxels of the headline shape; fp32
-    storage, no activation checkpointing: ~161 GB of HBM).  No CPU oracle finishes at this size, so the step is held
+@pytest.mark.parametrize("recompute,storage", [(False, "f32"), (True, "f32"), (True, "bf16")],
+                         ids=["keep", "recompute", "bf16-recompute"])
+def test_config4_geometry_train_step_properties(recompute, storage):
+    """BASELINE configs[4] geometry (resnet50segreg, 1x1x256x512x512 -- 8x the voxels of the headline shape): in fp32
+    storage without / with activation recompute (~182 / 131 GB of HBM) and AS SPECIFIED -- bf16 storage with
+    activation checkpointing (the per-GPU work of the 8-GPU job).  No CPU oracle finishes at this size, so the step is held
     to size-independent properties: finite loss and gradients for every parameter, dense maps inside [0, 1], the
     pooled scores equal to the lung-masked mean of the dense maps they come from (recomputed with torch from the
     returned volumes), BN running statistics moved, and a second identical step from the same state reproducing
@@ -485,6 +487,8 @@ def test_config4_geometry_train_step_properties(recompute):
     torch.manual_seed(0)
     m = med3d.resnet50segreg().to(DEV).train()
     m.activation_recompute = recompute
+    if storage == "bf16":
+        m.storage_dtype = torch.bfloat16
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
     g = torch.Generator(device=DEV).manual_seed(1234)
@@ -515,7 +519,7 @@ def test_config4_geometry_train_step_properties(recompute):
     for d, o in zip(dense, outs):
         assert float(d.min()) >= 0.0 and float(d.max()) <= 1.0      # sigmoid saturates to exactly 1.0 in fp32
         ref = (d.double() * lg).sum() / lg.double().sum()
-        assert abs(float(o) - float(ref)) < 1e-5 * abs(float(ref))
+        assert abs(float(o) - float(ref)) < 1e-5 * abs(float(ref))      # (the dense maps are fp32 on both storage paths)
     assert float((m.state_dict()["bn1.running_mean"] - sd0["bn1.running_mean"]).abs().max()) > 0
     peak = torch.cuda.max_memory_allocated() / 1e9
     del dense, outs
@@ -523,7 +527,7 @@ def test_config4_geometry_train_step_properties(recompute):
     assert torch.equal(loss, loss2)
     for n in grads:
         assert torch.equal(grads[n], grads2[n]), n
-    print(f"[configs[4] geometry, activation recompute {recompute}] loss {float(loss):.6f}, peak HBM {peak:.0f} GB")
+    print(f"[configs[4] geometry, {storage} storage, activation recompute {recompute}] loss {float(loss):.6f}, peak HBM {peak:.0f} GB")
 
 
 @pytest.mark.parametrize("factory,shape", [("resnet18segreg", (2, 1, 16, 32, 32)), ("resnet50segcls", (1, 1, 16, 32, 32)),
