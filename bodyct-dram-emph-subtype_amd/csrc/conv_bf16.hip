@@ -582,20 +582,225 @@ __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 1x1x1 convolutions (the Bottleneck blocks of ResNet-50, med3d.py:147-162) as plain bf16 GEMMs over the flat
+// voxel index.  All of them are HBM-bound (256->64 at 32x64x64: 84 MB moved for 4.3 GFLOP), so the tiles are simple:
+//   gemm1_bf16_kernel<NB, EPI>   y[m][n] = sum_k x[m][k] w[n][k]: 256 rows x 32 NB columns per workgroup (4 waves),
+//                                64-channel K chunks, A and W tiles double-buffered by LDS-DMA, 128-B rows swizzled
+//                                in 16-B slots by (row >> 1) & 7; epilogues as in conv3_bf16_kernel.
+//   wgrad1_bf16_kernel           dW[co][ci] = sum_m dy[m][co] x[m][ci]: a 64 x 64 (co, ci) block per workgroup, one
+//                                32 x 32 accumulator per wave, 256-voxel tiles of dy and x (two [voxel][64 B] images
+//                                each) double-buffered, transposed LDS reads; voxel splits -> slabs -> ordered reduce.
+struct G1Geom {
+  long M;              // voxels
+  int Cin, Cout;
+  int m_tiles, n_tiles, nblk;
+};
+
+template <int NB, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm1_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                            const bf16_t* __restrict__ add,
+                                                            const bf16_t* __restrict__ gate, bf16_t* __restrict__ y,
+                                                            float* __restrict__ stats, const G1Geom g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int WR = (32 * NB * 8 + 255) / 256;                  // weight DMA rounds per chunk
+  __shared__ __attribute__((aligned(1024))) unsigned char a0[32768];
+  __shared__ __attribute__((aligned(1024))) unsigned char a1[32768];
+  __shared__ __attribute__((aligned(1024))) unsigned char w0[WR * 4096];
+  __shared__ __attribute__((aligned(1024))) unsigned char w1[WR * 4096];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int L = xcd_remap(blockIdx.x, g.nblk);
+  const int nt = L % g.n_tiles, mt = L / g.n_tiles;
+  const long m0 = (long)mt * 256;
+  const int co0 = nt * 32 * NB;
+  const long xbytes = g.M * g.Cin * 2, wbytes = (long)g.Cout * g.Cin * 2;
+  unsigned aoff[8], woff[WR];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int p = i * 256 + tid, r = p >> 3, ps = p & 7;
+    aoff[i] = (m0 + r < g.M) ? (unsigned)(((m0 + r) * g.Cin + (ps ^ ((r >> 1) & 7)) * 8) * 2) : 0xffffffffu;
+  }
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    const int p = i * 256 + tid, r = p >> 3, ps = p & 7;
+    woff[i] = r < 32 * NB ? (unsigned)((((long)co0 + r) * g.Cin + (ps ^ ((r >> 1) & 7)) * 8) * 2) : 0xffffffffu;
+  }
+  auto issue = [&](int c, unsigned char* ab, unsigned char* wb) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(x, (long)c * 128, xbytes), rw = make_rsrc(w, (long)c * 128, wbytes);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) BUFLDS16(ra, aoff[i], ab + i * 4096 + wave * 1024);
+#pragma unroll
+    for (int i = 0; i < WR; ++i) BUFLDS16(rw, woff[i], wb + i * 4096 + wave * 1024);
+  };
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][nb][e] = 0.f;
+  const int arow = wave * 64 + li;
+  const int akey0 = (arow >> 1) & 7, akey1 = ((arow + 32) >> 1) & 7, bkey = (li >> 1) & 7;
+  const int nchunk = g.Cin / 64;
+  issue(0, a0, w0);
+  for (int c = 0; c < nchunk; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // chunk c is in LDS for every wave; the other stage is free
+    if (c + 1 < nchunk) {
+      if (c & 1) issue(c + 1, a0, w0);
+      else issue(c + 1, a1, w1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* al = (c & 1) ? a1 : a0;
+    const unsigned char* wl = (c & 1) ? w1 : w0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int sl = 2 * j + lh;
+      const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(al + arow * 128 + ((sl ^ akey0) << 4));
+      const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(al + (arow + 32) * 128 + ((sl ^ akey1) << 4));
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const bf16x8 bf = *reinterpret_cast<const bf16x8*>(wl + (nb * 32 + li) * 128 + ((sl ^ bkey) << 4));
+        acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, bf, acc[0][nb], 0, 0, 0);
+        acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, bf, acc[1][nb], 0, 0, 0);
+      }
+    }
+  }
+  float s1[NB], s2[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) { s1[nb] = 0.f; s2[nb] = 0.f; }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const long m = m0 + wave * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (m < g.M) {
+        const long o = m * g.Cout + co0 + li;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          float v = acc[mi][nb][e];
+          if (EPI == 1 && add) {
+            const float av = bf16_to_f32(add[o + nb * 32]);
+            v += gate ? (bf16_to_f32(gate[o + nb * 32]) > 0.f ? av : 0.f) : av;
+          }
+          const bf16_t hv = f32_to_bf16(v);
+          y[o + nb * 32] = hv;
+          if (EPI == 0) {
+            const float vr = bf16_to_f32(hv);
+            s1[nb] += vr;
+            s2[nb] += vr * vr;
+          }
+        }
+      }
+    }
+  if (EPI == 0 && stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(a0);   // [4 waves][2][32 NB]
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const float t1 = s1[nb] + __shfl_xor(s1[nb], 32, 64);
+      const float t2 = s2[nb] + __shfl_xor(s2[nb], 32, 64);
+      if (lh == 0) {
+        red[(wave * 2 + 0) * 32 * NB + nb * 32 + li] = t1;
+        red[(wave * 2 + 1) * 32 * NB + nb * 32 + li] = t2;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * 32 * NB) {
+      const int which = tid / (32 * NB), cc = tid % (32 * NB);
+      float v = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) v += red[(wv * 2 + which) * 32 * NB + cc];
+      stats[((long)mt * 2 + which) * g.Cout + co0 + cc] = v;
+    }
+  }
+#endif
+}
+
+struct W1Geom {
+  long M;
+  int Cin, Cout;
+  int ntile, nsplit, ci_blocks, co_blocks, npairs, nblk;
+};
+
+__global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                          float* __restrict__ slab, const W1Geom g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char d0[32768];   // dy tile: [2 cb][256 voxels][64 B]
+  __shared__ __attribute__((aligned(1024))) unsigned char d1[32768];
+  __shared__ __attribute__((aligned(1024))) unsigned char x0[32768];   // x tile:  [2 ib][256 voxels][64 B]
+  __shared__ __attribute__((aligned(1024))) unsigned char x1[32768];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = xcd_remap(blockIdx.x, g.nblk);
+  const int pair = L % g.npairs, split = L / g.npairs;
+  const int cib = pair % g.ci_blocks, cob = pair / g.ci_blocks;
+  const int cb = wave & 1, ib = wave >> 1;
+  const long xbytes = g.M * g.Cin * 2, dbytes = g.M * g.Cout * 2;
+  auto issue = [&](int t, unsigned char* db, unsigned char* xb) __attribute__((always_inline)) {
+    const long m0 = (long)t * 256;
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(dy, m0 * g.Cout * 2, dbytes), rx = make_rsrc(x, m0 * g.Cin * 2, xbytes);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                     // granule p -> (half, voxel, slot): byte p * 16 of the image pair
+      const int p = i * 256 + tid, hf = p >> 10, r = (p >> 2) & 255, sl = p & 3;
+      const int cd = cob * 64 + hf * 32 + sl * 8, cx = cib * 64 + hf * 32 + sl * 8;
+      const bool inr = m0 + r < g.M;
+      BUFLDS16(rd, (inr && cd < g.Cout) ? (unsigned)(((long)r * g.Cout + cd) * 2) : 0xffffffffu, db + i * 4096 + wave * 1024);
+      BUFLDS16(rx, (inr && cx < g.Cin) ? (unsigned)(((long)r * g.Cin + cx) * 2) : 0xffffffffu, xb + i * 4096 + wave * 1024);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int g4 = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3, h = g4 >> 1;
+  const int cpiece = ((g4 & 1) * 2 + (p4 >> 1)) * 16 + (p4 & 1) * 8;
+  const int lo0 = (h * 8 + q) * 64 + cpiece, lo1 = (h * 8 + 4 + q) * 64 + cpiece;
+  auto tr8 = [&](const unsigned char* base) __attribute__((always_inline)) {
+    const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + lo0));
+    const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + lo1));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+  int t = split, buf = 0;
+  if (t < g.ntile) issue(t, d0, x0);
+  for (; t < g.ntile; t += g.nsplit, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + g.nsplit < g.ntile) {
+      if (buf == 0) issue(t + g.nsplit, d1, x1);
+      else issue(t + g.nsplit, d0, x0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* db = (buf == 0 ? d0 : d1) + cb * 16384;
+    const unsigned char* xb = (buf == 0 ? x0 : x1) + ib * 16384;
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(db + ks * 1024), tr8(xb + ks * 1024), acc, 0, 0, 0);
+  }
+  const int li = lane & 31, lh = lane >> 5;
+  float* sb = slab + ((long)split * g.npairs + pair) * 4096;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+    sb[(cb * 32 + row) * 64 + ib * 32 + li] = acc[e];
+  }
+}
+
 // dw[co][ci][tap] = sum_split slab[split][pair(co / 64, ci / 32)][tap][co % 64][ci % 32], fixed order
 __global__ void wgrad3_bf16_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin,
-                                          int ci_blocks, int npairs, int nsplit, int cw /* ci block width: 32 | 64 */) {
-  const long n = (long)Cout * Cin * 27;
+                                          int ci_blocks, int npairs, int nsplit, int cw /* ci block width: 32 | 64 */,
+                                          int taps) {
+  const long n = (long)Cout * Cin * taps;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int ci = (int)(i % Cin);
     long r = i / Cin;
     const int co = (int)(r % Cout);
     const int tap = (int)(r / Cout);
     const int pair = (co >> 6) * ci_blocks + ci / cw;
-    const float* s = slab + ((long)pair * 27 + tap) * 64 * cw + (co & 63) * cw + ci % cw;
+    const float* s = slab + ((long)pair * taps + tap) * 64 * cw + (co & 63) * cw + ci % cw;
     float a = 0.f;
-    for (int k = 0; k < nsplit; ++k) a += s[(long)k * npairs * 27 * 64 * cw];
-    dw[((long)co * Cin + ci) * 27 + tap] = a;
+    for (int k = 0; k < nsplit; ++k) a += s[(long)k * npairs * taps * 64 * cw];
+    dw[((long)co * Cin + ci) * taps + tap] = a;
   }
 }
 
@@ -632,6 +837,17 @@ __global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __re
 inline int ew_grid(long total) {
   long b = (total + 255) / 256;
   return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+bool geom1_ok(const DramConvDesc* d) {       // 1x1x1, stride 1: a GEMM over the flat voxel index
+  if (!d) return false;
+  if (d->B < 1 || d->D < 1 || d->H < 1 || d->W < 1) return false;
+  if (d->k != 1 || d->stride != 1 || d->pad != 0) return false;
+  if (d->Do != d->D || d->Ho != d->H || d->Wo != d->W) return false;
+  if (d->Cin < 64 || d->Cout < 64 || d->Cin % 64 != 0 || d->Cout % 64 != 0) return false;
+  const long long vox = (long long)d->B * d->D * d->H * d->W;
+  const long long cmax = d->Cin > d->Cout ? d->Cin : d->Cout;
+  return vox * cmax < (1LL << 31);
 }
 
 bool geom_ok(const DramConvDesc* d) {
@@ -754,11 +970,48 @@ void plan_zwalk(const DramConvDesc* d, ZGeom& g) {
   g.nblk = g.npairs * g.nsplit;
 }
 
+int launch_gemm1(const bf16_t* x, const bf16_t* w, const bf16_t* add, const bf16_t* gate, bf16_t* y, float* stats,
+                 const DramConvDesc* d, int cin, int cout, int epi, hipStream_t s) {
+  G1Geom g{};
+  g.M = (long)d->B * d->D * d->H * d->W;
+  g.Cin = cin; g.Cout = cout;
+  g.m_tiles = (int)((g.M + 255) / 256);
+  const int nb = cout % 128 == 0 ? 4 : 2;
+  g.n_tiles = cout / (32 * nb);
+  g.nblk = g.m_tiles * g.n_tiles;
+  DramProf prof(DRAM_FAM_CONV_BF16, 8 + epi * 2 + (nb == 4), 2.0 * (double)g.m_tiles * 256.0 * cin * cout,
+                2.0 * ((double)g.M * (cin + cout * (1.0 + (add ? 1 : 0) + (gate ? 1 : 0))) + (double)cin * cout), s,
+                2.0 * (double)g.M * cin * cout);
+#define LAUNCH_(NB_, EPI_) \
+  hipLaunchKernelGGL((gemm1_bf16_kernel<NB_, EPI_>), dim3(g.nblk), dim3(256), 0, s, x, w, add, gate, y, stats, g)
+  if (epi == 0) { if (nb == 4) LAUNCH_(4, 0); else LAUNCH_(2, 0); }
+  else          { if (nb == 4) LAUNCH_(4, 1); else LAUNCH_(2, 1); }
+#undef LAUNCH_
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+void plan_wgrad1(const DramConvDesc* d, W1Geom& g) {
+  g.M = (long)d->B * d->D * d->H * d->W;
+  g.Cin = d->Cin; g.Cout = d->Cout;
+  g.ntile = (int)((g.M + 255) / 256);
+  g.ci_blocks = d->Cin / 64;
+  g.co_blocks = d->Cout / 64;
+  g.npairs = g.ci_blocks * g.co_blocks;
+  int ns = (1024 + g.npairs - 1) / g.npairs;
+  if (ns > g.ntile / 2) ns = g.ntile / 2;
+  if (ns > 256) ns = 256;
+  if (ns < 1) ns = 1;
+  g.nsplit = ns;
+  g.nblk = g.npairs * g.nsplit;
+}
+
 }  // namespace
 
-extern "C" int dram_conv_bf16_supported(const DramConvDesc* d) { return geom_ok(d) ? 1 : 0; }
+extern "C" int dram_conv_bf16_supported(const DramConvDesc* d) { return (geom_ok(d) || geom1_ok(d)) ? 1 : 0; }
 
 extern "C" int dram_conv_bf16_num_stat_rows(const DramConvDesc* d) {
+  if (geom1_ok(d)) return (int)(((long long)d->B * d->D * d->H * d->W + 255) / 256);
   if (!geom_ok(d)) return DRAM_ERR_UNSUPPORTED;
   int Tz, Ty, Tx;
   long long ntile;
@@ -800,6 +1053,11 @@ extern "C" int dram_cast_bf16_to_f32(const void* src, float* dst, long long n, d
 extern "C" int dram_conv3d_fwd_bf16(const void* x, const void* wf, const float* bias, void* y, float* stats_partial,
                                     const DramConvDesc* d, dram_stream_t stream) {
   if (!x || !wf || !y) return DRAM_ERR_BAD_ARG;
+  if (geom1_ok(d)) {
+    if (bias) return DRAM_ERR_UNSUPPORTED;             // the Bottleneck 1x1x1 convolutions carry no bias
+    return launch_gemm1((const bf16_t*)x, (const bf16_t*)wf, nullptr, nullptr, (bf16_t*)y, stats_partial, d, d->Cin,
+                        d->Cout, 0, (hipStream_t)stream);
+  }
   if (!geom_ok(d)) return DRAM_ERR_UNSUPPORTED;
   return launch_conv((const bf16_t*)x, (const bf16_t*)wf, bias, nullptr, nullptr, (bf16_t*)y, stats_partial, d, d->Cin,
                      d->Cout, 0, (hipStream_t)stream);
@@ -808,12 +1066,20 @@ extern "C" int dram_conv3d_fwd_bf16(const void* x, const void* wf, const float* 
 extern "C" int dram_conv3d_bwd_data_bf16(const void* dy, const void* wb, void* dx, const void* add, const void* gate,
                                          const DramConvDesc* d, dram_stream_t stream) {
   if (!dy || !wb || !dx || (gate && !add)) return DRAM_ERR_BAD_ARG;
+  if (geom1_ok(d))
+    return launch_gemm1((const bf16_t*)dy, (const bf16_t*)wb, (const bf16_t*)add, (const bf16_t*)gate, (bf16_t*)dx, nullptr,
+                        d, d->Cout, d->Cin, 1, (hipStream_t)stream);
   if (!geom_ok(d)) return DRAM_ERR_UNSUPPORTED;
   return launch_conv((const bf16_t*)dy, (const bf16_t*)wb, nullptr, (const bf16_t*)add, (const bf16_t*)gate, (bf16_t*)dx,
                      nullptr, d, d->Cout, d->Cin, 1, (hipStream_t)stream);
 }
 
 extern "C" size_t dram_conv3d_bwd_weight_bf16_workspace(const DramConvDesc* d) {
+  if (geom1_ok(d)) {
+    W1Geom w1{};
+    plan_wgrad1(d, w1);
+    return (size_t)w1.nsplit * w1.npairs * 4096 * sizeof(float);
+  }
   if (!geom_ok(d)) return 0;
   if (use_zwalk(d)) {
     ZGeom z{};
@@ -828,6 +1094,26 @@ extern "C" size_t dram_conv3d_bwd_weight_bf16_workspace(const DramConvDesc* d) {
 extern "C" int dram_conv3d_bwd_weight_bf16(const void* x, const void* dy, float* dw, const DramConvDesc* d,
                                            void* workspace, size_t workspace_bytes, dram_stream_t stream) {
   if (!x || !dy || !dw) return DRAM_ERR_BAD_ARG;
+  if (geom1_ok(d)) {
+    W1Geom w1{};
+    plan_wgrad1(d, w1);
+    const size_t need1 = (size_t)w1.nsplit * w1.npairs * 4096 * sizeof(float);
+    if (!workspace || workspace_bytes < need1) return DRAM_ERR_WORKSPACE;
+    hipStream_t s1 = (hipStream_t)stream;
+    {
+      DramProf prof(DRAM_FAM_WGRAD_BF16, 4, 2.0 * (double)w1.ntile * 256.0 * d->Cin * d->Cout,
+                    2.0 * (double)w1.M * (d->Cin + d->Cout) + 4.0 * d->Cin * d->Cout, s1, 2.0 * (double)w1.M * d->Cin * d->Cout);
+      hipLaunchKernelGGL(wgrad1_bf16_kernel, dim3(w1.nblk), dim3(256), 0, s1, (const bf16_t*)x, (const bf16_t*)dy,
+                         (float*)workspace, w1);
+      DRAM_LAUNCH_CHECK();
+    }
+    const long n1 = (long)d->Cout * d->Cin;
+    DramProf prof(DRAM_FAM_WGRAD_BF16, 5, 0.0, 4.0 * (double)n1 * (w1.nsplit + 1), s1);
+    hipLaunchKernelGGL(wgrad3_bf16_reduce_kernel, dim3(ew_grid(n1)), dim3(256), 0, s1, (const float*)workspace, dw, d->Cout,
+                       d->Cin, w1.ci_blocks, w1.npairs, w1.nsplit, 64, 1);
+    DRAM_LAUNCH_CHECK();
+    return DRAM_OK;
+  }
   if (!geom_ok(d)) return DRAM_ERR_UNSUPPORTED;
   if (use_zwalk(d)) {
     ZGeom z{};
@@ -846,7 +1132,7 @@ extern "C" int dram_conv3d_bwd_weight_bf16(const void* x, const void* dy, float*
     const long nz = (long)d->Cout * d->Cin * 27;
     DramProf prof(DRAM_FAM_WGRAD_BF16, 3, 0.0, 4.0 * (double)nz * (z.nsplit + 1), sz);
     hipLaunchKernelGGL(wgrad3_bf16_reduce_kernel, dim3(ew_grid(nz)), dim3(256), 0, sz, (const float*)workspace, dw, d->Cout,
-                       d->Cin, z.ci_blocks, z.npairs, z.nsplit, 64);
+                       d->Cin, z.ci_blocks, z.npairs, z.nsplit, 64, 27);
     DRAM_LAUNCH_CHECK();
     return DRAM_OK;
   }
@@ -866,7 +1152,7 @@ extern "C" int dram_conv3d_bwd_weight_bf16(const void* x, const void* dy, float*
   const long n = (long)d->Cout * d->Cin * 27;
   DramProf prof(DRAM_FAM_WGRAD_BF16, 1, 0.0, 4.0 * (double)n * (g.nsplit + 1), s);
   hipLaunchKernelGGL(wgrad3_bf16_reduce_kernel, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)workspace, dw, d->Cout,
-                     d->Cin, g.ci_blocks, g.npairs, g.nsplit, 32);
+                     d->Cin, g.ci_blocks, g.npairs, g.nsplit, 32, 27);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

