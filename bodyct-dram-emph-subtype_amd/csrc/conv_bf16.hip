@@ -109,6 +109,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3_bf16_kernel(const bf16_t* __
 
   // halo DMA sources: granule p = round * NT + tid -> voxel p / 4, physical slot p % 4 holding the logical slot
   // (p % 4) ^ ((hx >> 1) & 3)
+  // (offsets are relative to the first in-volume z plane the halo touches -- the descriptor starts there --, so
+  // only the halo's own window has to fit 32 bits, not the tensor: us1.0 of ResNet-50 at 256x512x512 reads 4.8 GB)
+  const int gz_first = (rz + g.d * (lz0 - 1)) < 0 ? rz : rz + g.d * (lz0 - 1);
+  const long xbase = (((long)b * g.D + (gz_first < g.D ? gz_first : 0)) * g.H * g.W) * g.Cin * 2;
   unsigned hoff[HROUNDS];
 #pragma unroll
   for (int i = 0; i < HROUNDS; ++i) {
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3_bf16_kernel(const bf16_t* __
     const int hz = hv / 100, hy = (hv / 10) % 10, hx = hv % 10;
     const int gz = rz + g.d * (lz0 + hz - 1), gy = ry + g.d * (ly0 + hy - 1), gx = rx + g.d * (lx0 + hx - 1);
     const bool ok = (hv < HV) & (gz >= 0) & (gz < g.D) & (gy >= 0) & (gy < g.H) & (gx >= 0) & (gx < g.W);
-    const long e = ((((long)b * g.D + gz) * g.H + gy) * g.W + gx) * g.Cin + (ps ^ ((hx >> 1) & 3)) * 8;
+    const long e = ((((long)(gz - gz_first)) * g.H + gy) * g.W + gx) * g.Cin + (ps ^ ((hx >> 1) & 3)) * 8;
     hoff[i] = ok ? (unsigned)(e * 2) : 0xffffffffu;
   }
   // weight DMA sources: granule q -> row q / 4 = kx * 32 NB + co, physical slot q % 4 = logical ^ ((co >> 2) & 3)
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3_bf16_kernel(const bf16_t* __
     woff[r] = row < WROWS ? (unsigned)((((long)kx * g.Cout + co0 + co) * g.Cin + (ps ^ ((co >> 2) & 3)) * 8) * 2) : 0xffffffffu;
   }
   auto issue_halo = [&](int c) __attribute__((always_inline)) {
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(x, (long)c * 64, xbytes);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(x, xbase + (long)c * 64, xbytes);
 #pragma unroll
     for (int i = 0; i < HROUNDS; ++i) BUFLDS16(rs, hoff[i], halo + i * (NT * 16) + wave * 1024);
   };
@@ -856,10 +860,11 @@ bool geom_ok(const DramConvDesc* d) {
   if (d->k != 3 || d->stride != 1 || d->dil < 1 || d->pad != d->dil) return false;
   if (d->Do != d->D || d->Ho != d->H || d->Wo != d->W) return false;
   if (d->Cin < 32 || d->Cout < 32 || d->Cin % 32 != 0 || d->Cout % 32 != 0) return false;
-  const long long vox = (long long)d->B * d->D * d->H * d->W;
+  // 32-bit byte offsets inside ONE halo window (10 z planes of the dilation lattice at most) and inside the weights;
+  // tensors themselves may exceed 4 GB (64-bit bases)
   const long long cmax = d->Cin > d->Cout ? d->Cin : d->Cout;
-  if (vox * cmax >= (1LL << 31)) return false;                          // 32-bit element offsets
-  if ((long long)d->Cout * d->Cin * 27 >= (1LL << 31)) return false;
+  if (10LL * d->dil * d->H * d->W * cmax * 2 >= (1LL << 32)) return false;
+  if ((long long)d->Cout * d->Cin * 27 * 2 >= (1LL << 32)) return false;
   return true;
 }
 
