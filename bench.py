@@ -74,19 +74,20 @@ FAMILY_DESC = {
     "wgrad_bf16": "wgrad3_bf16_kernel + reduce (bf16-storage weight gradient, transposed LDS operands, bf16 MFMA 32x32x16)",
 }
 # family -> key in profiles/r*_pmc_hbm_traffic.json
-TRAFFIC_KEY = {"conv_wino2d": "conv_wino2d", "wino_in": "wino_in", "wino_gemm_nn": "wino_gemm_nn",
+TRAFFIC_KEY = {"conv_bf16": "conv_bf16", "wgrad_bf16": "wgrad_bf16", "conv_wino2d": "conv_wino2d", "wino_in": "wino_in", "wino_gemm_nn": "wino_gemm_nn",
                "wino_out": "wino_out", "wino_gemm_tn": "wino_gemm_tn", "conv_wgrad_w2d": "conv_wgrad_w2d",
                "conv_igemm": "conv_igemm", "bn_elementwise": "bn_elementwise", "stem": "stem"}
 
 
-def measured_traffic():
+def measured_traffic(config=1):
     """HBM bytes per launch per family from the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
     runs, guide's gfx950 corrections; tools/profile_round.sh + tools/summarize_profile.py), recorded for
     config 1.  PMC counters cannot be read from inside bench.py, so the file carries the fingerprint of the
     kernel sources it was measured on and is IGNORED (traffic = null) when the sources differ."""
     import glob
     from bodyct_dram_emph_subtype_amd import _build
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    sfx = "" if config == 1 else f"_config{config}"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic{sfx}.json")))
     for path in reversed(files):
         try:
             with open(path) as f:
@@ -457,7 +458,8 @@ def main():
         if timeline:
             fams = timeline.families()
             rows = family_table(fams, args.steps, tl_step_s)
-            traffic, tsrc = measured_traffic() if args.config == 1 else (None, None)
+            default_dtype = "bf16" if args.config in BF16_CONFIGS else "f32"
+            traffic, tsrc = measured_traffic(args.config) if (args.config in (1, 2) and args.dtype == default_dtype) else (None, None)
             for name, row in rows.items():
                 key = TRAFFIC_KEY.get(name)
                 row["traffic"] = float(traffic[key]["total"]) if (traffic and key in traffic) else None

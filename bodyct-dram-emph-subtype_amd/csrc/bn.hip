@@ -283,6 +283,86 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restric
   }
 }
 
+// bn_bwd_apply for channel counts whose quad count divides the block size: the thread's channel quad is fixed, so the
+// per-channel constants (mean, invstd, gamma, the two batch means -- double multiplies in the generic kernel, per
+// element) live in registers, there is no 64-bit modulo per element, and two elements are in flight per thread.
+// Same expression per element as bn_bwd_apply_kernel (bit-identical results).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const T* __restrict__ dz, const T* __restrict__ z,
+                                                                const T* __restrict__ y, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
+                                                                const double* __restrict__ sums, double inv_count_host,
+                                                                const double* __restrict__ count_dev,
+                                                                T* __restrict__ dy, int C, long total4, int relu,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                float* __restrict__ colpart) {
+  const int Q = C >> 2;
+  const int c = 4 * (threadIdx.x % Q);
+  const double inv_count = count_dev ? 1.0 / *count_dev : inv_count_host;
+  const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+  const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+  float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+  if (relu && !z) {
+    sc = *reinterpret_cast<const float4*>(scale + c);
+    sh = *reinterpret_cast<const float4*>(shift + c);
+  }
+  const float4 mg = make_float4((float)(sums[c] * inv_count), (float)(sums[c + 1] * inv_count),
+                                (float)(sums[c + 2] * inv_count), (float)(sums[c + 3] * inv_count));
+  const float4 mgx = make_float4((float)(sums[C + c] * inv_count), (float)(sums[C + c + 1] * inv_count),
+                                 (float)(sums[C + c + 2] * inv_count), (float)(sums[C + c + 3] * inv_count));
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long stride = (long)gridDim.x * 256;
+  for (long i0 = blockIdx.x * 256L + threadIdx.x; i0 < total4; i0 += 2 * stride) {
+    float4 g[2], yv[2], zv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long i = i0 + u * stride;
+      if (i < total4) {
+        g[u] = ld4<T>(dz, 4 * i);
+        yv[u] = ld4<T>(y, 4 * i);
+        if (relu && z) zv[u] = ld4<T>(z, 4 * i);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long i = i0 + u * stride;
+      if (i < total4) {
+        float4 gg = g[u];
+        if (relu) {
+          float4 m = zv[u];
+          if (!z) m = make_float4(__builtin_fmaf(yv[u].x, sc.x, sh.x), __builtin_fmaf(yv[u].y, sc.y, sh.y),
+                                  __builtin_fmaf(yv[u].z, sc.z, sh.z), __builtin_fmaf(yv[u].w, sc.w, sh.w));
+          gg.x = m.x > 0.f ? gg.x : 0.f; gg.y = m.y > 0.f ? gg.y : 0.f;
+          gg.z = m.z > 0.f ? gg.z : 0.f; gg.w = m.w > 0.f ? gg.w : 0.f;
+        }
+        float4 o;
+        o.x = ga.x * is.x * (gg.x - mg.x - ((yv[u].x - mu.x) * is.x) * mgx.x);
+        o.y = ga.y * is.y * (gg.y - mg.y - ((yv[u].y - mu.y) * is.y) * mgx.y);
+        o.z = ga.z * is.z * (gg.z - mg.z - ((yv[u].z - mu.z) * is.z) * mgx.z);
+        o.w = ga.w * is.w * (gg.w - mg.w - ((yv[u].w - mu.w) * is.w) * mgx.w);
+        st4<T>(dy, 4 * i, o);
+        cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
+      }
+    }
+  }
+  if (colpart) {
+    __shared__ float4 sm[256];
+    sm[threadIdx.x] = cs;
+    __syncthreads();
+    if ((int)threadIdx.x < Q) {
+      float4 t = sm[threadIdx.x];
+      for (int k = threadIdx.x + Q; k < 256; k += Q) {
+        const float4 u = sm[k];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      *reinterpret_cast<float4*>(colpart + (long)blockIdx.x * C + 4 * threadIdx.x) = t;
+    }
+  }
+}
+
 __global__ void add_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ o,
                            long n4, const float* __restrict__ as, const float* __restrict__ bs,
                            float* __restrict__ os, long n) {
@@ -475,9 +555,14 @@ static int bn_bwd_apply_impl(const T* dz, const T* z, const T* y, const float* m
   if (colsum_partial && dram_bn_bwd_apply_nparts(rows, C) < 1) return DRAM_ERR_UNSUPPORTED;
   const long total4 = (long)rows * (C >> 2);
   DramProf prof(DRAM_FAM_BN, 5, 0.0, 4.0 * sizeof(T) * (double)total4 * (relu && z ? 4.0 : 3.0), (hipStream_t)stream);
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dz, z, y, mean,
-                     invstd, gamma, sums, count_dev ? 0.0 : 1.0 / count, count_dev, dy, C, total4, relu, scale, shift,
-                     colsum_partial);
+  if (256 % (C >> 2) == 0)      // (same grid as the generic kernel: the colsum partial rows are one per block)
+    hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dz, z, y,
+                       mean, invstd, gamma, sums, count_dev ? 0.0 : 1.0 / count, count_dev, dy, C, total4, relu, scale,
+                       shift, colsum_partial);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dz, z, y, mean,
+                       invstd, gamma, sums, count_dev ? 0.0 : 1.0 / count, count_dev, dy, C, total4, relu, scale, shift,
+                       colsum_partial);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

@@ -12,7 +12,11 @@ cd $R
 python bench.py --steps 20 --warmup 5 > $O/bench_config1.json.log 2>$O/bench_config1.err
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --detail $O/bench_config1_per_layer.txt > $O/bench_config1_detail.json.log 2>/dev/null
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --timeline off > $O/bench_config1_no_timeline.json.log 2>/dev/null
-for c in 0 2 3; do python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config$c.json.log 2>/dev/null; done
+for c in 0 3 5; do python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config$c.json.log 2>/dev/null; done
+python bench.py --config 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_config2.json.log 2>/dev/null          # bf16, as specified
+python bench.py --config 2 --dtype f32 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config2_f32.json.log 2>/dev/null
+python bench.py --config 3 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config3_bf16.json.log 2>/dev/null
+python bench.py --config 4 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_config4.json.log 2>/dev/null           # bf16 + recompute
 cd /tmp && export TMPDIR=/tmp
 # the profiled passes run the step on ONE stream, like bench.py's timeline pass: with the weight-gradient kernels
 # overlapping the data-gradient chain on a second stream, per-kernel durations contain the time a kernel shared its
@@ -22,7 +26,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/b
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --timeline off > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --timeline off > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --timeline off > /dev/null 2>&1
+# the same four passes for BASELINE configs[2] as specified (bf16 storage path)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c2 -- python3 $R/bench.py --config 2 --steps 5 --warmup 2 --no-cpu-baseline --timeline off > $O/bench_config2_under_rocprofv3.json.log 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_c2 -- python3 $R/bench.py --config 2 --steps 3 --warmup 1 --no-cpu-baseline --timeline off > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_c2 -- python3 $R/bench.py --config 2 --steps 3 --warmup 1 --no-cpu-baseline --timeline off > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq_c2 -- python3 $R/bench.py --config 2 --steps 3 --warmup 1 --no-cpu-baseline --timeline off > /dev/null 2>&1
 # keep only the small csv files (kernel traces of the PMC passes are not needed)
 find $O -name "*agent_info.csv" -delete
-find $O/pmc_fetch $O/pmc_write $O/pmc_sq -name "*kernel_trace.csv" -delete
+find $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch_c2 $O/pmc_write_c2 $O/pmc_sq_c2 -name "*kernel_trace.csv" -delete
 ls -la $O $O/*/* | head -40
