@@ -58,6 +58,11 @@ __device__ __forceinline__ void decode_tile(int t, const CGeom& g, int& b, int& 
   lz0 = tzi * 4; ly0 = tyi * 8; lx0 = txi * 8;
 }
 
+// Ablation switch of the tuning builds (tools/conv_bf16_ablate.sh; 0 = the product): 1 no weight DMA, 2 no halo DMA,
+// 3 no LDS operand reads, 4 no MFMAs, 5 no epilogue stores, 6 no barriers.  Results are garbage in those builds.
+#ifndef DRAM_BF16_ABL
+#define DRAM_BF16_ABL 0
+#endif
 constexpr int HALO_GRAN = 2560;   // 6 x 10 x 10 voxels x 4 slots = 2400 16-B granules, padded to 10 x 256
 
 // LDS-DMA through a buffer descriptor: the per-lane source is a 32-bit BYTE offset held in a register for the whole
@@ -135,11 +140,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3_bf16_kernel(const bf16_t* __
   }
   auto issue_halo = [&](int c) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(x, xbase + (long)c * 64, xbytes);
+    if (DRAM_BF16_ABL == 2) return;
 #pragma unroll
     for (int i = 0; i < HROUNDS; ++i) BUFLDS16(rs, hoff[i], halo + i * (NT * 16) + wave * 1024);
   };
   auto issue_w = [&](int c, int gi, unsigned char* buf) __attribute__((always_inline)) {
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(w, ((long)(3 * gi) * g.Cout * g.Cin + c * 32) * 2, wbytes);
+    const __amdgpu_buffer_rsrc_t rs = DRAM_BF16_ABL == 8 ? make_rsrc(w, 0, wbytes)
+                                                          : make_rsrc(w, ((long)(3 * gi) * g.Cout * g.Cin + c * 32) * 2, wbytes);
+    if (DRAM_BF16_ABL == 1) return;
 #pragma unroll
     for (int r = 0; r < WROUNDS; ++r) BUFLDS16(rs, woff[r], buf + r * (NT * 16) + wave * 1024);
   };
@@ -175,9 +183,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3_bf16_kernel(const bf16_t* __
     issue_halo(c);
 #pragma unroll
     for (int gi = 0; gi < 9; ++gi) {
-      if (gi == 0 || (gi == 8 && last)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (DRAM_BF16_ABL == 1 || DRAM_BF16_ABL == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (DRAM_BF16_ABL == 7) { if (gi == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WROUNDS) : "memory"); }
+      else if (gi == 0 || (gi == 8 && last)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WROUNDS) : "memory");
-      __builtin_amdgcn_s_barrier();        // group gi's weights (gi == 0: and the halo) are in LDS for every wave;
+      if (DRAM_BF16_ABL != 6) __builtin_amdgcn_s_barrier();        // group gi's weights (gi == 0: and the halo) are in LDS for every wave;
                                            // slot (gi + 2) % 3, read during group gi - 1, is free
       // (group 0 refills at its END instead: the wait-count pass, which does not see the hand-placed wait, guards
       // the first halo read with its own vmcnt(0) and would wait for a refill issued in front of it)
@@ -192,6 +202,17 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3_bf16_kernel(const bf16_t* __
       bf16x8 af[2][2], bfr[2][NB];
       auto frag = [&](int st, int buf) __attribute__((always_inline)) {
         const int kx = st >> 1, j = st & 1;
+        if (DRAM_BF16_ABL == 3) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) af[buf][mi][e] = (__bf16)(float)(lane + st);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bfr[buf][nb][e] = (__bf16)(float)(lane - st);
+          return;
+        }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
           af[buf][mi] = *reinterpret_cast<const bf16x8*>(halo + abase[mi] + tapo + kx * 64 + (((2 * j + lh) ^ akey[kx]) << 4));
@@ -207,7 +228,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3_bf16_kernel(const bf16_t* __
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st & 1][mi], bfr[st & 1][nb], acc[mi][nb], 0, 0, 0);
+            if (DRAM_BF16_ABL == 4) acc[mi][nb][0] += (float)af[st & 1][mi][0] * (float)bfr[st & 1][nb][0];
+            else acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st & 1][mi], bfr[st & 1][nb], acc[mi][nb], 0, 0, 0);
         if (st + 1 < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2 + NB, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * NB, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -245,7 +267,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3_bf16_kernel(const bf16_t* __
             v += gate ? (bf16_to_f32(gate[o + nb * 32]) > 0.f ? av : 0.f) : av;
           }
           const bf16_t h = f32_to_bf16(v);
-          y[o + nb * 32] = h;
+          if (DRAM_BF16_ABL != 5 || v == 12345.f) y[o + nb * 32] = h;
           if (EPI == 0) {                  // BatchNorm sums of the values the next pass will read (the rounded ones)
             const float vr = bf16_to_f32(h);
             s1[nb] += vr;
@@ -875,10 +897,14 @@ void fill_tiles(const DramConvDesc* d, int& Tz, int& Ty, int& Tx, long long& nti
   ntile = (long long)d->B * d->dil * d->dil * d->dil * Tz * Ty * Tx;
 }
 
-// Tile depth of the forward / data-gradient kernel: 4 z-slices (256 voxels, two workgroups per CU).  The 8-slice
-// form (512 voxels, 8 waves, one workgroup per CU: half the LDS-DMA pieces per MFMA) measured 0-5 % SLOWER on every
-// layer of config 2 -- two independent workgroups hide each other's barriers and halo refills better than the
-// larger tile saves -- and is kept behind DRAM_BF16_NW=8 (tests run it).
+// Tile depth of the forward / data-gradient kernel: 4 z-slices (256 voxels, 4 waves, two workgroups per CU).
+// Measured alternatives (tools/conv_bf16_bench.py, config 2's layers, same box): 8 waves x 512 voxels with one
+// workgroup per CU (DRAM_BF16_NW=8, kept for A/B and tests): 0-5 % slower; 4 waves x 512 voxels with 16-channel
+// chunks, two workgroups per CU, 100 instead of 170 bytes of LDS fill per MFMA (tried in round 3, removed): +-1 %.
+// The kernel is POWER-bound on random data, not fill- or issue-bound: with all-zero activations (or weights) the
+// same launches run 14-28 % faster (layer4: 1.34 -> 1.65-1.77 PFLOP/s; BENCH_ZERO=act|w) -- the chip does not hold
+// its clock under dense random bf16 MFMA work, and an ablation that removes the weight DMA "gains" 40 % only because
+// it feeds zeros to the matrix pipe.
 int pick_nw(const DramConvDesc* d, int n_tiles) {
   (void)d; (void)n_tiles;
   if (const char* e = getenv("DRAM_BF16_NW")) {
@@ -898,7 +924,7 @@ int launch_conv(const bf16_t* x, const bf16_t* w, const float* bias, const bf16_
   long long ntile;
   const int nb = pick_nb(cout);
   g.n_tiles = cout / (32 * nb);
-  const int nw = pick_nw(d, g.n_tiles);
+  const int nw = pick_nw(d, g.n_tiles);                                 // tile depth in z-slices
   fill_tiles(d, g.Tz, g.Ty, g.Tx, ntile, nw);
   const long long nblk = ntile * g.n_tiles;
   if (nblk >= (1LL << 31)) return DRAM_ERR_UNSUPPORTED;

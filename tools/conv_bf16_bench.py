@@ -32,6 +32,10 @@ with ops.launch_scope(dev):
         x = torch.randn(g.in_shape, device=dev).bfloat16()
         dy = torch.randn(g.out_shape, device=dev).bfloat16()
         w = torch.randn(Cout, Cin, 3, 3, 3, device=dev) * 0.05
+        if os.environ.get("BENCH_ZERO") == "act":      # power / clock probe: all-zero operands toggle far fewer bits
+            x.zero_(); dy.zero_()
+        elif os.environ.get("BENCH_ZERO") == "w":
+            w.zero_()
         wf, wb = ops.pack_conv_weight(w, True, True, g, torch.bfloat16)
         fns = {"fwd": lambda: ops.conv3d_fwd_keep(x, wf, None, g, True, False),
                "dgrad": lambda: ops.conv3d_bwd_data(dy, wb, g),
