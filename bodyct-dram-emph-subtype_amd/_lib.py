@@ -119,6 +119,8 @@ SIGNATURES = {
     "dram_conv3d_bwd_weight_bf16": (I, [P, P, P, DP, P, SZ, P]),
     "dram_stem_fwd_bf16": (I, [P, P, P, P, I, I, I, I, P]),
     "dram_stem_bwd_weight_bf16": (I, [P, P, P, I, I, I, I, P, SZ, P]),
+    "dram_stem_fwd_bf16mm": (I, [P, P, P, P, I, I, I, I, P]),
+    "dram_stem_bwd_weight_bf16mm": (I, [P, P, P, I, I, I, I, P, SZ, P]),
     "dram_bn_apply_bf16": (I, [P, P, P, P, I, I, I, I, I, P, I, I, I, I, I, I, P]),
     "dram_bn_bwd_reduce_bf16": (I, [P, P, P, P, P, P, P, P, LL, I, I, P]),
     "dram_bn_bwd_apply_bf16": (I, [P, P, P, P, P, P, P, P, P, D, P, P, P, LL, I, I, P]),

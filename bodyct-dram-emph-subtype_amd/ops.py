@@ -638,8 +638,8 @@ def stem_fwd(x: Tensor, w: Tensor, want_stats: bool, out_dtype=torch.float32):
         nt = _L().dram_stem_num_tiles(B, Do, Ho, Wo)
         stats = torch.empty((nt, 2, 64), device=x.device, dtype=torch.float32)
     with _span("stem_fwd_kernel", 2.0 * B * Do * Ho * Wo * 64 * 343):
-        _chk(_fn("dram_stem_fwd", "_bf16" if out_dtype == BF16 else "")(_p(x), _p(w), _p(y), _p(stats), B, D, H, W, _stream()),
-             "dram_stem_fwd")
+        sfx = "" if out_dtype != BF16 else ("_bf16mm" if os.environ.get("DRAM_STEM_BF16", "1") != "0" else "_bf16")
+        _chk(_fn("dram_stem_fwd", sfx)(_p(x), _p(w), _p(y), _p(stats), B, D, H, W, _stream()), "dram_stem_fwd" + sfx)
     return y, stats
 
 
@@ -652,8 +652,10 @@ def stem_bwd_weight(x: Tensor, dy: Tensor, out: Optional[Tensor] = None) -> Tens
     dw = out if out is not None else torch.empty((64, 1, 7, 7, 7), device=x.device, dtype=torch.float32)
     _req(dw, "dw", shape=(64, 1, 7, 7, 7))
     with _span("stem_wgrad_kernel+reduce", 2.0 * dy.numel() * 343):
+        if sfx and os.environ.get("DRAM_STEM_BF16", "1") != "0":
+            sfx = "_bf16mm"                          # bf16 matrix cores (the "_bf16" form: fp32 MFMA on the up-cast dy)
         _chk(_fn("dram_stem_bwd_weight", sfx)(_p(x), _p(dy), _p(dw), B, D, H, W, _p(ws), nbytes, _stream()),
-             "dram_stem_bwd_weight")
+             "dram_stem_bwd_weight" + sfx)
     return dw
 
 

@@ -475,6 +475,12 @@ int dram_stem_fwd_bf16(const float* x, const float* w, void* y, float* stats_par
                        dram_stream_t stream);
 int dram_stem_bwd_weight_bf16(const float* x, const void* dy, float* dw, int B, int D, int H, int W, void* workspace,
                               size_t workspace_bytes, dram_stream_t stream);
+/* the same two on the bf16 matrix cores (input rounded to bf16 on its way into LDS, weights rounded per launch;
+ * same tile geometry, statistic rows and workspace as the fp32-MFMA forms above) */
+int dram_stem_fwd_bf16mm(const float* x, const float* w, void* y, float* stats_partial, int B, int D, int H, int W,
+                         dram_stream_t stream);
+int dram_stem_bwd_weight_bf16mm(const float* x, const void* dy, float* dw, int B, int D, int H, int W, void* workspace,
+                                size_t workspace_bytes, dram_stream_t stream);
 int dram_bn_apply_bf16(const void* y, const float* scale, const float* shift, const void* residual, int Dr, int Hr,
                        int Wr, int Cr, int rs, void* z, int B, int D, int H, int W, int C, int relu,
                        dram_stream_t stream);

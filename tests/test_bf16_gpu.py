@@ -170,7 +170,31 @@ def test_conv_bf16_fallback_geometries(ops, case):
     assert rel_l2(dw.cpu(), gw_ref) < 2e-5
 
 
-def test_elementwise_bf16_kernels_equal_fp32_kernels_on_upcast_operands(ops):
+def test_stem_bf16_matrix_core_kernels(ops):
+    """stem_bf16.hip: the 7x7x7 stride-2 stem on the bf16 matrix cores (input and weights rounded to bf16, fp32
+    accumulation) against the fp64 convolution of the same rounded operands: forward (bf16 store: 2e-3) with its
+    BatchNorm sums, weight gradient (fp32: 2e-5), ragged extents."""
+    for B, D, H, W in ((1, 16, 24, 24), (2, 9, 20, 35)):
+        x = r16(rnd(B, 1, D, H, W, seed=1))
+        w32 = rnd(64, 1, 7, 7, 7, seed=2) * 0.05
+        w = r16(w32).requires_grad_(True)
+        y_ref = F.conv3d(x.double(), w.double(), None, 2, 3)
+        gy = r16(rnd(*y_ref.shape, seed=3))
+        (gw_ref,) = torch.autograd.grad(y_ref, [w], gy.double())
+        xd = x[:, 0].contiguous().to(DEV)
+        y, stats = ops.stem_fwd(xd, w32.to(DEV), True, BF)
+        assert y.dtype == BF and rel_l2(nc(y), y_ref.detach()) < 2e-3
+        s = ops.reduce_partials(stats).cpu()
+        yr = nc(y).double()
+        assert torch.allclose(s[0], yr.sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(s[1], (yr * yr).sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+        dw = ops.stem_bwd_weight(xd, nd(gy))
+        assert rel_l2(dw.cpu(), gw_ref) < 2e-5
+        assert torch.equal(dw, ops.stem_bwd_weight(xd, nd(gy)))
+
+
+def test_elementwise_bf16_kernels_equal_fp32_kernels_on_upcast_operands(ops, monkeypatch):
+    monkeypatch.setenv("DRAM_STEM_BF16", "0")      # the fp32-MFMA stem with a bf16 store (the bf16-MFMA stem: test above)
     """Every element-wise kernel of the bf16 path is the SAME template as its fp32 form with a different storage
     type: run on bf16 tensors it must give, bit for bit, the fp32 kernel's result on the up-cast tensors rounded
     once to bf16 (fp32 outputs -- partial sums, dense maps -- must be bit-identical outright)."""
