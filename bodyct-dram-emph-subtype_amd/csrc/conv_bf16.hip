@@ -327,6 +327,7 @@ __global__ __launch_bounds__(512) void wgrad3_bf16_kernel(const bf16_t* __restri
   const CGeom cg{g.B, g.D, g.H, g.W, g.Cin, g.Cout, g.d, g.Tz, g.Ty, g.Tx, 1, 0};
 
   auto issue_tile = [&](int t, unsigned char* hb, unsigned char* db) __attribute__((always_inline)) {
+    if (DRAM_BF16_ABL == 11) return;
     int b, rz, ry, rx, lz0, ly0, lx0;
     decode_tile(t, cg, b, rz, ry, rx, lz0, ly0, lx0);
 #pragma unroll
@@ -409,11 +410,15 @@ __global__ __launch_bounds__(512) void wgrad3_bf16_kernel(const bf16_t* __restri
       const int zt = ks >> 2, yp = ks & 3;
       const unsigned char* da = db + (zt * 64 + yp * 16) * 128;            // voxel (zt, 2 yp, 0)
       const unsigned char* ha = hb + (zt * 100 + yp * 20) * 64;            // halo voxel (zt, 2 yp, 0)
-      const bf16x8 af = tr8(da, aoff[0], aoff[1]);
+      bf16x8 af;
+      if (DRAM_BF16_ABL == 12) { for (int e = 0; e < 8; ++e) af[e] = (__bf16)(float)(lane + ks); }
+      else af = tr8(da, aoff[0], aoff[1]);
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         if (i < ntap) {
-          const bf16x8 bfr = tr8(ha, boff[i][0], boff[i][1]);
+          bf16x8 bfr;
+          if (DRAM_BF16_ABL == 12) { for (int e = 0; e < 8; ++e) bfr[e] = (__bf16)(float)(lane - i); }
+          else bfr = tr8(ha, boff[i][0], boff[i][1]);
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
         }
       }
