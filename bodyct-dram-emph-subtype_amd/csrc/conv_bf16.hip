@@ -405,23 +405,36 @@ __global__ __launch_bounds__(512) void wgrad3_bf16_kernel(const bf16_t* __restri
     }
     const unsigned char* hb = buf == 0 ? halo0 : halo1;
     const unsigned char* db = buf == 0 ? dyt0 : dyt1;
-#pragma unroll 2
-    for (int ks = 0; ks < 16; ++ks) {
+    // The operand fragments of k16 step ks + 1 (one dy fragment, seven x fragments: 16 transposed reads) are issued
+    // while the seven MFMAs of step ks run.  Left to the compiler every MFMA waited for reads issued ONE MFMA
+    // earlier (32 cycles of cover for >100 cycles of LDS latency): 2.7x the matrix-pipe time per tile.  All seven
+    // accumulators are always fed (a wave with six taps feeds its seventh from tap 0 and never stores it).
+    bf16x8 afr[2], bq[2][7];
+    auto frag = [&](int ks, int bufi) __attribute__((always_inline)) {
       const int zt = ks >> 2, yp = ks & 3;
       const unsigned char* da = db + (zt * 64 + yp * 16) * 128;            // voxel (zt, 2 yp, 0)
       const unsigned char* ha = hb + (zt * 100 + yp * 20) * 64;            // halo voxel (zt, 2 yp, 0)
-      bf16x8 af;
-      if (DRAM_BF16_ABL == 12) { for (int e = 0; e < 8; ++e) af[e] = (__bf16)(float)(lane + ks); }
-      else af = tr8(da, aoff[0], aoff[1]);
+      if (DRAM_BF16_ABL == 12) {
+        for (int e = 0; e < 8; ++e) afr[bufi][e] = (__bf16)(float)(lane + ks);
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        if (i < ntap) {
-          bf16x8 bfr;
-          if (DRAM_BF16_ABL == 12) { for (int e = 0; e < 8; ++e) bfr[e] = (__bf16)(float)(lane - i); }
-          else bfr = tr8(ha, boff[i][0], boff[i][1]);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
-        }
+        for (int i = 0; i < 7; ++i)
+          for (int e = 0; e < 8; ++e) bq[bufi][i][e] = (__bf16)(float)(lane - i);
+        return;
       }
+      afr[bufi] = tr8(da, aoff[0], aoff[1]);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) bq[bufi][i] = tr8(ha, boff[i][0], boff[i][1]);
+    };
+    frag(0, 0);
+#pragma unroll 2
+    for (int ks = 0; ks < 16; ++ks) {
+      if (ks + 1 < 16) frag(ks + 1, (ks + 1) & 1);
+#pragma unroll
+      for (int i = 0; i < 7; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks & 1], bq[ks & 1][i], acc[i], 0, 0, 0);
+      if (ks + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -572,20 +585,29 @@ __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restr
           if (z + 1 < z1 - z0) issue_d(z0 + z + 1, DRING_(u + 1));
           __builtin_amdgcn_sched_barrier(0);
           const unsigned char* dl = DRING_(u);
+          // x fragments are read TWO taps (four MFMAs, 128 cycles: the LDS latency) ahead of their use; all seven
+          // tap slots are always fed (a wave with six taps feeds the seventh from tap 0 and never stores it)
 #pragma unroll 1
           for (int ks = 0; ks < 4; ++ks) {
             const bf16x8 a0 = tr8(dl + ks * 1024, a_lane[0], a_lane[1]);
             const bf16x8 a1 = tr8(dl + 4096 + ks * 1024, a_lane[0], a_lane[1]);
+            bf16x8 bq[7];
+            auto bfrag = [&](int i) __attribute__((always_inline)) {
+              // x plane z + kz - 1 lives in slot (u + kz) & 3 (named arrays: see RING_ in conv3_bf16_kernel)
+              const unsigned char* xb = tapkz[i] == 0 ? XRING_(u) : (tapkz[i] == 1 ? XRING_(u + 1) : XRING_(u + 2));
+              bq[i] = tr8(xb + ks * 1280 + tapoff[i], b_lane[0], b_lane[1]);
+            };
+            bfrag(0);
+            bfrag(1);
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
-              if (i < ntap) {
-                // x plane z + kz - 1 lives in slot (z + kz) & 3 = (u + kz) & 3
-                const unsigned char* xl = tapkz[i] == 0 ? XRING_(u) : (tapkz[i] == 1 ? XRING_(u + 1) : XRING_(u + 2));
-                const bf16x8 bfr = tr8(xl + ks * 1280 + tapoff[i], b_lane[0], b_lane[1]);
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr, acc[i][1], 0, 0, 0);
-              }
+              if (i + 2 < 7) bfrag(i + 2);
+              acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[i], acc[i][0], 0, 0, 0);
+              acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[i], acc[i][1], 0, 0, 0);
+              if (i + 2 < 7) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
