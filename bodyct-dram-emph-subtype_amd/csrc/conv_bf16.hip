@@ -73,7 +73,8 @@ constexpr int HALO_GRAN = 2560;   // 6 x 10 x 10 voxels x 4 slots = 2400 16-B gr
   __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc_), (__attribute__((address_space(3))) void*)(dst_), 16, (voff_), 0, 0, 0)
 constexpr int BUF_FLAGS = 0x00020000;   // raw buffer, 32-bit data format
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long off_bytes, long total_bytes) {
-  const long left = total_bytes - off_bytes;
+  long left = total_bytes - off_bytes;
+  if (left < 0 || off_bytes < 0) { left = 0; off_bytes = 0; }       // a window wholly outside the tensor: empty descriptor
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + off_bytes, 0,
                                            (int)(left > 0xffffffffL ? 0xffffffffL : left), BUF_FLAGS);
 }
@@ -326,32 +327,55 @@ __global__ __launch_bounds__(512) void wgrad3_bf16_kernel(const bf16_t* __restri
   const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_zero_page);
   const CGeom cg{g.B, g.D, g.H, g.W, g.Cin, g.Cout, g.d, g.Tz, g.Ty, g.Tx, 1, 0};
 
+  // Per-lane DMA geometry, fixed for the whole kernel: the halo voxel (hz, hy, hx) / tile voxel (vz, vy, vx) a granule
+  // belongs to and its byte offset relative to the tile's first z plane (32-bit; negative before that plane's first
+  // row is fine: such lanes are out of the volume and never used).  Per tile only the plane base (scalar, in the
+  // buffer descriptor) and the range tests remain -- the first version re-derived everything per tile with 64-bit
+  // arithmetic (~45 VALU instructions per 1-KB piece).
+  int hco[5], hrel[5], vco[4], vrel[4];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {              // halo: 2560 granules / 512 threads
+    const int p = i * 512 + tid;
+    const int hv = p >> 2, ps = p & 3;
+    const int hz = hv / 100, hy = (hv / 10) % 10, hx = hv % 10;
+    hco[i] = hv < 600 ? (hz << 16) | (hy << 8) | hx : -1;
+    hrel[i] = ((((hz - 1) * g.H + (hy - 1)) * g.W + (hx - 1)) * g.d * g.Cin + cib * 32 + (ps ^ ((hx >> 1) & 3)) * 8) * 2;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {              // dy tile: 256 voxels x 8 slots (64 co); slot ^= 4 * ((v >> 1) & 1)
+    const int q = i * 512 + tid;
+    const int v = q >> 3, ps = q & 7;
+    const int ch = cob * 64 + (ps ^ (((v >> 1) & 1) << 2)) * 8;
+    vco[i] = ch < g.Cout ? ((v >> 6) << 16) | (((v >> 3) & 7) << 8) | (v & 7) : -1;
+    vrel[i] = ((((v >> 6) * g.H + ((v >> 3) & 7)) * g.W + (v & 7)) * g.d * g.Cout + ch) * 2;
+  }
+  const long xbytes = (long)g.B * g.D * g.H * g.W * g.Cin * 2, dbytes = (long)g.B * g.D * g.H * g.W * g.Cout * 2;
   auto issue_tile = [&](int t, unsigned char* hb, unsigned char* db) __attribute__((always_inline)) {
     if (DRAM_BF16_ABL == 11) return;
     int b, rz, ry, rx, lz0, ly0, lx0;
     decode_tile(t, cg, b, rz, ry, rx, lz0, ly0, lx0);
+    // descriptor bases at the tile's origin voxel (rz + d lz0, ry + d ly0, rx + d lx0): always inside the tensor's
+    // address range for tiles that exist; lanes whose voxel is outside the volume get the out-of-range offset
+    const int oz = rz + g.d * lz0, oy = ry + g.d * ly0, ox = rx + g.d * lx0;
+    const long org = (((long)b * g.D + oz) * g.H + oy) * g.W + ox;
+    // (the halo starts one lattice step BEFORE the origin: offsets are taken from a base moved back by the largest
+    // negative reach, (H W + W + 1) d voxels, clamped into the tensor, and corrected per lane by the same amount)
+    const long back = ((long)g.H * g.W + g.W + 1) * g.d;
+    const long hb0 = org - back < 0 ? 0 : org - back;
+    const int hshift = (int)((org - hb0) * g.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rh = make_rsrc(x, hb0 * g.Cin * 2, xbytes), rd = make_rsrc(dy, org * g.Cout * 2, dbytes);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {              // halo: 2560 granules / 512 threads
-      const int p = i * 512 + tid;
-      const int hv = p >> 2, ps = p & 3;
-      const int hz = hv / 100, hy = (hv / 10) % 10, hx = hv % 10;
-      const int gz = rz + g.d * (lz0 + hz - 1), gy = ry + g.d * (ly0 + hy - 1), gx = rx + g.d * (lx0 + hx - 1);
-      const bool ok = (hv < 600) & (gz >= 0) & (gz < g.D) & (gy >= 0) & (gy < g.H) & (gx >= 0) & (gx < g.W);
-      const long off = ((((long)b * g.D + gz) * g.H + gy) * g.W + gx) * g.Cin + cib * 32 + (ps ^ ((hx >> 1) & 3)) * 8;
-      const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(x + off) : zero;
-      GLDS16(src, hb + i * 8192 + wave * 1024);
+    for (int i = 0; i < 5; ++i) {
+      const int hz = hco[i] >> 16, hy = (hco[i] >> 8) & 255, hx = hco[i] & 255;
+      const int gz = oz + g.d * (hz - 1), gy = oy + g.d * (hy - 1), gx = ox + g.d * (hx - 1);
+      const bool ok = (hco[i] >= 0) & (gz >= 0) & (gz < g.D) & (gy >= 0) & (gy < g.H) & (gx >= 0) & (gx < g.W);
+      BUFLDS16(rh, ok ? (unsigned)(hrel[i] + hshift) : 0xffffffffu, hb + i * 8192 + wave * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {              // dy tile: 256 voxels x 8 slots (64 co); slot ^= 4 * ((v >> 1) & 1)
-      const int q = i * 512 + tid;
-      const int v = q >> 3, ps = q & 7;
-      const int slot = ps ^ (((v >> 1) & 1) << 2);
-      const int gz = rz + g.d * (lz0 + (v >> 6)), gy = ry + g.d * (ly0 + ((v >> 3) & 7)), gx = rx + g.d * (lx0 + (v & 7));
-      const int ch = cob * 64 + slot * 8;
-      const bool ok = (gz < g.D) & (gy < g.H) & (gx < g.W) & (ch < g.Cout);
-      const long off = ((((long)b * g.D + gz) * g.H + gy) * g.W + gx) * g.Cout + ch;
-      const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(dy + off) : zero;
-      GLDS16(src, db + i * 8192 + wave * 1024);
+    for (int i = 0; i < 4; ++i) {
+      const int vz = vco[i] >> 16, vy = (vco[i] >> 8) & 255, vx = vco[i] & 255;
+      const bool ok = (vco[i] >= 0) & (oz + g.d * vz < g.D) & (oy + g.d * vy < g.H) & (ox + g.d * vx < g.W);
+      BUFLDS16(rd, ok ? (unsigned)vrel[i] : 0xffffffffu, db + i * 8192 + wave * 1024);
     }
   };
 
@@ -840,20 +864,30 @@ __global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const bf16_t* __restri
 }
 
 // dw[co][ci][tap] = sum_split slab[split][pair(co / 64, ci / 32)][tap][co % 64][ci % 32], fixed order
+// dw[co][ci][tap] = sum_split slab[split][pair][tap][co % 64][ci % cw], fixed order (deterministic).
+// PER_PAIR: one thread per (co, ci) -- its `taps` results are contiguous in dw and, for a fixed tap, neighbouring
+// threads read neighbouring slab floats: both sides coalesced (wide layers: 512 x 512 x 27 results, few slabs).
+// Otherwise one thread per result (narrow layers: few (co, ci) pairs, many slabs -- the serial sum must be short).
+template <bool PER_PAIR>
 __global__ void wgrad3_bf16_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin,
                                           int ci_blocks, int npairs, int nsplit, int cw /* ci block width: 32 | 64 */,
                                           int taps) {
-  const long n = (long)Cout * Cin * taps;
+  const long sstride = (long)npairs * taps * 64 * cw;
+  const long n = PER_PAIR ? (long)Cout * Cin : (long)Cout * Cin * taps;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int ci = (int)(i % Cin);
-    long r = i / Cin;
+    const long r = i / Cin;
     const int co = (int)(r % Cout);
-    const int tap = (int)(r / Cout);
     const int pair = (co >> 6) * ci_blocks + ci / cw;
-    const float* s = slab + ((long)pair * taps + tap) * 64 * cw + (co & 63) * cw + ci % cw;
-    float a = 0.f;
-    for (int k = 0; k < nsplit; ++k) a += s[(long)k * npairs * taps * 64 * cw];
-    dw[((long)co * Cin + ci) * taps + tap] = a;
+    const float* s0 = slab + (long)pair * taps * 64 * cw + (co & 63) * cw + ci % cw;
+    float* o = dw + ((long)co * Cin + ci) * taps;
+    const int t_lo = PER_PAIR ? 0 : (int)(r / Cout), t_hi = PER_PAIR ? taps : t_lo + 1;
+    for (int tap = t_lo; tap < t_hi; ++tap) {
+      const float* s = s0 + (long)tap * 64 * cw;
+      float a = 0.f;
+      for (int k = 0; k < nsplit; ++k) a += s[k * sstride];
+      o[tap] = a;
+    }
   }
 }
 
@@ -912,7 +946,7 @@ bool geom_ok(const DramConvDesc* d) {
   // 32-bit byte offsets inside ONE halo window (10 z planes of the dilation lattice at most) and inside the weights;
   // tensors themselves may exceed 4 GB (64-bit bases)
   const long long cmax = d->Cin > d->Cout ? d->Cin : d->Cout;
-  if (10LL * d->dil * d->H * d->W * cmax * 2 >= (1LL << 32)) return false;
+  if (10LL * d->dil * d->H * d->W * cmax * 2 >= (1LL << 31)) return false;
   if ((long long)d->Cout * d->Cin * 27 * 2 >= (1LL << 32)) return false;
   return true;
 }
@@ -981,8 +1015,12 @@ void plan_wgrad(const DramConvDesc* d, WGeom& g) {
   g.ci_blocks = d->Cin / 32;
   g.co_blocks = (d->Cout + 63) / 64;
   g.npairs = g.ci_blocks * g.co_blocks;
-  // ~4 workgroups per CU in total, every split at least 2 tiles deep (double buffering), at most 256 slabs
-  int ns = (1024 + g.npairs - 1) / g.npairs;
+  // one workgroup per CU in total (147 KB of LDS: one is resident), every split at least 2 tiles deep (double
+  // buffering), at most 256 slabs: a slab is 27 x 2048 floats per (pair, split) and the reduce reads them all
+  // (512 -> 512 @ 2x16x32x32, ms: 1024 workgroups 0.69, 512 0.55, 256 0.56; 256 -> 256: 0.40 / 0.26 / 0.19)
+  // ... and 576 -> 64 @ 2x32x64x64 (1,024 tiles, 18 pairs): 0.73 / - / 0.93 -- large volumes want the finer split
+  const int wgs = getenv("DRAM_BF16_WGRAD_WGS") ? atoi(getenv("DRAM_BF16_WGRAD_WGS")) : (g.ntile >= 512 ? 1024 : 256);
+  int ns = (wgs + g.npairs - 1) / g.npairs;
   if (ns > g.ntile / 2) ns = g.ntile / 2;
   if (ns > 256) ns = 256;
   if (ns < 1) ns = 1;
@@ -995,6 +1033,17 @@ void plan_wgrad(const DramConvDesc* d, WGeom& g) {
 // 576->64 @ 32x64x64 0.79 / 1.10 (nine ci blocks re-read every dy plane) and the 16x32x32 stages 0.076-0.70 /
 // 0.12-0.76 (columns of 4-16 planes: the walk never leaves its prologue).  So: walk deep lattices with few
 // channel-block pairs, tile the rest.  DRAM_BF16_WGRAD = tile | zwalk forces one (A/B, tests).
+void launch_reduce(const float* slab, float* dw, int Cout, int Cin, int ci_blocks, int npairs, int nsplit, int cw, int taps,
+                   hipStream_t s) {
+  const long pairs = (long)Cout * Cin;
+  if (taps > 1 && pairs >= 65536)
+    hipLaunchKernelGGL((wgrad3_bf16_reduce_kernel<true>), dim3(ew_grid(pairs)), dim3(256), 0, s, slab, dw, Cout, Cin,
+                       ci_blocks, npairs, nsplit, cw, taps);
+  else
+    hipLaunchKernelGGL((wgrad3_bf16_reduce_kernel<false>), dim3(ew_grid(pairs * taps)), dim3(256), 0, s, slab, dw, Cout,
+                       Cin, ci_blocks, npairs, nsplit, cw, taps);
+}
+
 bool use_zwalk(const DramConvDesc* d) {
   if (d->Cin % 64 != 0) return false;
   const char* e = getenv("DRAM_BF16_WGRAD");
@@ -1167,8 +1216,7 @@ extern "C" int dram_conv3d_bwd_weight_bf16(const void* x, const void* dy, float*
     }
     const long n1 = (long)d->Cout * d->Cin;
     DramProf prof(DRAM_FAM_WGRAD_BF16, 5, 0.0, 4.0 * (double)n1 * (w1.nsplit + 1), s1);
-    hipLaunchKernelGGL(wgrad3_bf16_reduce_kernel, dim3(ew_grid(n1)), dim3(256), 0, s1, (const float*)workspace, dw, d->Cout,
-                       d->Cin, w1.ci_blocks, w1.npairs, w1.nsplit, 64, 1);
+    launch_reduce((const float*)workspace, dw, d->Cout, d->Cin, w1.ci_blocks, w1.npairs, w1.nsplit, 64, 1, s1);
     DRAM_LAUNCH_CHECK();
     return DRAM_OK;
   }
@@ -1189,8 +1237,7 @@ extern "C" int dram_conv3d_bwd_weight_bf16(const void* x, const void* dy, float*
     }
     const long nz = (long)d->Cout * d->Cin * 27;
     DramProf prof(DRAM_FAM_WGRAD_BF16, 3, 0.0, 4.0 * (double)nz * (z.nsplit + 1), sz);
-    hipLaunchKernelGGL(wgrad3_bf16_reduce_kernel, dim3(ew_grid(nz)), dim3(256), 0, sz, (const float*)workspace, dw, d->Cout,
-                       d->Cin, z.ci_blocks, z.npairs, z.nsplit, 64, 27);
+    launch_reduce((const float*)workspace, dw, d->Cout, d->Cin, z.ci_blocks, z.npairs, z.nsplit, 64, 27, sz);
     DRAM_LAUNCH_CHECK();
     return DRAM_OK;
   }
@@ -1209,8 +1256,7 @@ extern "C" int dram_conv3d_bwd_weight_bf16(const void* x, const void* dy, float*
   }
   const long n = (long)d->Cout * d->Cin * 27;
   DramProf prof(DRAM_FAM_WGRAD_BF16, 1, 0.0, 4.0 * (double)n * (g.nsplit + 1), s);
-  hipLaunchKernelGGL(wgrad3_bf16_reduce_kernel, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)workspace, dw, d->Cout,
-                     d->Cin, g.ci_blocks, g.npairs, g.nsplit, 32, 27);
+  launch_reduce((const float*)workspace, dw, d->Cout, d->Cin, g.ci_blocks, g.npairs, g.nsplit, 32, 27, s);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

@@ -57,6 +57,9 @@ def build_parser() -> ArgumentParser:
     p.add_argument("--synthetic", default=1, type=int)
     p.add_argument("--seed", default=0, type=int)
     p.add_argument("--augment", default=0, type=int, help="1: GPU-side train-time augmentations (models.py:66-74)")
+    # Lightning Trainer flag the reference exposes through Trainer.add_argparse_args (train.py:46): "bf16" runs the
+    # step under autocast(bfloat16) there, the bf16 storage path here
+    p.add_argument("--precision", default="32", type=str, choices=("32", "bf16"))
     return p
 
 
@@ -153,6 +156,8 @@ def run_training_job(argv=None):
     torch.manual_seed(args.seed)
     module = (models.ScanRegLightningModule if "dram" in args.model_arch else models.ScanCLSLightningModule)(args)
     module = module.to(device)
+    if args.precision == "bf16":
+        module.model.storage_dtype = torch.bfloat16
     (optimizer,), (scheduler,) = module.configure_optimizers()
     start_epoch = 0
     found = find_checkpoint(ckp_path, args.ckp)

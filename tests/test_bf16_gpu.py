@@ -449,3 +449,43 @@ def test_config2_as_specified_full_size_bf16_vs_fp32_path():
     _, _, l16b, g16b, _ = step(BF)
     assert l16b == l16 and all(torch.equal(g16[n], g16b[n]) for n in g16)
     print(f"[config 2 as specified, bf16] loss {l16:.6f} (fp32 path {l32:.6f}); worst gradient distance to the fp32 path {worst}")
+
+
+def test_graphed_bf16_train_step_equals_eager():
+    """graph.GraphedTrainStep on the bf16 storage path: three replays of the captured step leave the weights, running
+    statistics and Adam state bit-identical to three eager steps (buffer-descriptor DMA, rings and slabs are all
+    plain stream work with host-side arguments fixed at capture)."""
+    from bodyct_dram_emph_subtype_amd import med3d
+    from bodyct_dram_emph_subtype_amd.graph import GraphedTrainStep
+    from bodyct_dram_emph_subtype_amd.models import cls_train_loss
+    from bodyct_dram_emph_subtype_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    batch = (torch.randn(2, 1, 16, 32, 32, generator=g).to(DEV), (torch.rand(2, 1, 16, 32, 32, generator=g) > 0.3).float().to(DEV),
+             torch.randint(0, 6, (2,), generator=g).to(DEV), torch.randint(0, 3, (2,), generator=g).to(DEV))
+    cw, pw = torch.full((6,), 1 / 6, device=DEV), torch.full((3,), 1 / 3, device=DEV)
+
+    def run(graphed):
+        torch.manual_seed(11)
+        m = med3d.resnet18segcls(n_classes=[6, 3]).to(DEV).train()
+        m.storage_dtype = BF
+        opt = FusedAdam(m.parameters(), lr=1e-3, capturable=True)
+        loss_fn = lambda i, l, c, p: cls_train_loss(m(i, l)[1], c, p, cw, pw)[0]      # noqa: E731
+        if graphed:
+            step = GraphedTrainStep(m, opt, loss_fn, batch, warmup=2)
+        else:
+            def step(*b):
+                opt.zero_grad(set_to_none=True)
+                loss = loss_fn(*b)
+                loss.backward()
+                opt.step()
+                return loss.detach()
+            step(*batch); step(*batch)
+        for _ in range(3):
+            loss = step(*batch).clone()
+        torch.cuda.synchronize()
+        return float(loss), {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    lg, sg = run(True)
+    le, se = run(False)
+    assert lg == le
+    for k in se:
+        assert torch.equal(sg[k], se[k]), k
