@@ -125,6 +125,40 @@ __global__ __launch_bounds__(256) void bn_apply_fast_kernel(const T* __restrict_
   }
 }
 
+// The same pass as ONE-SHOT blocks (common.h, ew_blocks): block b owns the 1024 channel quads [1024 b, 1024 (b + 1)),
+// four per thread 256 apart (the thread's channel quad stays fixed: 256 % Q == 0).  NT: streaming cache policy on the
+// tensor loads and stores.  Same expression per element (bit-identical results).
+template <int RES, typename T, bool NT>
+__global__ __launch_bounds__(256) void bn_apply_shot_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const T* __restrict__ res,
+                                                            T* __restrict__ z, int Q, long total4, int relu) {
+  const int q = threadIdx.x % Q;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + 4 * q);
+  const float4 sh = *reinterpret_cast<const float4*>(shift + 4 * q);
+  const long i0 = blockIdx.x * 1024L + threadIdx.x;
+  float4 v[4], rr[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long i = i0 + u * 256;
+    if (i < total4) {
+      v[u] = NT ? ld4s<T>(y, 4 * i) : ld4<T>(y, 4 * i);
+      if (RES == 1) rr[u] = NT ? ld4s<T>(res, 4 * i) : ld4<T>(res, 4 * i);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long i = i0 + u * 256;
+    if (i < total4) {
+      float4 o;
+      o.x = __builtin_fmaf(v[u].x, sc.x, sh.x); o.y = __builtin_fmaf(v[u].y, sc.y, sh.y);
+      o.z = __builtin_fmaf(v[u].z, sc.z, sh.z); o.w = __builtin_fmaf(v[u].w, sc.w, sh.w);
+      if (RES == 1) { o.x += rr[u].x; o.y += rr[u].y; o.z += rr[u].z; o.w += rr[u].w; }
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (NT) st4s<T>(z, 4 * i, o); else st4<T>(z, 4 * i, o);
+    }
+  }
+}
+
 // shortcut type A needs the residual tensor's own dims -> dedicated kernel
 template <typename T>
 __global__ void bn_apply_shortcut_a_kernel(const T* __restrict__ y, const float* __restrict__ scale,
@@ -287,7 +321,11 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restric
 // per-channel constants (mean, invstd, gamma, the two batch means -- double multiplies in the generic kernel, per
 // element) live in registers, there is no 64-bit modulo per element, and two elements are in flight per thread.
 // Same expression per element as bn_bwd_apply_kernel (bit-identical results).
-template <typename T>
+// SHOT 0: capped grid + grid-stride loop (needed when per-block column sums are asked for: the caller sized colpart by
+// dram_bn_bwd_apply_nparts); SHOT 1 / 2: one-shot blocks of 256 U quads (common.h, ew_blocks), 2 = streaming loads and
+// stores.  U elements in flight per thread: 2 for fp32, 4 for bf16 (half the bytes per element against the same
+// per-thread set-up of the channel constants).
+template <typename T, int SHOT, int U>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const T* __restrict__ dz, const T* __restrict__ z,
                                                                 const T* __restrict__ y, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd,
@@ -314,20 +352,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const T* __restr
   const float4 mgx = make_float4((float)(sums[C + c] * inv_count), (float)(sums[C + c + 1] * inv_count),
                                  (float)(sums[C + c + 2] * inv_count), (float)(sums[C + c + 3] * inv_count));
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-  const long stride = (long)gridDim.x * 256;
-  for (long i0 = blockIdx.x * 256L + threadIdx.x; i0 < total4; i0 += 2 * stride) {
-    float4 g[2], yv[2], zv[2];
+  const long stride = SHOT ? 256L : (long)gridDim.x * 256;
+  for (long i0 = blockIdx.x * (SHOT ? 256L * U : 256L) + threadIdx.x; i0 < total4; i0 += U * stride) {
+    float4 g[U], yv[U], zv[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
       const long i = i0 + u * stride;
       if (i < total4) {
-        g[u] = ld4<T>(dz, 4 * i);
-        yv[u] = ld4<T>(y, 4 * i);
-        if (relu && z) zv[u] = ld4<T>(z, 4 * i);
+        g[u] = SHOT == 2 ? ld4s<T>(dz, 4 * i) : ld4<T>(dz, 4 * i);
+        yv[u] = SHOT == 2 ? ld4s<T>(y, 4 * i) : ld4<T>(y, 4 * i);
+        if (relu && z) zv[u] = SHOT == 2 ? ld4s<T>(z, 4 * i) : ld4<T>(z, 4 * i);
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
       const long i = i0 + u * stride;
       if (i < total4) {
         float4 gg = g[u];
@@ -343,12 +381,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const T* __restr
         o.y = ga.y * is.y * (gg.y - mg.y - ((yv[u].y - mu.y) * is.y) * mgx.y);
         o.z = ga.z * is.z * (gg.z - mg.z - ((yv[u].z - mu.z) * is.z) * mgx.z);
         o.w = ga.w * is.w * (gg.w - mg.w - ((yv[u].w - mu.w) * is.w) * mgx.w);
-        st4<T>(dy, 4 * i, o);
+        if (SHOT == 2) st4s<T>(dy, 4 * i, o); else st4<T>(dy, 4 * i, o);
         cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
       }
     }
+    if (SHOT) break;
   }
-  if (colpart) {
+  if (SHOT == 0 && colpart) {
     __shared__ float4 sm[256];
     sm[threadIdx.x] = cs;
     __syncthreads();
@@ -441,14 +480,22 @@ static int bn_apply_impl(const T* y, const float* scale, const float* shift, con
   if (!y || !scale || !shift || !z || B < 1 || D < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
   const long total4 = (long)B * D * H * W * (C >> 2);
   hipStream_t s = (hipStream_t)stream;
-  const int grid = ew_grid(total4);
+  const int grid = ew_blocks(total4, 256, 4096);
   // y read, z written, residual read (identity: full size; shortcut A: 1/rs^3 of Cr/C of it)
   const double res_frac = !residual ? 0.0 : ((double)Cr / C) / ((double)rs * rs * rs);
   DramProf prof(DRAM_FAM_BN, 2, 0.0, 4.0 * sizeof(T) * (double)total4 * (2.0 + res_frac), s);
   const int Q = C >> 2;
   const bool identity = residual && rs == 1 && Cr == C && Dr == D && Hr == H && Wr == W;
   static const int ew_u = getenv("DRAM_EW_U") ? atoi(getenv("DRAM_EW_U")) : 4;      // A/B switch (tools/ew_bench.py)
-  if ((!residual || identity) && 256 % Q == 0 && ew_u > 0) {
+  if ((!residual || identity) && 256 % Q == 0 && ew_u > 0 && ew_shape() > 0) {
+    const int g1 = ew_blocks(total4, 1024, 0);
+#define BN_SHOT_(RES_, NT_) hipLaunchKernelGGL((bn_apply_shot_kernel<RES_, T, NT_>), dim3(g1), dim3(256), 0, s, y, scale, \
+                                               shift, residual, z, Q, total4, relu)
+    const bool nt = ew_stream(sizeof(T) * 4 * total4);
+    if (!residual) { if (nt) BN_SHOT_(0, true); else BN_SHOT_(0, false); }
+    else           { if (nt) BN_SHOT_(1, true); else BN_SHOT_(1, false); }
+#undef BN_SHOT_
+  } else if ((!residual || identity) && 256 % Q == 0 && ew_u > 0) {
     const long per = (total4 + 255) / 256;
     const int g2 = (int)((per + ew_u - 1) / ew_u < 8192 ? ((per + ew_u - 1) / ew_u < 1 ? 1 : (per + ew_u - 1) / ew_u) : 8192);
 #define BN_FAST_(RES_, U_) hipLaunchKernelGGL((bn_apply_fast_kernel<RES_, T, U_>), dim3(g2), dim3(256), 0, s, y, scale, shift, \
@@ -555,10 +602,17 @@ static int bn_bwd_apply_impl(const T* dz, const T* z, const T* y, const float* m
   if (colsum_partial && dram_bn_bwd_apply_nparts(rows, C) < 1) return DRAM_ERR_UNSUPPORTED;
   const long total4 = (long)rows * (C >> 2);
   DramProf prof(DRAM_FAM_BN, 5, 0.0, 4.0 * sizeof(T) * (double)total4 * (relu && z ? 4.0 : 3.0), (hipStream_t)stream);
-  if (256 % (C >> 2) == 0)      // (same grid as the generic kernel: the colsum partial rows are one per block)
-    hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dz, z, y,
-                       mean, invstd, gamma, sums, count_dev ? 0.0 : 1.0 / count, count_dev, dy, C, total4, relu, scale,
-                       shift, colsum_partial);
+  if (256 % (C >> 2) == 0) {   // (with column sums: same grid as the generic kernel, one partial row per block)
+#define BN_BWD_FAST_(SHOT_, U_, GRID_)                                                                                    \
+  hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<T, SHOT_, U_>), dim3(GRID_), dim3(256), 0, (hipStream_t)stream, dz, z, y,    \
+                     mean, invstd, gamma, sums, count_dev ? 0.0 : 1.0 / count, count_dev, dy, C, total4, relu, scale,     \
+                     shift, colsum_partial)
+    constexpr int U = sizeof(T) == 2 ? 4 : 2;
+    if (colsum_partial || ew_shape() == 0) BN_BWD_FAST_(0, 2, ew_grid(total4));
+    else if (ew_stream(sizeof(T) * 4 * total4)) BN_BWD_FAST_(2, U, ew_blocks(total4, 256 * U, 0));
+    else BN_BWD_FAST_(1, U, ew_blocks(total4, 256 * U, 0));
+#undef BN_BWD_FAST_
+  }
   else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dz, z, y, mean,
                        invstd, gamma, sums, count_dev ? 0.0 : 1.0 / count, count_dev, dy, C, total4, relu, scale, shift,
@@ -585,7 +639,7 @@ extern "C" int dram_add(const float* a, const float* b, float* out, long long n,
   if (!a || !b || !out || n < 1) return DRAM_ERR_BAD_ARG;
   const long n4 = ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0) ? n / 4 : 0;
   DramProf prof(DRAM_FAM_BN, 6, 0.0, 12.0 * (double)n, (hipStream_t)stream);
-  hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n4 > 0 ? n4 : (n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n4 > 0 ? n4 : (n + 3) / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)a, (const float4*)b, (float4*)out, n4, a, b, out, (long)n);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;

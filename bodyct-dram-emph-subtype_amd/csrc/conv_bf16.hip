@@ -921,10 +921,7 @@ __global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __re
     dst[i] = bf16_to_f32(src[i]);
 }
 
-inline int ew_grid(long total) {
-  long b = (total + 255) / 256;
-  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
-}
+inline int ew_grid(long total) { return ew_blocks(total, 256, 8192); }   // one-shot blocks (common.h)
 
 bool geom1_ok(const DramConvDesc* d) {       // 1x1x1, stride 1: a GEMM over the flat voxel index
   if (!d) return false;

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 // store phases no longer overlap: 2.7 TB/s where the smaller tilings reach the ~5.3 TB/s of a write-dominated
 // HBM stream.  Here a (tile, 64-channel block) is TWO units: unit hx keeps only the x points 3hx .. 3hx + 2
 // of every x row as it is loaded (108 live values); both units read the whole tile, the second from L1/L2.
-template <int MODE, int HX, bool SPLIT>
+template <int MODE, int HX, bool SPLIT, bool NT>
 __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float* __restrict__ o, const WinoGeom& g,
                                             const int C, const int c, const int lane, const int b, const int z0,
                                             const int y0, const int x0, const long plane) {
@@ -425,10 +425,14 @@ __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk)
-        o[((i * NJ + j) * NK + 3 * HX + kk) * plane] = SPLIT ? split_pack(v[i][j][kk], lane & 1) : v[i][j][kk];
+      {
+        const float val = SPLIT ? split_pack(v[i][j][kk], lane & 1) : v[i][j][kk];
+        if (NT) __builtin_nontemporal_store(val, o + ((i * NJ + j) * NK + 3 * HX + kk) * plane);
+        else o[((i * NJ + j) * NK + 3 * HX + kk) * plane] = val;
+      }
 }
 
-template <int MODE, bool SPLIT>
+template <int MODE, bool SPLIT, bool NT>
 __global__ __launch_bounds__(256, 2) void wino_in444_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                          const WinoGeom g, const int C) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -452,8 +456,8 @@ __global__ __launch_bounds__(256, 2) void wino_in444_kernel(const float* __restr
     }
     int b, z0, y0, x0;
     tile_origin(g, t, b, z0, y0, x0);
-    if (hx == 0) wino_half444<MODE, 0, SPLIT>(in, o, g, C, c, lane, b, z0, y0, x0, plane);
-    else wino_half444<MODE, 1, SPLIT>(in, o, g, C, c, lane, b, z0, y0, x0, plane);
+    if (hx == 0) wino_half444<MODE, 0, SPLIT, NT>(in, o, g, C, c, lane, b, z0, y0, x0, plane);
+    else wino_half444<MODE, 1, SPLIT, NT>(in, o, g, C, c, lane, b, z0, y0, x0, plane);
   }
 }
 
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void wino_in444_kernel(const float* __restr
 constexpr int WINO_TPB = 16;
 __constant__ float c_at4[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};   // A^T of F(4,3)
 
-template <int NZ, int NY, int NX>
+template <int NZ, int NY, int NX, bool NT>
 __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ mh, const float* __restrict__ bias,
                                                        const float* __restrict__ add, const float* __restrict__ gate,
                                                        float* __restrict__ out, float* __restrict__ stats,
@@ -497,7 +501,8 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-          for (int k = 0; k < NK; ++k) m[j][k] = sp[(j * NK + k) * plane];
+          for (int k = 0; k < NK; ++k)
+            m[j][k] = NT ? __builtin_nontemporal_load(sp + (j * NK + k) * plane) : sp[(j * NK + k) * plane];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) atz<NX>(m[j], p[j]);
 #pragma unroll
@@ -714,7 +719,8 @@ template <int NJ>
 __global__ __launch_bounds__(512) void wino_gemm_nn_kernel(const float* __restrict__ A, const float* __restrict__ Bw,
                                                            float* __restrict__ Y, const int Mpad, const int N,
                                                            const int K, const int m_tiles, const int n_tiles,
-                                                           const int nblk, const int npts, const GemmEpilogue ep) {
+                                                           const int nblk, const int npts, const GemmEpilogue ep,
+                                                           const int epi_lds) {
   constexpr int BN = 64 * NJ;
   constexpr int STAGE = (256 + BN) * 32;
   __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
@@ -808,6 +814,31 @@ __global__ __launch_bounds__(512) void wino_gemm_nn_kernel(const float* __restri
   }
 
   const bool fused = ep.bias || ep.add || ep.stats;       // uniform
+  if (NJ <= 2 && !fused && epi_lds) {     // (NJ = 4: the eight regions would not fit beside nothing: 139 KB)
+    // Plain store of the tile (every Winograd-domain GEMM of the pipeline): the 32x32 accumulator layout gives a lane
+    // ONE column, so direct stores are 32 dword stores per accumulator in 128-B pieces -- 64 vector-memory instructions
+    // per wave behind only 128 MFMAs when K = 64.  Each wave turns its 32 x 32 NJ half-tile through a private LDS
+    // region (row pitch 32 NJ + 8 floats: the two row groups of a write land in different bank halves) and stores
+    // 16 B per lane: a quarter of the store instructions, 128 NJ-byte pieces.
+    constexpr int P = 32 * NJ + 8;
+    __syncthreads();                                      // every wave is done with the last operand stage
+    float* reg = lds + wave * (32 * P);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) reg[((e & 3) + 8 * (e >> 2) + 4 * lh) * P + nj * 32 + li] = acc[mi][nj][e];
+#pragma unroll
+      for (int r = 0; r < 4 * NJ; ++r) {
+        const int idx = r * 64 + lane;
+        const int row = idx / (8 * NJ), cq = idx % (8 * NJ);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * P + 4 * cq);
+        *reinterpret_cast<f32x4*>(Yb + (long)(wm * 64 + mi * 32 + row) * N + wn * NJ * 32 + 4 * cq) = v;
+      }
+    }
+    return;
+  }
   float s1[NJ], s2[NJ], bv[NJ];
 #pragma unroll
   for (int nj = 0; nj < NJ; ++nj) {
@@ -1365,6 +1396,13 @@ bool plan_tn(const DramConvDesc* d, const WinoGeom& g, TnPlan& p) {
   return true;
 }
 
+// streaming (non-temporal) cache policy on the Winograd-domain images, which are written once and read once:
+// bit 0 the input transform's stores, bit 1 the output transform's loads   (DRAM_WINO_NT, A/B switch)
+int wino_nt() {
+  static const int v = getenv("DRAM_WINO_NT") ? atoi(getenv("DRAM_WINO_NT")) : 3;
+  return v;
+}
+
 int grid_for(long waves) {
   long b = (waves + 3) / 4;
   return (int)(b > 65536 ? 65536 : (b < 1 ? 1 : b));
@@ -1380,8 +1418,9 @@ int launch_wino_in(const float* src, float* dst, const WinoGeom& g, const int C,
                 4.0 * (in_elems + (double)g.npts * g.Tpad * C), s);
   static const int half = getenv("DRAM_WINO_HALF") ? atoi(getenv("DRAM_WINO_HALF")) : 1;   // A/B switch (tools)
   if (half && g.nz == 4 && g.ny == 4 && g.nx == 4) {
-    if (math) hipLaunchKernelGGL((wino_in444_kernel<MODE, true>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C);
-    else hipLaunchKernelGGL((wino_in444_kernel<MODE, false>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C);
+    if (math) hipLaunchKernelGGL((wino_in444_kernel<MODE, true, false>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C);
+    else if (wino_nt() & 1) hipLaunchKernelGGL((wino_in444_kernel<MODE, false, true>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C);
+    else hipLaunchKernelGGL((wino_in444_kernel<MODE, false, false>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C);
     DRAM_LAUNCH_CHECK();
     return DRAM_OK;
   }
@@ -1432,7 +1471,8 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
   }
 #define WNN(NJ_)                                                                                                   \
   hipLaunchKernelGGL((wino_gemm_nn_kernel<NJ_>), dim3(nblk), dim3(512), 0, s, A, U, Y, g.Tpad, N, K, m_tiles, n_tiles, \
-                     nblk, g.npts, ep)
+                     nblk, g.npts, ep, epi_lds)
+  static const int epi_lds = getenv("DRAM_WINO_EPI") ? atoi(getenv("DRAM_WINO_EPI")) : 1;      // A/B switch
   if (nj == 4) WNN(4);
   else if (nj == 2) WNN(2);
   else WNN(1);
@@ -1459,8 +1499,14 @@ int run_conv(const float* in, const float* U, const float* bias, const float* ad
   DramProf prof(DRAM_FAM_WINO_OUT, g.nz * 100 + g.ny * 10 + g.nx, 0.0,
                 4.0 * ((double)g.npts * g.Tpad * N + out_elems * (1 + (add ? 1 : 0) + (gate ? 1 : 0))), s);
 #define W_OUT(NZ_, NY_, NX_)                                                                                              \
-  hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_, NX_>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add, gate, out, stats, \
-                     g, N)
+  do {                                                                                                                    \
+    if (wino_nt() & 2)                                                                                                    \
+      hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_, NX_, true>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add, gate, \
+                         out, stats, g, N);                                                                               \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_, NX_, false>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add,     \
+                         gate, out, stats, g, N);                                                                         \
+  } while (0)
   WINO_TILING_DISPATCH(g, W_OUT);
 #undef W_OUT
   DRAM_LAUNCH_CHECK();

@@ -8,10 +8,8 @@
 
 namespace {
 
-inline int ew_grid(long total) {
-  long b = (total + 255) / 256;
-  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
-}
+// one-shot blocks (common.h, ew_blocks): each loop below then runs once per thread
+inline int ew_grid(long total) { return ew_blocks(total, 256, 8192); }
 
 // ------------------------------------------------------------------ max pool
 template <typename T>
