@@ -73,6 +73,37 @@ template <typename T> __device__ __forceinline__ void st1(T* p, long off, float 
 template <> __device__ __forceinline__ void st1<float>(float* p, long off, float v) { p[off] = v; }
 template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, long off, float v) { p[off] = f32_to_bf16(v); }
 
+// VW channels of one voxel per thread, 16 B when VW * sizeof(T) == 16 (fp32: 4, bf16: 8): the gather kernels of
+// pool_up.hip cost one address per lane and instruction whatever its width, so bf16 storage moves 8 channels per lane.
+template <int VW> struct fvec { float v[VW]; };
+template <typename T, int VW> __device__ __forceinline__ fvec<VW> ldv(const T* p, long off);
+template <> __device__ __forceinline__ fvec<4> ldv<float, 4>(const float* p, long off) {
+  const float4 t = *reinterpret_cast<const float4*>(p + off);
+  return fvec<4>{{t.x, t.y, t.z, t.w}};
+}
+template <> __device__ __forceinline__ fvec<4> ldv<bf16_t, 4>(const bf16_t* p, long off) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p + off);
+  return fvec<4>{{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                  __uint_as_float(u.y & 0xffff0000u)}};
+}
+template <> __device__ __forceinline__ fvec<8> ldv<bf16_t, 8>(const bf16_t* p, long off) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p + off);
+  return fvec<8>{{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                  __uint_as_float(u.y & 0xffff0000u), __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                  __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)}};
+}
+template <typename T, int VW> __device__ __forceinline__ void stv(T* p, long off, const fvec<VW>& a);
+template <> __device__ __forceinline__ void stv<float, 4>(float* p, long off, const fvec<4>& a) {
+  *reinterpret_cast<float4*>(p + off) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+template <> __device__ __forceinline__ void stv<bf16_t, 4>(bf16_t* p, long off, const fvec<4>& a) {
+  *reinterpret_cast<uint2*>(p + off) = make_uint2(pack2_bf16(a.v[0], a.v[1]), pack2_bf16(a.v[2], a.v[3]));
+}
+template <> __device__ __forceinline__ void stv<bf16_t, 8>(bf16_t* p, long off, const fvec<8>& a) {
+  *reinterpret_cast<uint4*>(p + off) = make_uint4(pack2_bf16(a.v[0], a.v[1]), pack2_bf16(a.v[2], a.v[3]),
+                                                  pack2_bf16(a.v[4], a.v[5]), pack2_bf16(a.v[6], a.v[7]));
+}
+
 // Streaming forms (non-temporal cache policy) for tensors a kernel touches exactly once: with one-shot blocks (below)
 // an element-wise pass moves 6.2 TB/s read+write instead of 4.6-5.0 (tools/stream_probe.hip).
 typedef float f32x4_nt __attribute__((ext_vector_type(4)));

@@ -4,6 +4,7 @@
 // align_corners=True) + crop_concat_5d (med3d.py:83-87, :39-48), F.interpolate at
 // models.py:438-441, and their autograd backward.  HBM-bound; float4 = 4 channels/lane.
 #include <stdlib.h>
+#include <initializer_list>
 #include "common.h"
 
 namespace {
@@ -12,20 +13,23 @@ namespace {
 inline int ew_grid(long total) { return ew_blocks(total, 256, 8192); }
 
 // ------------------------------------------------------------------ max pool
-template <typename T>
+// A thread owns VW channels of one voxel (VW * sizeof(T) = 16 B where the channel count allows: common.h, fvec).
+template <typename T, int VW>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                    uint8_t* __restrict__ amax, int D, int H, int W, int C, int Do, int Ho, int Wo,
-                                   long total4) {
-  const int Q = C >> 2;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+                                   long total) {
+  const int Q = C / VW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i % Q);
     long v = i / Q;
     const int xo = (int)(v % Wo); v /= Wo;
     const int yo = (int)(v % Ho); v /= Ho;
     const int zo = (int)(v % Do);
     const long b = v / Do;
-    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    int ax = 0, ay = 0, az = 0, aw = 0;
+    fvec<VW> m;
+    int am[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) { m.v[k] = -INFINITY; am[k] = 0; }
     bool first = true;
     // scan order kd, kh, kw; strict '>' keeps the first maximum (ATen max_pool3d semantics).  The nine taps of a
     // plane are loaded together (clamped coordinates, validity flags) -- a guarded load per tap is waited for
@@ -33,7 +37,7 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
     for (int kz = 0; kz < 3; ++kz) {
       const int zi = 2 * zo - 1 + kz;
       if (zi < 0 || zi >= D) continue;
-      float4 t[3][3];
+      fvec<VW> t[3][3];
       bool ok[3][3];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
@@ -42,50 +46,57 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
           const int yi = 2 * yo - 1 + ky, xi = 2 * xo - 1 + kx;
           ok[ky][kx] = (yi >= 0) & (yi < H) & (xi >= 0) & (xi < W);
           const int yc = yi < 0 ? 0 : (yi >= H ? H - 1 : yi), xc = xi < 0 ? 0 : (xi >= W ? W - 1 : xi);
-          t[ky][kx] = ld4<T>(x, (((b * D + zi) * H + yc) * W + xc) * (long)C + 4 * q);
+          t[ky][kx] = ldv<T, VW>(x, (((b * D + zi) * H + yc) * W + xc) * (long)C + VW * q);
         }
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           if (!ok[ky][kx]) continue;
-          const float4 tv = t[ky][kx];
           const int tap = (kz * 3 + ky) * 3 + kx;
-          if (first || tv.x > m.x || tv.x != tv.x) { m.x = tv.x; ax = tap; }
-          if (first || tv.y > m.y || tv.y != tv.y) { m.y = tv.y; ay = tap; }
-          if (first || tv.z > m.z || tv.z != tv.z) { m.z = tv.z; az = tap; }
-          if (first || tv.w > m.w || tv.w != tv.w) { m.w = tv.w; aw = tap; }
+#pragma unroll
+          for (int k = 0; k < VW; ++k) {
+            const float tv = t[ky][kx].v[k];
+            if (first || tv > m.v[k] || tv != tv) { m.v[k] = tv; am[k] = tap; }
+          }
           first = false;
         }
     }
-    st4<T>(y, 4 * i, m);
-    reinterpret_cast<uchar4*>(amax)[i] = make_uchar4((unsigned char)ax, (unsigned char)ay, (unsigned char)az,
-                                                     (unsigned char)aw);
+    stv<T, VW>(y, VW * i, m);
+#pragma unroll
+    for (int k = 0; k < VW; k += 4)
+      reinterpret_cast<uchar4*>(amax)[(VW / 4) * i + (k >> 2)] =
+          make_uchar4((unsigned char)am[k], (unsigned char)am[k + 1], (unsigned char)am[k + 2], (unsigned char)am[k + 3]);
   }
 }
 
-template <typename T>
+template <typename T, int VW>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ amax,
                                    const T* __restrict__ add, int add_stride, T* __restrict__ dx, int D, int H,
-                                   int W, int C, int Do, int Ho, int Wo, long total4) {
-  const int Q = C >> 2;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+                                   int W, int C, int Do, int Ho, int Wo, long total) {
+  const int Q = C / VW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i % Q);
     long v = i / Q;
     const int xi = (int)(v % W); v /= W;
     const int yi = (int)(v % H); v /= H;
     const int zi = (int)(v % D);
     const long b = v / D;
-    // add: a tensor shaped like dx, or a channel slice of a wider one (add_stride floats per voxel)
-    float4 s = add ? ld4<T>(add, (i / Q) * (long)add_stride + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // add: a tensor shaped like dx, or a channel slice of a wider one (add_stride elements per voxel)
+    fvec<VW> s;
+    if (add) s = ldv<T, VW>(add, (i / Q) * (long)add_stride + VW * q);
+    else {
+#pragma unroll
+      for (int k = 0; k < VW; ++k) s.v[k] = 0.f;
+    }
     // windows containing zi: zo with 2zo-1 <= zi <= 2zo+1
     const int zlo = zi >> 1, zhi = (zi + 1) >> 1;  // ceil((zi-1)/2) == zi>>1 for zi>=0
     const int ylo = yi >> 1, yhi = (yi + 1) >> 1;
     const int xlo = xi >> 1, xhi = (xi + 1) >> 1;
     // the (up to) 2 x 2 x 2 windows containing this voxel: all eight (argmax, dy) pairs are loaded together with
     // clamped window indices, invalid ones are skipped afterwards -- in the original scan order
-    uchar4 am[2][2][2];
-    float4 gg[2][2][2];
+    uchar4 am[2][2][2][VW / 4];
+    fvec<VW> gg[2][2][2];
 #pragma unroll
     for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
@@ -94,8 +105,9 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __re
         for (int dx_ = 0; dx_ < 2; ++dx_) {
           const int zo = min(zlo + dz, Do - 1), yo = min(ylo + dy_, Ho - 1), xo = min(xlo + dx_, Wo - 1);
           const long o = ((((b * Do + zo) * Ho + yo) * Wo + xo) * (long)Q + q);
-          am[dz][dy_][dx_] = reinterpret_cast<const uchar4*>(amax)[o];
-          gg[dz][dy_][dx_] = ld4<T>(dy, 4 * o);
+#pragma unroll
+          for (int k = 0; k < VW / 4; ++k) am[dz][dy_][dx_][k] = reinterpret_cast<const uchar4*>(amax)[(VW / 4) * o + k];
+          gg[dz][dy_][dx_] = ldv<T, VW>(dy, VW * o);
         }
 #pragma unroll
     for (int dz = 0; dz < 2; ++dz)
@@ -107,14 +119,17 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __re
           if (zo > zhi || zo >= Do || yo > yhi || yo >= Ho || xo > xhi || xo >= Wo) continue;
           const int kz = zi - (2 * zo - 1), ky = yi - (2 * yo - 1), kx = xi - (2 * xo - 1);
           const unsigned char tap = (unsigned char)((kz * 3 + ky) * 3 + kx);
-          const uchar4 a = am[dz][dy_][dx_];
-          const float4 g = gg[dz][dy_][dx_];
-          if (a.x == tap) s.x += g.x;
-          if (a.y == tap) s.y += g.y;
-          if (a.z == tap) s.z += g.z;
-          if (a.w == tap) s.w += g.w;
+#pragma unroll
+          for (int k = 0; k < VW / 4; ++k) {
+            const uchar4 a = am[dz][dy_][dx_][k];
+            const fvec<VW>& g = gg[dz][dy_][dx_];
+            if (a.x == tap) s.v[4 * k] += g.v[4 * k];
+            if (a.y == tap) s.v[4 * k + 1] += g.v[4 * k + 1];
+            if (a.z == tap) s.v[4 * k + 2] += g.v[4 * k + 2];
+            if (a.w == tap) s.v[4 * k + 3] += g.v[4 * k + 3];
+          }
         }
-    st4<T>(dx, 4 * i, s);
+    stv<T, VW>(dx, VW * i, s);
   }
 }
 
@@ -131,32 +146,33 @@ __device__ __forceinline__ void lin_src(int dst, float scale, int in, int& i0, i
   w0 = 1.f - w1;
 }
 
-template <typename T>
+template <typename T, int VW>
 __global__ void upcat_fwd_kernel(const T* __restrict__ src, const T* __restrict__ skip,
                                  T* __restrict__ cat, int Ds, int Hs, int Ws, int Cu, int Dk, int Hk, int Wk,
-                                 int Ck, int oz, int oy, int ox, float sz, float sy, float sx, long total4) {
+                                 int Ck, int oz, int oy, int ox, float sz, float sy, float sx, long total) {
   const int Do = 2 * Ds, Ho = 2 * Hs, Wo = 2 * Ws;
-  const int Ct = Cu + Ck, Q = Ct >> 2, Qu = Cu >> 2;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+  const int Ct = Cu + Ck, Q = Ct / VW, Qu = Cu / VW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i % Q);
     long v = i / Q;
     const int xo = (int)(v % Wo); v /= Wo;
     const int yo = (int)(v % Ho); v /= Ho;
     const int zo = (int)(v % Do);
     const long b = v / Do;
-    float4 o;
+    fvec<VW> o;
     if (q < Qu) {
       int z0, z1, y0, y1, x0, x1;
       float wz0, wz1, wy0, wy1, wx0, wx1;
       lin_src(zo, sz, Ds, z0, z1, wz0, wz1);
       lin_src(yo, sy, Hs, y0, y1, wy0, wy1);
       lin_src(xo, sx, Ws, x0, x1, wx0, wx1);
-      o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < VW; ++k) o.v[k] = 0.f;
 #define UP_ACC(zz, yy, xx, ww)                                                                                   \
   {                                                                                                              \
-    const float4 t = ld4<T>(src, (((b * Ds + zz) * Hs + yy) * Ws + xx) * (long)Cu + 4 * q);                     \
+    const fvec<VW> t = ldv<T, VW>(src, (((b * Ds + zz) * Hs + yy) * Ws + xx) * (long)Cu + VW * q);               \
     const float w_ = (ww);                                                                                       \
-    o.x += w_ * t.x; o.y += w_ * t.y; o.z += w_ * t.z; o.w += w_ * t.w;                                          \
+    _Pragma("unroll") for (int k = 0; k < VW; ++k) o.v[k] += w_ * t.v[k];                                        \
   }
       // same association as ATen: w0z*(w0y*(w0x*a + w1x*b) + ...) is not reproduced bit-wise; fp32 tolerance
       UP_ACC(z0, y0, x0, wz0 * wy0 * wx0) UP_ACC(z0, y0, x1, wz0 * wy0 * wx1)
@@ -165,9 +181,9 @@ __global__ void upcat_fwd_kernel(const T* __restrict__ src, const T* __restrict_
       UP_ACC(z1, y1, x0, wz1 * wy1 * wx0) UP_ACC(z1, y1, x1, wz1 * wy1 * wx1)
 #undef UP_ACC
     } else {
-      o = ld4<T>(skip, (((b * Dk + zo + oz) * Hk + yo + oy) * Wk + xo + ox) * (long)Ck + 4 * (q - Qu));
+      o = ldv<T, VW>(skip, (((b * Dk + zo + oz) * Hk + yo + oy) * Wk + xo + ox) * (long)Ck + VW * (q - Qu));
     }
-    st4<T>(cat, 4 * i, o);
+    stv<T, VW>(cat, VW * i, o);
   }
 }
 
@@ -178,15 +194,17 @@ __global__ void upcat_fwd_kernel(const T* __restrict__ src, const T* __restrict_
 // most 5 past the first output's floor) are loaded once per 64-channel block into LDS instead of
 // being gathered eight times per output from L2 / MALL (8 x the output bytes: the untiled kernel ran at 2.5 TB/s).
 // Same corner order and weights as upcat_fwd_kernel.
-template <typename T>
+template <typename T, int VW>
 __global__ __launch_bounds__(256) void upcat_fwd_tiled_kernel(const T* __restrict__ src, const T* __restrict__ skip,
                                                               T* __restrict__ cat, int Ds, int Hs, int Ws, int Cu,
                                                               int Dk, int Hk, int Wk, int Ck, int oz, int oy, int ox,
                                                               float sz, float sy, float sx, int tz_n, int ty_n,
                                                               int tx_n) {
-  __shared__ float4 tile[216 * 16];          // [6][6][6] voxels x 16 channel quads
+  constexpr int LPV = 64 / VW;               // lanes per voxel of a 64-channel block
+  constexpr int SLOTS = 256 / LPV;           // voxels per pass
+  __shared__ float4 tile[216 * 16];          // [6][6][6] voxels x 64 channels, fp32 (converted once at the fill)
   const int Do = 2 * Ds, Ho = 2 * Hs, Wo = 2 * Ws;
-  const int Ct = Cu + Ck, Q = Ct >> 2, Qu = Cu >> 2, Qk = Ck >> 2;
+  const int Ct = Cu + Ck, Qk = Ck / VW;
   int r = blockIdx.x;
   const int txi = r % tx_n; r /= tx_n;
   const int tyi = r % ty_n; r /= ty_n;
@@ -199,17 +217,20 @@ __global__ __launch_bounds__(256) void upcat_fwd_tiled_kernel(const T* __restric
   lin_src(z0, sz, Ds, zb, d1, w0, w1);
   lin_src(y0, sy, Hs, yb, d1, w0, w1);
   lin_src(x0, sx, Ws, xb, d1, w0, w1);
-  const int tid = threadIdx.x, q = tid & 15, vs = tid >> 4;     // channel quad, voxel slot (16 per pass)
-  for (int cb = 0; cb < Qu; cb += 16) {
+  const int tid = threadIdx.x, q = tid % LPV, vs = tid / LPV;     // channel group, voxel slot
+  for (int cb = 0; cb < Cu; cb += 64) {
     __syncthreads();                       // previous channel block consumed
-    for (int e = tid; e < 216 * 16; e += 256) {
-      const int qq = e & 15, v = e >> 4;
+    for (int e = tid; e < 216 * LPV; e += 256) {
+      const int qq = e % LPV, v = e / LPV;
       const int lx = v % 6, ly = (v / 6) % 6, lz = v / 36;
       const int zz = min(zb + lz, Ds - 1), yy = min(yb + ly, Hs - 1), xx = min(xb + lx, Ws - 1);
-      tile[e] = ld4<T>(src, (((b * Ds + zz) * Hs + yy) * Ws + xx) * (long)Cu + 4 * (cb + qq));
+      const fvec<VW> t = ldv<T, VW>(src, (((b * Ds + zz) * Hs + yy) * Ws + xx) * (long)Cu + cb + VW * qq);
+#pragma unroll
+      for (int k = 0; k < VW; k += 4)
+        tile[v * 16 + (VW / 4) * qq + (k >> 2)] = make_float4(t.v[k], t.v[k + 1], t.v[k + 2], t.v[k + 3]);
     }
     __syncthreads();
-    for (int v = vs; v < 512; v += 16) {
+    for (int v = vs; v < 512; v += SLOTS) {
       const int zo = z0 + (v >> 6), yo = y0 + ((v >> 3) & 7), xo = x0 + (v & 7);
       if (zo >= Do || yo >= Ho || xo >= Wo) continue;
       int za, zc, ya, yc, xa, xc;
@@ -218,12 +239,16 @@ __global__ __launch_bounds__(256) void upcat_fwd_tiled_kernel(const T* __restric
       lin_src(yo, sy, Hs, ya, yc, wy0, wy1);
       lin_src(xo, sx, Ws, xa, xc, wx0, wx1);
       za -= zb; zc -= zb; ya -= yb; yc -= yb; xa -= xb; xc -= xb;
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#define UPT_ACC(zz, yy, xx, ww)                                            \
-  {                                                                        \
-    const float4 t = tile[(((zz) * 6 + (yy)) * 6 + (xx)) * 16 + q];        \
-    const float w_ = (ww);                                                 \
-    o.x += w_ * t.x; o.y += w_ * t.y; o.z += w_ * t.z; o.w += w_ * t.w;    \
+      fvec<VW> o;
+#pragma unroll
+      for (int k = 0; k < VW; ++k) o.v[k] = 0.f;
+#define UPT_ACC(zz, yy, xx, ww)                                                              \
+  {                                                                                          \
+    const float w_ = (ww);                                                                   \
+    _Pragma("unroll") for (int k = 0; k < VW; k += 4) {                                      \
+      const float4 t = tile[(((zz) * 6 + (yy)) * 6 + (xx)) * 16 + (VW / 4) * q + (k >> 2)];  \
+      o.v[k] += w_ * t.x; o.v[k + 1] += w_ * t.y; o.v[k + 2] += w_ * t.z; o.v[k + 3] += w_ * t.w; \
+    }                                                                                        \
   }
       UPT_ACC(za, ya, xa, wz0 * wy0 * wx0) UPT_ACC(za, ya, xc, wz0 * wy0 * wx1)
       UPT_ACC(za, yc, xa, wz0 * wy1 * wx0) UPT_ACC(za, yc, xc, wz0 * wy1 * wx1)
@@ -231,7 +256,7 @@ __global__ __launch_bounds__(256) void upcat_fwd_tiled_kernel(const T* __restric
       UPT_ACC(zc, yc, xa, wz1 * wy1 * wx0) UPT_ACC(zc, yc, xc, wz1 * wy1 * wx1)
 #undef UPT_ACC
       const long vox = ((b * Do + zo) * Ho + yo) * (long)Wo + xo;
-      st4<T>(cat, 4 * (vox * Q + cb + q), o);
+      stv<T, VW>(cat, vox * Ct + cb + VW * q, o);
     }
   }
   // centre-cropped skip connection -> channels Cu .. Ct - 1
@@ -240,8 +265,8 @@ __global__ __launch_bounds__(256) void upcat_fwd_tiled_kernel(const T* __restric
     const int zo = z0 + (v >> 6), yo = y0 + ((v >> 3) & 7), xo = x0 + (v & 7);
     if (zo >= Do || yo >= Ho || xo >= Wo) continue;
     const long vox = ((b * Do + zo) * Ho + yo) * (long)Wo + xo;
-    st4<T>(cat, 4 * (vox * Q + Qu + qq),
-           ld4<T>(skip, (((b * Dk + zo + oz) * Hk + yo + oy) * Wk + xo + ox) * (long)Ck + 4 * qq));
+    stv<T, VW>(cat, vox * Ct + Cu + VW * qq,
+               ldv<T, VW>(skip, (((b * Dk + zo + oz) * Hk + yo + oy) * Wk + xo + ox) * (long)Ck + VW * qq));
   }
 }
 
@@ -283,12 +308,12 @@ __device__ __forceinline__ UpAxis up_axis(int s, float scale, int in, int out) {
 // separable and channel-independent: three 6-entry tables (18 lin_src evaluations; the first version re-derived them
 // inside a 7x7x7 candidate loop with three levels of data-dependent `continue`, one load in flight: 1.3 TB/s), then
 // rows of 6 predicated loads issued together.
-template <typename T>
+template <typename T, int VW>
 __global__ void upcat_bwd_src_kernel(const T* __restrict__ dcat, T* __restrict__ dsrc, int Ds, int Hs, int Ws,
-                                     int Cu, int Ct, float sz, float sy, float sx, long total4) {
+                                     int Cu, int Ct, float sz, float sy, float sx, long total) {
   const int Do = 2 * Ds, Ho = 2 * Hs, Wo = 2 * Ws;
-  const int Qu = Cu >> 2;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+  const int Qu = Cu / VW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i % Qu);
     long v = i / Qu;
     const int xs = (int)(v % Ws); v /= Ws;
@@ -296,7 +321,9 @@ __global__ void upcat_bwd_src_kernel(const T* __restrict__ dcat, T* __restrict__
     const int zs = (int)(v % Ds);
     const long b = v / Ds;
     const UpAxis tz = up_axis(zs, sz, Ds, Do), ty = up_axis(ys, sy, Hs, Ho), tx = up_axis(xs, sx, Ws, Wo);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    fvec<VW> acc;
+#pragma unroll
+    for (int k = 0; k < VW; ++k) acc.v[k] = 0.f;
 #pragma unroll 1
     for (int jz = 0; jz < 6; ++jz) {
       if (tz.w[jz] == 0.f) continue;
@@ -304,29 +331,30 @@ __global__ void upcat_bwd_src_kernel(const T* __restrict__ dcat, T* __restrict__
       for (int jy = 0; jy < 6; ++jy) {
         const float wzy = tz.w[jz] * ty.w[jy];
         if (wzy == 0.f) continue;
-        const T* row = dcat + (((b * Do + tz.lo + jz) * Ho + ty.lo + jy) * (long)Wo + tx.lo) * (long)Ct + 4 * q;
-        float4 g[6];
+        const T* row = dcat + (((b * Do + tz.lo + jz) * Ho + ty.lo + jy) * (long)Wo + tx.lo) * (long)Ct + VW * q;
+        fvec<VW> g[6];
 #pragma unroll
         for (int jx = 0; jx < 6; ++jx)      // clamped address + zero weight instead of a branch per load
-          g[jx] = ld4<T>(row, (long)(tx.w[jx] != 0.f ? jx : 0) * Ct);
+          g[jx] = ldv<T, VW>(row, (long)(tx.w[jx] != 0.f ? jx : 0) * Ct);
 #pragma unroll
         for (int jx = 0; jx < 6; ++jx) {
           const float w_ = wzy * tx.w[jx];
-          acc.x += w_ * g[jx].x; acc.y += w_ * g[jx].y; acc.z += w_ * g[jx].z; acc.w += w_ * g[jx].w;
+#pragma unroll
+          for (int k = 0; k < VW; ++k) acc.v[k] += w_ * g[jx].v[k];
         }
       }
     }
-    st4<T>(dsrc, 4 * i, acc);
+    stv<T, VW>(dsrc, VW * i, acc);
   }
 }
 
-template <typename T>
+template <typename T, int VW>
 __global__ void upcat_bwd_skip_kernel(const T* __restrict__ dcat, T* __restrict__ dskip, int Do, int Ho,
                                       int Wo, int Cu, int Dk, int Hk, int Wk, int Ck, int oz, int oy, int ox,
-                                      long total4) {
-  const int Qk = Ck >> 2;
+                                      long total) {
+  const int Qk = Ck / VW;
   const int Ct = Cu + Ck;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i % Qk);
     long v = i / Qk;
     const int xk = (int)(v % Wk); v /= Wk;
@@ -334,10 +362,12 @@ __global__ void upcat_bwd_skip_kernel(const T* __restrict__ dcat, T* __restrict_
     const int zk = (int)(v % Dk);
     const long b = v / Dk;
     const int zo = zk - oz, yo = yk - oy, xo = xk - ox;
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    fvec<VW> o;
+#pragma unroll
+    for (int k = 0; k < VW; ++k) o.v[k] = 0.f;
     if (zo >= 0 && zo < Do && yo >= 0 && yo < Ho && xo >= 0 && xo < Wo)
-      o = ld4<T>(dcat, (((b * Do + zo) * Ho + yo) * Wo + xo) * (long)Ct + Cu + 4 * q);
-    st4<T>(dskip, 4 * i, o);
+      o = ldv<T, VW>(dcat, (((b * Do + zo) * Ho + yo) * Wo + xo) * (long)Ct + Cu + VW * q);
+    stv<T, VW>(dskip, VW * i, o);
   }
 }
 
@@ -378,6 +408,25 @@ inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (flo
 
 }  // namespace
 
+// channels per thread: 8 for bf16 storage when every channel count / stride involved is a multiple of 8 (16-B
+// vectors), else 4.  DRAM_POOL_VW=4 forces the narrow form (A/B).
+static inline bool pool_wide(size_t elem, std::initializer_list<long> counts) {
+  static const bool narrow = getenv("DRAM_POOL_VW") && atoi(getenv("DRAM_POOL_VW")) == 4;
+  if (elem != 2 || narrow) return false;
+  for (long c : counts)
+    if (c & 7) return false;
+  return true;
+}
+#define POOL_LAUNCH(WIDE_, KERNEL_, GRID_, ...)                                                                       \
+  do {                                                                                                                \
+    if constexpr (sizeof(T) == 2) {                                                                                   \
+      if (WIDE_) hipLaunchKernelGGL((KERNEL_<T, 8>), dim3(GRID_), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);     \
+      else hipLaunchKernelGGL((KERNEL_<T, 4>), dim3(GRID_), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);           \
+    } else {                                                                                                          \
+      hipLaunchKernelGGL((KERNEL_<T, 4>), dim3(GRID_), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);                \
+    }                                                                                                                 \
+  } while (0)
+
 template <typename T>
 static int maxpool_fwd_impl(const T* x, T* y, uint8_t* argmax, int B, int D, int H, int W, int C, dram_stream_t stream) {
   if (!x || !y || !argmax || B < 1 || D < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
@@ -385,8 +434,9 @@ static int maxpool_fwd_impl(const T* x, T* y, uint8_t* argmax, int B, int D, int
   const long total4 = (long)B * Do * Ho * Wo * (C >> 2);
   DramProf prof(DRAM_FAM_POOL_UP, 0, 0.0, (double)sizeof(T) * ((double)B * D * H * W * C + 4.0 * total4) + 4.0 * total4,
                 (hipStream_t)stream);
-  hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, D, H,
-                     W, C, Do, Ho, Wo, total4);
+  const bool wide = pool_wide(sizeof(T), {C});
+  const long total = wide ? total4 / 2 : total4;
+  POOL_LAUNCH(wide, maxpool_fwd_kernel, ew_grid(total), x, y, argmax, D, H, W, C, Do, Ho, Wo, total);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
@@ -409,8 +459,9 @@ static int maxpool_bwd_impl(const T* dy, const uint8_t* argmax, const T* add, in
   DramProf prof(DRAM_FAM_POOL_UP, 1, 0.0,
                 (double)sizeof(T) * 4.0 * total4 * (1.0 + (add ? 1 : 0)) + (1.0 + sizeof(T)) * (double)B * Do * Ho * Wo * C,
                 (hipStream_t)stream);
-  hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, argmax, add,
-                     add_stride, dx, D, H, W, C, Do, Ho, Wo, total4);
+  const bool wide = pool_wide(sizeof(T), {C, add ? add_stride : 0, (add && ((uintptr_t)add & 15)) ? 1 : 0});
+  const long total = wide ? total4 / 2 : total4;
+  POOL_LAUNCH(wide, maxpool_bwd_kernel, ew_grid(total), dy, argmax, add, add_stride, dx, D, H, W, C, Do, Ho, Wo, total);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
@@ -436,16 +487,16 @@ static int upcat_fwd_impl(const T* src, const T* skip, T* cat, int B, int Ds, in
   DramProf prof(DRAM_FAM_POOL_UP, 2, 0.0,
                 (double)sizeof(T) * ((double)B * Ds * Hs * Ws * Cu + (double)B * Do * Ho * Wo * Ck + 4.0 * total4),
                 (hipStream_t)stream);
+  const bool wide = pool_wide(sizeof(T), {Cu, Ck});
   if (Cu % 64 == 0 && tiles >= 512 && tiles < (1L << 31) && !getenv("DRAM_UPCAT_UNTILED")) {
-    hipLaunchKernelGGL((upcat_fwd_tiled_kernel<T>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, src, skip, cat,
-                       Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck, oz, oy, ox, ac_scale(Ds, Do), ac_scale(Hs, Ho), ac_scale(Ws, Wo),
-                       (Do + 7) / 8, (Ho + 7) / 8, (Wo + 7) / 8);
+    POOL_LAUNCH(wide, upcat_fwd_tiled_kernel, (unsigned)tiles, src, skip, cat, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck, oz, oy, ox,
+                ac_scale(Ds, Do), ac_scale(Hs, Ho), ac_scale(Ws, Wo), (Do + 7) / 8, (Ho + 7) / 8, (Wo + 7) / 8);
     DRAM_LAUNCH_CHECK();
     return DRAM_OK;
   }
-  hipLaunchKernelGGL((upcat_fwd_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, src, skip, cat, Ds,
-                     Hs, Ws, Cu, Dk, Hk, Wk, Ck, oz, oy, ox, ac_scale(Ds, Do), ac_scale(Hs, Ho), ac_scale(Ws, Wo),
-                     total4);
+  const long total = wide ? total4 / 2 : total4;
+  POOL_LAUNCH(wide, upcat_fwd_kernel, ew_grid(total), src, skip, cat, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck, oz, oy, ox,
+              ac_scale(Ds, Do), ac_scale(Hs, Ho), ac_scale(Ws, Wo), total);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
@@ -467,18 +518,21 @@ static int upcat_bwd_impl(const T* dcat, T* dsrc, T* dskip, int B, int Ds, int H
   if (Dk < Do || Hk < Ho || Wk < Wo) return DRAM_ERR_BAD_ARG;
   const int oz = (Dk - Do + 1) / 2, oy = (Hk - Ho + 1) / 2, ox = (Wk - Wo + 1) / 2;
   hipStream_t s = (hipStream_t)stream;
+  const bool wide = pool_wide(sizeof(T), {Cu, Ck});
   if (dsrc) {
     const long total4 = (long)B * Ds * Hs * Ws * (Cu >> 2);
     DramProf prof(DRAM_FAM_POOL_UP, 3, 0.0, (double)sizeof(T) * ((double)B * Do * Ho * Wo * Cu + 4.0 * total4), s);
-    hipLaunchKernelGGL((upcat_bwd_src_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, s, dcat, dsrc, Ds, Hs, Ws, Cu,
-                       Cu + Ck, ac_scale(Ds, Do), ac_scale(Hs, Ho), ac_scale(Ws, Wo), total4);
+    const long total = wide ? total4 / 2 : total4;
+    POOL_LAUNCH(wide, upcat_bwd_src_kernel, ew_grid(total), dcat, dsrc, Ds, Hs, Ws, Cu, Cu + Ck, ac_scale(Ds, Do),
+                ac_scale(Hs, Ho), ac_scale(Ws, Wo), total);
     DRAM_LAUNCH_CHECK();
   }
   if (dskip) {
     const long total4 = (long)B * Dk * Hk * Wk * (Ck >> 2);
     DramProf prof(DRAM_FAM_POOL_UP, 4, 0.0, (double)sizeof(T) * ((double)B * Do * Ho * Wo * Ck + 4.0 * total4), s);
-    hipLaunchKernelGGL((upcat_bwd_skip_kernel<T>), dim3(ew_grid(total4)), dim3(256), 0, s, dcat, dskip, Do, Ho, Wo, Cu, Dk,
-                       Hk, Wk, Ck, oz, oy, ox, total4);
+    const long total = wide ? total4 / 2 : total4;
+    POOL_LAUNCH(wide, upcat_bwd_skip_kernel, ew_grid(total), dcat, dskip, Do, Ho, Wo, Cu, Dk, Hk, Wk, Ck, oz, oy, ox,
+                total);
     DRAM_LAUNCH_CHECK();
   }
   return DRAM_OK;

@@ -229,7 +229,15 @@ def test_elementwise_bf16_kernels_equal_fp32_kernels_on_upcast_operands(ops, mon
     gp = rnd(*p16.shape, seed=10).to(DEV).to(BF)
     assert torch.equal(ops.maxpool_bwd(gp, a16, tuple(y.shape), res), ops.maxpool_bwd(f(gp), a32, tuple(y.shape), f(res)).to(BF))
     # upsample + concat forward (tiled and untiled forms) / backward
-    for sshape, kshape in (((1, 3, 4, 5, 64), (1, 7, 9, 10, 32)), ((1, 32, 32, 32, 64), (1, 64, 64, 64, 64))):
+    # (channel counts that are not multiples of 8 take the 4-channel-per-thread form of the bf16 kernels)
+    y12 = rnd(1, 5, 6, 7, 12, seed=20).to(DEV).to(BF)
+    q16, b16 = ops.maxpool_fwd(y12)
+    q32, b32 = ops.maxpool_fwd(f(y12))
+    assert torch.equal(q16, q32.to(BF)) and torch.equal(b16, b32)
+    gq = rnd(*q16.shape, seed=21).to(DEV).to(BF)
+    assert torch.equal(ops.maxpool_bwd(gq, b16, tuple(y12.shape), None), ops.maxpool_bwd(f(gq), b32, tuple(y12.shape), None).to(BF))
+    for sshape, kshape in (((1, 3, 4, 5, 64), (1, 7, 9, 10, 32)), ((1, 32, 32, 32, 64), (1, 64, 64, 64, 64)),
+                           ((1, 3, 4, 5, 12), (1, 7, 9, 10, 20))):
         src, skip = rnd(*sshape, seed=11).to(DEV).to(BF), rnd(*kshape, seed=12).to(DEV).to(BF)
         c16 = ops.upcat_fwd(src, skip)
         assert torch.equal(c16, ops.upcat_fwd(f(src), f(skip)).to(BF))
