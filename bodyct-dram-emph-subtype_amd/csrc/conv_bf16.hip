@@ -478,6 +478,204 @@ __global__ __launch_bounds__(512) void wgrad3_bf16_kernel(const bf16_t* __restri
   }
 }
 
+__global__ __launch_bounds__(512) void wgrad3b_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                          float* __restrict__ slab, const WGeom g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char halo0[HALO_GRAN * 16];
+  __shared__ __attribute__((aligned(1024))) unsigned char halo1[HALO_GRAN * 16];
+  __shared__ __attribute__((aligned(1024))) unsigned char dyt0[2048 * 16];      // [256 voxels][64 co] bf16
+  __shared__ __attribute__((aligned(1024))) unsigned char dyt1[2048 * 16];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = xcd_remap(blockIdx.x, g.nblk);
+  const int pair = L % g.npairs, split = L / g.npairs;
+  const int cib = pair % g.ci_blocks, cob = pair / g.ci_blocks;
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_zero_page);
+  const CGeom cg{g.B, g.D, g.H, g.W, g.Cin, g.Cout, g.d, g.Tz, g.Ty, g.Tx, 1, 0};
+
+  // Per-lane DMA geometry, fixed for the whole kernel: the halo voxel (hz, hy, hx) / tile voxel (vz, vy, vx) a granule
+  // belongs to and its byte offset relative to the tile's first z plane (32-bit; negative before that plane's first
+  // row is fine: such lanes are out of the volume and never used).  Per tile only the plane base (scalar, in the
+  // buffer descriptor) and the range tests remain -- the first version re-derived everything per tile with 64-bit
+  // arithmetic (~45 VALU instructions per 1-KB piece).
+  int hco[5], hrel[5], vco[4], vrel[4];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {              // halo: 2560 granules / 512 threads
+    const int p = i * 512 + tid;
+    const int hv = p >> 2, ps = p & 3;
+    const int hz = hv / 100, hy = (hv / 10) % 10, hx = hv % 10;
+    hco[i] = hv < 600 ? (hz << 16) | (hy << 8) | hx : -1;
+    hrel[i] = ((((hz - 1) * g.H + (hy - 1)) * g.W + (hx - 1)) * g.d * g.Cin + cib * 32 + (ps ^ ((hx >> 1) & 3)) * 8) * 2;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {              // dy tile: 256 voxels x 8 slots (64 co); slot ^= 4 * ((v >> 1) & 1)
+    const int q = i * 512 + tid;
+    const int v = q >> 3, ps = q & 7;
+    const int ch = cob * 64 + (ps ^ (((v >> 1) & 1) << 2)) * 8;
+    vco[i] = ch < g.Cout ? ((v >> 6) << 16) | (((v >> 3) & 7) << 8) | (v & 7) : -1;
+    vrel[i] = ((((v >> 6) * g.H + ((v >> 3) & 7)) * g.W + (v & 7)) * g.d * g.Cout + ch) * 2;
+  }
+  const long xbytes = (long)g.B * g.D * g.H * g.W * g.Cin * 2, dbytes = (long)g.B * g.D * g.H * g.W * g.Cout * 2;
+  auto issue_tile = [&](int t, unsigned char* hb, unsigned char* db) __attribute__((always_inline)) {
+    if (DRAM_BF16_ABL == 11) return;
+    int b, rz, ry, rx, lz0, ly0, lx0;
+    decode_tile(t, cg, b, rz, ry, rx, lz0, ly0, lx0);
+    // descriptor bases at the tile's origin voxel (rz + d lz0, ry + d ly0, rx + d lx0): always inside the tensor's
+    // address range for tiles that exist; lanes whose voxel is outside the volume get the out-of-range offset
+    const int oz = rz + g.d * lz0, oy = ry + g.d * ly0, ox = rx + g.d * lx0;
+    const long org = (((long)b * g.D + oz) * g.H + oy) * g.W + ox;
+    // (the halo starts one lattice step BEFORE the origin: offsets are taken from a base moved back by the largest
+    // negative reach, (H W + W + 1) d voxels, clamped into the tensor, and corrected per lane by the same amount)
+    const long back = ((long)g.H * g.W + g.W + 1) * g.d;
+    const long hb0 = org - back < 0 ? 0 : org - back;
+    const int hshift = (int)((org - hb0) * g.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rh = make_rsrc(x, hb0 * g.Cin * 2, xbytes), rd = make_rsrc(dy, org * g.Cout * 2, dbytes);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int hz = hco[i] >> 16, hy = (hco[i] >> 8) & 255, hx = hco[i] & 255;
+      const int gz = oz + g.d * (hz - 1), gy = oy + g.d * (hy - 1), gx = ox + g.d * (hx - 1);
+      const bool ok = (hco[i] >= 0) & (gz >= 0) & (gz < g.D) & (gy >= 0) & (gy < g.H) & (gx >= 0) & (gx < g.W);
+      BUFLDS16(rh, ok ? (unsigned)(hrel[i] + hshift) : 0xffffffffu, hb + i * 8192 + wave * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vz = vco[i] >> 16, vy = (vco[i] >> 8) & 255, vx = vco[i] & 255;
+      const bool ok = (vco[i] >= 0) & (oz + g.d * vz < g.D) & (oy + g.d * vy < g.H) & (ox + g.d * vx < g.W);
+      BUFLDS16(rd, ok ? (unsigned)vrel[i] : 0xffffffffu, db + i * 8192 + wave * 1024);
+    }
+  };
+
+  // this wave: BOTH co halves of the block's 64, taps wave, wave + 8, wave + 16 (+ 24 for waves 0-2).  The first form
+  // (wgrad3_bf16_kernel: one co half, seven taps per wave) reads 16 operand pieces per 7 MFMAs -- 128 transposed reads
+  // of 512 B per k16 step and workgroup, 512 LDS cycles against 448 matrix cycles: LDS-bound.  Here the dy fragments
+  // serve both halves' accumulators of every tap: 86 reads (344 cycles) per step for the same 54 MFMAs.
+  const int ntap = wave < 3 ? 4 : 3;
+  const bool has4 = wave < 3;                    // wave-uniform
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][c][e] = 0.f;
+
+  // transposed-read addresses: 16-lane group g4 = lane >> 4 (bit 0: column half, bit 1: k half), lane 4 q + p of a
+  // group addresses row q, the 8-byte piece p of the group's 16 columns
+  const int g4 = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, h = g4 >> 1;
+  const int cslot = (g4 & 1) * 2 + (p >> 1), cbyte = (p & 1) * 8;
+  // A (dy): voxel (zt, 2 yp + h, 4 s + q) of the tile -> byte v * 128 + ((4 cb + cslot) ^ 4 ((v >> 1) & 1)) * 16 + cbyte;
+  // with x = 4 s + q: (v >> 1) & 1 = (q >> 1) & 1 for both s
+  int aoff[2][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int v = h * 8 + 4 * s + q;
+      aoff[c][s] = v * 128 + (((4 * c + cslot) ^ (((v >> 1) & 1) << 2)) << 4) + cbyte;
+    }
+  // B (x halo): voxel (zt + kz, 2 yp + h + ky, 4 s + q + kx) -> byte hv * 64 + (cslot ^ ((hx >> 1) & 3)) * 16 + cbyte
+  int boff[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int tap = (wave + 8 * i) < 27 ? wave + 8 * i : 0;
+    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int hx = 4 * s + q + kx;
+      boff[i][s] = ((kz * 10 + h + ky) * 10 + hx) * 64 + ((cslot ^ ((hx >> 1) & 3)) << 4) + cbyte;
+    }
+  }
+  auto tr8 = [&](const unsigned char* base, int o0, int o1) __attribute__((always_inline)) {
+    const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o0));
+    const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o1));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+
+  // The tile loop is written out for the two buffer pairs: with `hb = buf ? halo1 : halo0` the wait-count pass cannot
+  // tell the operand reads of one pair from the LDS-DMA writes into the other and put "s_waitcnt vmcnt(0)" between
+  // the DMA issue and the first read of EVERY tile -- the next tile's load was waited for before the current tile's
+  // first MFMA (no DMA: -26 % in the ablation was exactly this).  Named objects per phase answer the alias query.
+  auto compute = [&](const unsigned char* hb, const unsigned char* db) __attribute__((always_inline)) {
+    // The operand fragments of k16 step ks + 1 are issued while the MFMAs of step ks run (see wgrad3_bf16_kernel).
+    // The fourth tap of waves 0-2 is a block of its own behind a wave-uniform branch: its reads (next step) and its two
+    // MFMAs (this step) are independent of each other.
+    bf16x8 afr[2][2], bq[2][4];
+    auto frag = [&](int ks, int bufi) __attribute__((always_inline)) {
+      const int zt = ks >> 2, yp = ks & 3;
+      const unsigned char* da = db + (zt * 64 + yp * 16) * 128;            // voxel (zt, 2 yp, 0)
+      const unsigned char* ha = hb + (zt * 100 + yp * 20) * 64;            // halo voxel (zt, 2 yp, 0)
+      if (DRAM_BF16_ABL == 12) {           // ablation: no LDS operand reads
+        for (int e = 0; e < 8; ++e) afr[bufi][0][e] = afr[bufi][1][e] = (__bf16)(float)(lane + ks);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          for (int e = 0; e < 8; ++e) bq[bufi][i][e] = (__bf16)(float)(lane - i);
+        return;
+      }
+      afr[bufi][0] = tr8(da, aoff[0][0], aoff[0][1]);
+      afr[bufi][1] = tr8(da, aoff[1][0], aoff[1][1]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) bq[bufi][i] = tr8(ha, boff[i][0], boff[i][1]);
+    };
+    auto frag4 = [&](int ks, int bufi) __attribute__((always_inline)) {
+      const int zt = ks >> 2, yp = ks & 3;
+      if (DRAM_BF16_ABL == 12) { for (int e = 0; e < 8; ++e) bq[bufi][3][e] = (__bf16)(float)(lane - 3); return; }
+      bq[bufi][3] = tr8(hb + (zt * 100 + yp * 20) * 64, boff[3][0], boff[3][1]);
+    };
+    frag(0, 0);
+    if (has4) frag4(0, 0);
+#pragma unroll 2
+    for (int ks = 0; ks < 16; ++ks) {
+      if (ks + 1 < 16 && DRAM_BF16_ABL != 14) frag(ks + 1, (ks + 1) & 1);     // ablation 14: operands read once per tile
+      if (DRAM_BF16_ABL == 14 && ks == 0) frag(1, 1);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          if (DRAM_BF16_ABL == 13) acc[i][c][0] += (float)afr[ks & 1][c][0] * (float)bq[ks & 1][i][0];   // ablation: no MFMAs
+          else acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks & 1][c], bq[ks & 1][i], acc[i][c], 0, 0, 0);
+      if (ks + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (has4) {
+        if (ks + 1 < 16 && DRAM_BF16_ABL != 14) frag4(ks + 1, (ks + 1) & 1);
+        if (DRAM_BF16_ABL == 14 && ks == 0) frag4(1, 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          if (DRAM_BF16_ABL == 13) acc[3][c][0] += (float)afr[ks & 1][c][0] * (float)bq[ks & 1][3][0];
+          else acc[3][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ks & 1][c], bq[ks & 1][3], acc[3][c], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (split < g.ntile) issue_tile(split, halo0, dyt0);
+  for (int t = split; t < g.ntile; t += 2 * g.nsplit) {
+    __syncthreads();                                     // tile t has landed in pair 0; pair 1 is free
+    const bool more = t + g.nsplit < g.ntile;
+    if (more) issue_tile(t + g.nsplit, halo1, dyt1);
+    compute(halo0, dyt0);
+    __syncthreads();                                     // tile t + nsplit has landed in pair 1; pair 0 is free
+    if (t + 2 * g.nsplit < g.ntile) issue_tile(t + 2 * g.nsplit, halo0, dyt0);
+    if (more) compute(halo1, dyt1);
+  }
+
+  // slab[split][pair][tap][co 64][ci 32]
+  const int li = lane & 31, lh = lane >> 5;
+  float* sb = slab + ((long)split * g.npairs + pair) * 27 * 2048;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < ntap) {
+      const int tap = wave + 8 * i;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+          sb[(tap * 64 + c * 32 + row) * 32 + li] = acc[i][c][e];
+        }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // weight gradient, z-walking form (Cin % 64 == 0).  The tile kernel above loads 72 KB per 864 MFMAs (83 B per MFMA:
 // at the full matrix rate that is 6 TB/s into LDS -- it ran at 0.28 of the pipe, bound by exactly that).  Here a
@@ -838,21 +1036,27 @@ __global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const bf16_t* __restri
     const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + lo1));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7));
   };
-  int t = split, buf = 0;
-  if (t < g.ntile) issue(t, d0, x0);
-  for (; t < g.ntile; t += g.nsplit, buf ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + g.nsplit < g.ntile) {
-      if (buf == 0) issue(t + g.nsplit, d1, x1);
-      else issue(t + g.nsplit, d0, x0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned char* db = (buf == 0 ? d0 : d1) + cb * 16384;
-    const unsigned char* xb = (buf == 0 ? x0 : x1) + ib * 16384;
+  // (two phases with named buffer pairs, as in wgrad3b_bf16_kernel: a selected pointer made the wait-count pass wait
+  // for the NEXT tile's DMA in front of the first operand read of every tile)
+  auto compute = [&](const unsigned char* db, const unsigned char* xb) __attribute__((always_inline)) {
 #pragma unroll 4
     for (int ks = 0; ks < 16; ++ks)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(db + ks * 1024), tr8(xb + ks * 1024), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(db + cb * 16384 + ks * 1024), tr8(xb + ib * 16384 + ks * 1024), acc,
+                                                    0, 0, 0);
+  };
+  if (split < g.ntile) issue(split, d0, x0);
+  for (int t = split; t < g.ntile; t += 2 * g.nsplit) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool more = t + g.nsplit < g.ntile;
+    if (more) issue(t + g.nsplit, d1, x1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(d0, x0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 * g.nsplit < g.ntile) issue(t + 2 * g.nsplit, d0, x0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) compute(d1, x1);
   }
   const int li = lane & 31, lh = lane >> 5;
   float* sb = slab + ((long)split * g.npairs + pair) * 4096;
@@ -1247,8 +1451,13 @@ extern "C" int dram_conv3d_bwd_weight_bf16(const void* x, const void* dy, float*
   {
     DramProf prof(DRAM_FAM_WGRAD_BF16, 0, 2.0 * (double)g.ntile * 256.0 * 27.0 * g.ci_blocks * 32.0 * g.co_blocks * 64.0,
                   2.0 * vox * (d->Cin + d->Cout) + 4.0 * 27.0 * d->Cin * d->Cout, s, 2.0 * vox * 27.0 * d->Cin * d->Cout);
-    hipLaunchKernelGGL(wgrad3_bf16_kernel, dim3(g.nblk), dim3(512), 0, s, (const bf16_t*)x, (const bf16_t*)dy,
-                       (float*)workspace, g);
+    static const bool old_form = getenv("DRAM_BF16_WGRAD_TILE") && !strcmp(getenv("DRAM_BF16_WGRAD_TILE"), "old");   // A/B
+    if (old_form)
+      hipLaunchKernelGGL(wgrad3_bf16_kernel, dim3(g.nblk), dim3(512), 0, s, (const bf16_t*)x, (const bf16_t*)dy,
+                         (float*)workspace, g);
+    else
+      hipLaunchKernelGGL(wgrad3b_bf16_kernel, dim3(g.nblk), dim3(512), 0, s, (const bf16_t*)x, (const bf16_t*)dy,
+                         (float*)workspace, g);
     DRAM_LAUNCH_CHECK();
   }
   const long n = (long)d->Cout * d->Cin * 27;
