@@ -60,6 +60,16 @@ __device__ __forceinline__ void decode_tile(int t, const CGeom& g, int& b, int& 
 
 // Ablation switch of the tuning builds (tools/conv_bf16_ablate.sh; 0 = the product): 1 no weight DMA, 2 no halo DMA,
 // 3 no LDS operand reads, 4 no MFMAs, 5 no epilogue stores, 6 no barriers.  Results are garbage in those builds.
+// "s_waitcnt vmcnt(0)" as the BUILTIN (gfx9 encoding: lgkmcnt 15, expcnt 7, vmcnt 0), not as inline asm: the wait-count
+// pass reads the builtin and knows that no LDS-DMA is outstanding behind it.  Behind an asm wait it still believed the
+// previous step's DMA pending and guarded the first operand read of every step with a wait that also covered part of
+// the look-ahead DMA just issued (wgrad3z_bf16_kernel: "s_waitcnt vmcnt(2)" with three new DMAs in flight).
+#define WAIT_VM0()                         \
+  do {                                     \
+    __builtin_amdgcn_s_waitcnt(0x0F70);    \
+    asm volatile("" ::: "memory");         \
+  } while (0)
+
 #ifndef DRAM_BF16_ABL
 #define DRAM_BF16_ABL 0
 #endif
@@ -703,6 +713,10 @@ __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restr
   __shared__ __attribute__((aligned(1024))) unsigned char xr3[16384];
   __shared__ __attribute__((aligned(1024))) unsigned char dr0[8192];    // dy plane ring: [2 cb][64 voxels][64 B]
   __shared__ __attribute__((aligned(1024))) unsigned char dr1[8192];
+  // per-lane DMA offsets of the current column (x: two granules, dy: one): kept in LDS, not in registers -- the kernel
+  // sits at the 256-VGPR limit (224 accumulator registers), every spilled value is a scratch load that counts on
+  // vmcnt like the LDS-DMA, and the reload's "s_waitcnt vmcnt(0)" drained the look-ahead plane in every step
+  __shared__ unsigned offtab[3 * 512];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -730,12 +744,16 @@ __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restr
     a_lane[s] = (h * 8 + 4 * s + q) * 64 + cpiece;                       // dy voxel (2 ks + h, 4 s + q), + cb * 4096
     b_lane[s] = ib * 6400 + (h * 10 + 4 * s + q) * 64 + cpiece;          // x halo voxel (2 ks + h + ky, 4 s + q + kx)
   }
-  int tapoff[7], tapkz[7];
+  // Taps of tap group t0 (accumulator i): i < 6 -> z tap kz = i >> 1, in-plane tap j = 2 t0 + (i & 1) (of 0..7);
+  // i == 6 -> (kz = t0, j = 8) for t0 < 3.  The z tap of an accumulator is a COMPILE-TIME value: the ring slot an x
+  // fragment is read from is then a named array.  With kz a per-wave value (taps t0, t0 + 4, ...) the slot was a
+  // run-time select that folded into address arithmetic, the reads lost their underlying object, and the wait-count
+  // pass put "s_waitcnt vmcnt(0)" in front of them -- every step waited for the look-ahead plane it had just issued.
+  int tapoff[7];
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
-    const int tap = (t0 + 4 * i) < 27 ? t0 + 4 * i : 0;
-    tapkz[i] = tap / 9;
-    tapoff[i] = (((tap / 3) % 3) * 10 + tap % 3) * 64;
+    const int j = i < 6 ? 2 * t0 + (i & 1) : 8;
+    tapoff[i] = ((j / 3) * 10 + j % 3) * 64;
   }
   auto tr8 = [&](const unsigned char* base, int o0, int o1) __attribute__((always_inline)) {
     const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o0));
@@ -758,6 +776,8 @@ __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restr
     const int z0 = seg * g.lseg, z1 = (z0 + g.lseg < lzr) ? z0 + g.lseg : lzr;
     if (z0 >= z1) continue;                                              // (uniform)
     // per-lane DMA sources inside a plane: x granule pp -> (ib, halo voxel, slot); dy granule tid -> (cb, voxel, slot)
+    __builtin_amdgcn_s_barrier();                        // every wave is done with the rings of the last column
+    {
     unsigned xoff[2], doff;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -774,6 +794,10 @@ __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restr
       const bool ok = (gy < g.H) & (gx < g.W) & (ch < g.Cout);
       doff = ok ? (unsigned)((((long)gy * g.W + gx) * g.Cout + ch) * 2) : 0xffffffffu;
     }
+    offtab[tid] = xoff[0];
+    offtab[512 + tid] = xoff[1];
+    offtab[1024 + tid] = doff;
+    }
     // plane zl of the lattice (any integer): a descriptor over that plane alone, EMPTY (-> zeros) outside the volume
     auto issue_x = [&](int zl, unsigned char* dst) __attribute__((always_inline)) {
       const int gz = rz + g.d * zl;
@@ -781,16 +805,15 @@ __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restr
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char*>(reinterpret_cast<const char*>(x)) + ((long)b * g.D + (in ? gz : 0)) * plane_x, 0,
           in ? (int)plane_x : 0, BUF_FLAGS);
-      BUFLDS16(rs, xoff[0], dst + wave * 1024);
-      BUFLDS16(rs, xoff[1], dst + 8192 + wave * 1024);
+      BUFLDS16(rs, offtab[tid], dst + wave * 1024);
+      BUFLDS16(rs, offtab[512 + tid], dst + 8192 + wave * 1024);
     };
     auto issue_d = [&](int zl, unsigned char* dst) __attribute__((always_inline)) {
       const int gz = rz + g.d * zl;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char*>(reinterpret_cast<const char*>(dy)) + ((long)b * g.D + gz) * plane_dy, 0, (int)plane_dy, BUF_FLAGS);
-      BUFLDS16(rs, doff, dst + wave * 1024);
+      BUFLDS16(rs, offtab[1024 + tid], dst + wave * 1024);
     };
-    __builtin_amdgcn_s_barrier();                        // every wave is done with the rings of the last column
     // ring slots are indexed by (plane - z0 + 1) for x and (plane - z0) for dy: the same named slots for every column
     issue_x(z0 - 1, xr0);
     issue_x(z0, xr1);
@@ -801,7 +824,7 @@ __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restr
       for (int u = 0; u < 4; ++u) {
         const int z = zz + u;                            // relative plane
         if (z < z1 - z0) {                               // (uniform)
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          WAIT_VM0();
           __builtin_amdgcn_s_barrier();                  // planes z - 1 .. z + 1 of x and plane z of dy are in LDS
           issue_x(z0 + z + 2, XRING_(u + 3));            // relative plane z + 2 -> slot (z + 3) & 3 = (u + 3) & 3
           if (z + 1 < z1 - z0) issue_d(z0 + z + 1, DRING_(u + 1));
@@ -816,17 +839,25 @@ __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restr
             bf16x8 bq[7];
             auto bfrag = [&](int i) __attribute__((always_inline)) {
               // x plane z + kz - 1 lives in slot (u + kz) & 3 (named arrays: see RING_ in conv3_bf16_kernel)
-              const unsigned char* xb = tapkz[i] == 0 ? XRING_(u) : (tapkz[i] == 1 ? XRING_(u + 1) : XRING_(u + 2));
-              bq[i] = tr8(xb + ks * 1280 + tapoff[i], b_lane[0], b_lane[1]);
+              if (i < 6) {
+                bq[i] = tr8(XRING_(u + (i >> 1)) + ks * 1280 + tapoff[i], b_lane[0], b_lane[1]);
+              } else {                                   // the seventh tap: z tap t0 (wave-uniform branch, named slots)
+                if (t0 == 0) bq[i] = tr8(XRING_(u) + ks * 1280 + tapoff[i], b_lane[0], b_lane[1]);
+                else if (t0 == 1) bq[i] = tr8(XRING_(u + 1) + ks * 1280 + tapoff[i], b_lane[0], b_lane[1]);
+                else bq[i] = tr8(XRING_(u + 2) + ks * 1280 + tapoff[i], b_lane[0], b_lane[1]);
+              }
             };
-            bfrag(0);
-            bfrag(1);
+#ifndef DRAM_ZW_AHEAD
+#define DRAM_ZW_AHEAD 1          // x fragments read this many taps ahead (2: four more live registers -> spills)
+#endif
+#pragma unroll
+            for (int i = 0; i < DRAM_ZW_AHEAD; ++i) bfrag(i);
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
-              if (i + 2 < 7) bfrag(i + 2);
+              if (i + DRAM_ZW_AHEAD < 7) bfrag(i + DRAM_ZW_AHEAD);
               acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[i], acc[i][0], 0, 0, 0);
               acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[i], acc[i][1], 0, 0, 0);
-              if (i + 2 < 7) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              if (i + DRAM_ZW_AHEAD < 7) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
               __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -834,7 +865,7 @@ __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restr
         }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the look-ahead plane of the last step: drained before reuse
+    WAIT_VM0();     // the look-ahead plane of the last step: drained before reuse
   }
 #undef XRING_
 #undef DRING_
@@ -845,7 +876,7 @@ __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restr
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     if (i < ntap) {
-      const int tap = t0 + 4 * i;
+      const int tap = i < 6 ? (i >> 1) * 9 + 2 * t0 + (i & 1) : t0 * 9 + 8;
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -921,7 +952,7 @@ __global__ __launch_bounds__(256, 2) void gemm1_bf16_kernel(const bf16_t* __rest
   const int nchunk = g.Cin / 64;
   issue(0, a0, w0);
   for (int c = 0; c < nchunk; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WAIT_VM0();
     __builtin_amdgcn_s_barrier();                       // chunk c is in LDS for every wave; the other stage is free
     if (c + 1 < nchunk) {
       if (c & 1) issue(c + 1, a0, w0);
@@ -1046,13 +1077,13 @@ __global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const bf16_t* __restri
   };
   if (split < g.ntile) issue(split, d0, x0);
   for (int t = split; t < g.ntile; t += 2 * g.nsplit) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WAIT_VM0();
     __builtin_amdgcn_s_barrier();
     const bool more = t + g.nsplit < g.ntile;
     if (more) issue(t + g.nsplit, d1, x1);
     __builtin_amdgcn_sched_barrier(0);
     compute(d0, x0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WAIT_VM0();
     __builtin_amdgcn_s_barrier();
     if (t + 2 * g.nsplit < g.ntile) issue(t + 2 * g.nsplit, d0, x0);
     __builtin_amdgcn_sched_barrier(0);
