@@ -321,11 +321,12 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restric
 // per-channel constants (mean, invstd, gamma, the two batch means -- double multiplies in the generic kernel, per
 // element) live in registers, there is no 64-bit modulo per element, and two elements are in flight per thread.
 // Same expression per element as bn_bwd_apply_kernel (bit-identical results).
-// SHOT 0: capped grid + grid-stride loop (needed when per-block column sums are asked for: the caller sized colpart by
-// dram_bn_bwd_apply_nparts); SHOT 1 / 2: one-shot blocks of 256 U quads (common.h, ew_blocks), 2 = streaming loads and
-// stores.  U elements in flight per thread: 2 for fp32, 4 for bf16 (half the bytes per element against the same
+// SHOT 0: capped grid + grid-stride loop; SHOT 1 / 2: one-shot blocks of 256 U K quads (common.h, ew_blocks), 2 =
+// streaming loads and stores.  Per-block column sums of dy (the bias gradient of a convolution in front) need few
+// enough blocks for the partial rows: those launches sweep K > 1 consecutive 256 U-quad pieces per block (4,096 quads:
+// 5.3 TB/s in tools/stream_probe.hip's three-stream form against 5.7 for K = 1 and 4.1-4.6 for the capped grid).  U elements in flight per thread: 2 for fp32, 4 for bf16 (half the bytes per element against the same
 // per-thread set-up of the channel constants).
-template <typename T, int SHOT, int U>
+template <typename T, int SHOT, int U, int K>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const T* __restrict__ dz, const T* __restrict__ z,
                                                                 const T* __restrict__ y, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd,
@@ -353,7 +354,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const T* __restr
                                  (float)(sums[C + c + 2] * inv_count), (float)(sums[C + c + 3] * inv_count));
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
   const long stride = SHOT ? 256L : (long)gridDim.x * 256;
-  for (long i0 = blockIdx.x * (SHOT ? 256L * U : 256L) + threadIdx.x; i0 < total4; i0 += U * stride) {
+  int kk = 0;
+  for (long i0 = blockIdx.x * (SHOT ? 256L * U * K : 256L) + threadIdx.x; i0 < total4; i0 += U * stride) {
     float4 g[U], yv[U], zv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -385,9 +387,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const T* __restr
         cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
       }
     }
-    if (SHOT) break;
+    if (SHOT && ++kk == K) break;
   }
-  if (SHOT == 0 && colpart) {
+  if ((SHOT == 0 || K > 1) && colpart) {
     __shared__ float4 sm[256];
     sm[threadIdx.x] = cs;
     __syncthreads();
@@ -587,6 +589,7 @@ extern "C" int dram_colsum_bf16(const void* a, float* partial, long long rows, i
 extern "C" int dram_bn_bwd_apply_nparts(long long rows, int C) {
   if (rows < 1 || C < 4 || (C & 3)) return DRAM_ERR_BAD_ARG;
   if (256 % (C >> 2) != 0) return DRAM_ERR_UNSUPPORTED;
+  if (ew_shape() > 0) return ew_blocks((long)rows * (C >> 2), 4096, 0);    // one row per 4,096-quad block (fast kernel)
   return ew_grid((long)rows * (C >> 2));
 }
 
@@ -603,14 +606,15 @@ static int bn_bwd_apply_impl(const T* dz, const T* z, const T* y, const float* m
   const long total4 = (long)rows * (C >> 2);
   DramProf prof(DRAM_FAM_BN, 5, 0.0, 4.0 * sizeof(T) * (double)total4 * (relu && z ? 4.0 : 3.0), (hipStream_t)stream);
   if (256 % (C >> 2) == 0) {   // (with column sums: same grid as the generic kernel, one partial row per block)
-#define BN_BWD_FAST_(SHOT_, U_, GRID_)                                                                                    \
-  hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<T, SHOT_, U_>), dim3(GRID_), dim3(256), 0, (hipStream_t)stream, dz, z, y,    \
+#define BN_BWD_FAST_(SHOT_, U_, K_, GRID_)                                                                                \
+  hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<T, SHOT_, U_, K_>), dim3(GRID_), dim3(256), 0, (hipStream_t)stream, dz, z, y, \
                      mean, invstd, gamma, sums, count_dev ? 0.0 : 1.0 / count, count_dev, dy, C, total4, relu, scale,     \
                      shift, colsum_partial)
     constexpr int U = sizeof(T) == 2 ? 4 : 2;
-    if (colsum_partial || ew_shape() == 0) BN_BWD_FAST_(0, 2, ew_grid(total4));
-    else if (ew_stream(sizeof(T) * 4 * total4)) BN_BWD_FAST_(2, U, ew_blocks(total4, 256 * U, 0));
-    else BN_BWD_FAST_(1, U, ew_blocks(total4, 256 * U, 0));
+    if (ew_shape() == 0) BN_BWD_FAST_(0, 2, 1, ew_grid(total4));
+    else if (colsum_partial) BN_BWD_FAST_(1, U, 16 / U, ew_blocks(total4, 4096, 0));        // = dram_bn_bwd_apply_nparts
+    else if (ew_stream(sizeof(T) * 4 * total4)) BN_BWD_FAST_(2, U, 1, ew_blocks(total4, 256 * U, 0));
+    else BN_BWD_FAST_(1, U, 1, ew_blocks(total4, 256 * U, 0));
 #undef BN_BWD_FAST_
   }
   else

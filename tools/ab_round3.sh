@@ -1,7 +1,9 @@
-for v in "X=1" "DRAM_WINO_NT=0" "DRAM_WINO_NT=0 DRAM_WINO_EPI=0" "DRAM_WINO_NT=0 DRAM_EW_SHAPE=0" "DRAM_WINO_NT=0 DRAM_EW_SHAPE=1"; do
-  echo "== $v"; for c in 0 5; do env $v python bench.py --no-cpu-baseline --timeline off --config $c --steps 10 --warmup 3 2>/dev/null | python -c "
+set -e
+mkdir -p gpurun_out/ab
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py tests/test_bf16_gpu.py tests/test_models_gpu.py -x -q -m gpu > gpurun_out/ab/pytest.txt 2>&1 || { tail -40 gpurun_out/ab/pytest.txt; exit 1; }
+tail -2 gpurun_out/ab/pytest.txt
+for c in 1 2; do for r in 1 2; do python bench.py --no-cpu-baseline --timeline off --config $c 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print('  config$c', round(d['value'],2), round(d['ms_per_step'],2))"; done
-done
+        d=json.loads(l); print('config$c', round(d['value'],2), round(d['ms_per_step'],3))"; done; done

@@ -43,6 +43,48 @@ __global__ __launch_bounds__(256) void kE(const float4* __restrict__ x, float4* 
   }
 }
 
+// dword-per-lane forms (the Winograd transforms move one channel per lane: 256 B per wave instruction)
+template <int U>
+__global__ __launch_bounds__(256) void kD(const float* __restrict__ x, float* __restrict__ y, long n) {   // n floats
+  const long base = (long)blockIdx.x * (256 * U) + threadIdx.x;
+  float v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) if (base + u * 256 < n) v[u] = x[base + u * 256];
+#pragma unroll
+  for (int u = 0; u < U; ++u) if (base + u * 256 < n) y[base + u * 256] = fmaxf(v[u] * 2.f + 1.f, 0.f);
+}
+// scatter of the Winograd input transform: a wave reads P consecutive 256-B rows and writes them to P planes that lie
+// `plane` floats apart (one 256-B piece per plane), consecutive waves write consecutive pieces of every plane
+template <int P>
+__global__ __launch_bounds__(256) void kS(const float* __restrict__ x, float* __restrict__ y, long nw, long plane) {
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (w >= nw) return;
+  float v[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) v[p] = x[(w * P + p) * 64 + lane];
+#pragma unroll
+  for (int p = 0; p < P; ++p) y[p * plane + w * 64 + lane] = v[p] * 2.f + 1.f;
+}
+
+// F: one-shot blocks that each sweep K consecutive 4-KB sub-chunks (a kernel that needs per-block partial results and
+// cannot afford one partial row per 4 KB): 3 streams (two reads, one write) like bn_bwd_apply
+template <int K>
+__global__ __launch_bounds__(256) void kF(const float4* __restrict__ x, const float4* __restrict__ x2, float4* __restrict__ y, long n) {
+  const long base = (long)blockIdx.x * (256 * 2 * K) + threadIdx.x;
+  float acc = 0.f;
+#pragma unroll 1
+  for (int k = 0; k < K; ++k) {
+    const long i0 = base + k * 512;
+    float4 a[2], b[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) if (i0 + u * 256 < n) { a[u] = x[i0 + u * 256]; b[u] = x2[i0 + u * 256]; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) if (i0 + u * 256 < n) { float4 o = a[u]; o.x = fmaxf(o.x * b[u].x + 1.f, 0.f); acc += o.x; y[i0 + u * 256] = o; }
+  }
+  if (acc == 123.456f) y[0].y = acc;
+}
+
 template <typename F> float timeit(F f) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   for (int i = 0; i < 3; ++i) f();
@@ -64,6 +106,22 @@ int main() {
     }
 #define B_(U, NT) rep("B one-shot U=" #U " nt=" #NT, timeit([&] { hipLaunchKernelGGL((kB<U, NT>), dim3((unsigned)((n + 256 * U - 1) / (256 * U))), dim3(256), 0, 0, x, y, n); }))
     B_(1, 0); B_(2, 0); B_(4, 0); B_(8, 0); B_(4, 1); B_(4, 2); B_(8, 1);
+    {
+      float4* x2; CK(hipMalloc(&x2, n * 16)); CK(hipMemset(x2, 0x3c, n * 16));
+      auto rep3 = [&](const char* name, float ms) { printf("%5ld MiB  %-28s %8.1f us  %7.0f GB/s (3 streams)\n", mb, name, ms * 1e3, 3.0 * n * 16 / ms / 1e6); fflush(stdout); };
+#define F_(K) rep3("F 2 reads + 1 write, K=" #K, timeit([&] { hipLaunchKernelGGL(kF<K>, dim3((unsigned)((n + 512 * K - 1) / (512 * K))), dim3(256), 0, 0, x, (const float4*)x2, y, n); }))
+      F_(1); F_(2); F_(4); F_(8); F_(16); F_(32);
+      CK(hipFree(x2));
+    }
+    {
+      const long nf = n * 4;
+      rep("D dword one-shot U=1", timeit([&] { hipLaunchKernelGGL(kD<1>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, 0, (const float*)x, (float*)y, nf); }));
+      rep("D dword one-shot U=4", timeit([&] { hipLaunchKernelGGL(kD<4>, dim3((unsigned)((nf + 1023) / 1024)), dim3(256), 0, 0, (const float*)x, (float*)y, nf); }));
+      rep("D dword one-shot U=16", timeit([&] { hipLaunchKernelGGL(kD<16>, dim3((unsigned)((nf + 4095) / 4096)), dim3(256), 0, 0, (const float*)x, (float*)y, nf); }));
+      const long nw27 = nf / 64 / 27, nw108 = nf / 64 / 108;
+      rep("S 27 planes per wave", timeit([&] { hipLaunchKernelGGL(kS<27>, dim3((unsigned)((nw27 + 3) / 4)), dim3(256), 0, 0, (const float*)x, (float*)y, nw27, nw27 * 64); }));
+      rep("S 108 planes per wave", timeit([&] { hipLaunchKernelGGL(kS<108>, dim3((unsigned)((nw108 + 3) / 4)), dim3(256), 0, 0, (const float*)x, (float*)y, nw108, nw108 * 64); }));
+    }
     CK(hipFree(x)); CK(hipFree(y));
   }
   return 0;
