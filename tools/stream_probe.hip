@@ -85,6 +85,20 @@ __global__ __launch_bounds__(256) void kF(const float4* __restrict__ x, const fl
   if (acc == 123.456f) y[0].y = acc;
 }
 
+// write-heavy scatter (the input transform reads 64 voxels and writes 216 points per tile: 1 : 3.4): a wave reads R rows
+// and writes P planes
+template <int P, int R>
+__global__ __launch_bounds__(256) void kW(const float* __restrict__ x, float* __restrict__ y, long nw, long plane) {
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (w >= nw) return;
+  float v[R];
+#pragma unroll
+  for (int p = 0; p < R; ++p) v[p] = x[(w * R + p) * 64 + lane];
+#pragma unroll
+  for (int p = 0; p < P; ++p) y[p * plane + w * 64 + lane] = v[p % R] * 2.f + (float)p;
+}
+
 template <typename F> float timeit(F f) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   for (int i = 0; i < 3; ++i) f();
@@ -120,6 +134,12 @@ int main() {
       rep("D dword one-shot U=16", timeit([&] { hipLaunchKernelGGL(kD<16>, dim3((unsigned)((nf + 4095) / 4096)), dim3(256), 0, 0, (const float*)x, (float*)y, nf); }));
       const long nw27 = nf / 64 / 27, nw108 = nf / 64 / 108;
       rep("S 27 planes per wave", timeit([&] { hipLaunchKernelGGL(kS<27>, dim3((unsigned)((nw27 + 3) / 4)), dim3(256), 0, 0, (const float*)x, (float*)y, nw27, nw27 * 64); }));
+      {
+        const long nwW = nf / 64 / 108;
+        auto repw = [&](const char* name, float ms, double bytes) { printf("%5ld MiB  %-28s %8.1f us  %7.0f GB/s\n", mb, name, ms * 1e3, bytes / ms / 1e6); fflush(stdout); };
+        repw("W 32 rows -> 108 planes", timeit([&] { hipLaunchKernelGGL((kW<108, 32>), dim3((unsigned)((nwW + 3) / 4)), dim3(256), 0, 0, (const float*)x, (float*)y, nwW, nwW * 64); }), (double)nwW * 256 * 140);
+        repw("W 1 row -> 108 planes (write only)", timeit([&] { hipLaunchKernelGGL((kW<108, 1>), dim3((unsigned)((nwW + 3) / 4)), dim3(256), 0, 0, (const float*)x, (float*)y, nwW, nwW * 64); }), (double)nwW * 256 * 109);
+      }
       rep("S 108 planes per wave", timeit([&] { hipLaunchKernelGGL(kS<108>, dim3((unsigned)((nw108 + 3) / 4)), dim3(256), 0, 0, (const float*)x, (float*)y, nw108, nw108 * 64); }));
     }
     CK(hipFree(x)); CK(hipFree(y));
