@@ -1103,6 +1103,9 @@ __global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const bf16_t* __restri
 // PER_PAIR: one thread per (co, ci) -- its `taps` results are contiguous in dw and, for a fixed tap, neighbouring
 // threads read neighbouring slab floats: both sides coalesced (wide layers: 512 x 512 x 27 results, few slabs).
 // Otherwise one thread per result (narrow layers: few (co, ci) pairs, many slabs -- the serial sum must be short).
+// Both forms were latency-bound as first written (one load in flight per thread: 54 us for a 64 x 64 x 27 reduce over
+// 512 slabs, 86 us for 512 x 512 x 27 over 2): the per-pair form now carries nine taps at a time (nine independent
+// loads per slab), the per-result form eight interleaved partial sums over the slabs, combined in a fixed order.
 template <bool PER_PAIR>
 __global__ void wgrad3_bf16_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin,
                                           int ci_blocks, int npairs, int nsplit, int cw /* ci block width: 32 | 64 */,
@@ -1116,12 +1119,34 @@ __global__ void wgrad3_bf16_reduce_kernel(const float* __restrict__ slab, float*
     const int pair = (co >> 6) * ci_blocks + ci / cw;
     const float* s0 = slab + (long)pair * taps * 64 * cw + (co & 63) * cw + ci % cw;
     float* o = dw + ((long)co * Cin + ci) * taps;
-    const int t_lo = PER_PAIR ? 0 : (int)(r / Cout), t_hi = PER_PAIR ? taps : t_lo + 1;
-    for (int tap = t_lo; tap < t_hi; ++tap) {
+    if (PER_PAIR) {                       // taps == 27
+      const long tstride = 64L * cw;
+#pragma unroll 1
+      for (int t0 = 0; t0 < 27; t0 += 9) {
+        float a[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) a[t] = 0.f;
+        for (int k = 0; k < nsplit; ++k) {
+          const float* s = s0 + k * sstride + t0 * tstride;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) a[t] += s[t * tstride];
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o[t0 + t] = a[t];
+      }
+    } else {
+      const int tap = (int)(r / Cout);
       const float* s = s0 + (long)tap * 64 * cw;
-      float a = 0.f;
-      for (int k = 0; k < nsplit; ++k) a += s[k * sstride];
-      o[tap] = a;
+      float p[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[j] = 0.f;
+      int k = 0;
+      for (; k + 8 <= nsplit; k += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[j] += s[(k + j) * sstride];
+      }
+      for (int j = 0; k < nsplit; ++k, ++j) p[j] += s[k * sstride];
+      o[tap] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     }
   }
 }
@@ -1297,7 +1322,8 @@ void plan_zwalk(const DramConvDesc* d, ZGeom& g) {
   const long long cols = (long long)d->B * d->dil * d->dil * d->dil * g.Ty * g.Tx;
   // z segments: enough workgroups for two per CU, never shorter than 4 planes (each segment re-reads 2 halo planes)
   int nzs = 1;
-  while (cols * nzs * g.npairs < 512 && g.Lz / (nzs * 2) >= 4) nzs *= 2;
+  static const int zw_wgs = getenv("DRAM_BF16_ZWALK_WGS") ? atoi(getenv("DRAM_BF16_ZWALK_WGS")) : 512;     // A/B
+  while (cols * nzs * g.npairs < zw_wgs && g.Lz / (nzs * 2) >= 4) nzs *= 2;
   g.nzs = nzs;
   g.lseg = (g.Lz + nzs - 1) / nzs;
   g.ncol = (int)(cols * nzs);

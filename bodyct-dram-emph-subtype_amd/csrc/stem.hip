@@ -284,14 +284,32 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const float* __restr
   }
 }
 
-__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslab) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 64*NTAP
-  if (i >= 64 * NTAP) return;
-  const int co = i / NTAP, tap = i - co * NTAP;
-  if (tap >= 343) return;
-  float s = 0.f;
-  for (int k = 0; k < nslab; ++k) s += slab[(long)k * 64 * NTAP + i];
-  dw[co * 343 + tap] = s;
+// 64 results x 4 slab groups per block; a thread sums its group's slabs (k = kg, kg + 4, ...) in eight interleaved
+// partial sums, the four groups are combined through LDS in a fixed order (deterministic).  One thread per result with
+// a serial sum over 512 slabs was latency-bound: 120 us.
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                int nslab) {
+  __shared__ float part[4][64];
+  const int r = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + r;  // over 64*NTAP
+  const bool live = i < 64 * NTAP;
+  float p[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p[j] = 0.f;
+  if (live) {
+    int k = kg;
+    for (; k + 28 < nslab; k += 32) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[j] += slab[(long)(k + 4 * j) * 64 * NTAP + i];
+    }
+    for (int j = 0; k < nslab; k += 4, ++j) p[j] += slab[(long)k * 64 * NTAP + i];
+  }
+  part[kg][r] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+  __syncthreads();
+  if (kg == 0 && live) {
+    const int co = i / NTAP, tap = i - co * NTAP;
+    if (tap < 343) dw[co * 343 + tap] = (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
+  }
 }
 
 inline int stem_out(int n) { return (n + 6 - 7) / 2 + 1; }
@@ -353,7 +371,7 @@ static int stem_bwd_weight_impl(const float* x, const T* dy, float* dw, int B, i
                 4.0 * ((double)B * D * H * W + 64.0 * 343.0) + sizeof(T) * vo * 64.0, s);
   hipLaunchKernelGGL((stem_wgrad_kernel<T>), dim3(nblk), dim3(256), 0, s, x, dy, (float*)workspace, g);
   DRAM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * NTAP + 255) / 256), dim3(256), 0, s,
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * NTAP + 63) / 64), dim3(256), 0, s,
                      (const float*)workspace, dw, nblk);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;

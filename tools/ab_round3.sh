@@ -1,3 +1,11 @@
-for h in 1 3 4 5; do echo "== DRAM_WINO_HALF=$h"; DRAM_WINO_HALF=$h python tools/conv_bench.py 2 64 128 128 128 64 3 1 1 fwd,dgrad 10 2>&1 | grep ConvGeom | cut -c1-8,90-130; DRAM_WINO_HALF=$h python tools/conv_bench.py 2 16 32 32 512 512 3 1 4 fwd 10 2>&1 | grep ConvGeom | cut -c1-8,90-130; done
-DRAM_WINO_HALF=4 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "wino" 2>&1 | tail -2
-DRAM_WINO_HALF=5 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "wino" 2>&1 | tail -2
+set -e
+mkdir -p gpurun_out/ab
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py tests/test_bf16_gpu.py -x -q -m gpu > gpurun_out/ab/pytest.txt 2>&1 || { tail -40 gpurun_out/ab/pytest.txt; exit 1; }
+tail -2 gpurun_out/ab/pytest.txt
+for w in 512 256 128; do echo "== ZWALK_WGS=$w"; DRAM_BF16_ZWALK_WGS=$w timeout -k 10 200 python tools/conv_bf16_bench.py 10 2>&1 | grep -v amdgpu | sed 's/fwd.*wgrad/wgrad/' | grep -E "layer1|us1.1|us2|us3|per step"; done
+timeout -k 10 200 python tools/conv_bf16_bench.py 10 2>&1 | grep -v amdgpu | sed 's/fwd.*wgrad/wgrad/'
+for c in 2 1; do python bench.py --no-cpu-baseline --timeline off --config $c 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('config$c', round(d['value'],2), round(d['ms_per_step'],3))"; done
