@@ -343,8 +343,16 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
                                     int taps, int Cout, int Cin) {
   const long per = (long)taps * Cout * Cin;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += slab[(long)k * per + i];
+    float p[8];                        // eight interleaved partial sums: eight loads in flight, fixed combination order
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = 0.f;
+    int k = 0;
+    for (; k + 8 <= nslab; k += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[j] += slab[(long)(k + j) * per + i];
+    }
+    for (int j = 0; k < nslab; ++k, ++j) p[j] += slab[(long)k * per + i];
+    const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     const int ci = (int)(i % Cin);
     const long r = i / Cin;
     const int co = (int)(r % Cout);

@@ -217,8 +217,18 @@ __global__ __launch_bounds__(1024) void wgrad_w2d_reduce_kernel(const float* __r
   const int a = blockIdx.y;
   float s = 0.f;
   if (i < n) {
+    // eight interleaved partial sums (eight loads in flight; a serial sum was latency-bound), fixed combination order
     const float* src = slab + ((long)xi * 3 + a) * n + i;
-    for (int k = 0; k < nslab; ++k) s += src[(long)k * 48 * n];
+    float p[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = 0.f;
+    int k = 0;
+    for (; k + 8 <= nslab; k += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[j] += src[(long)(k + j) * 48 * n];
+    }
+    for (int j = 0; k < nslab; ++k, ++j) p[j] += src[(long)k * 48 * n];
+    s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
   }
   us[xi][e] = s;
   __syncthreads();

@@ -1539,9 +1539,16 @@ WinoGeom c1_geom(const DramConvDesc* d) {
 }
 __global__ void slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, const long n, const int nsplit) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slab[(long)k * n + i];
-    out[i] = s;
+    float p[4];                         // four interleaved partial sums (loads in flight), fixed combination order
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = 0.f;
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p[j] += slab[(long)(k + j) * n + i];
+    }
+    for (int j = 0; k < nsplit; ++k, ++j) p[j] += slab[(long)k * n + i];
+    out[i] = (p[0] + p[1]) + (p[2] + p[3]);
   }
 }
 }  // namespace
