@@ -110,6 +110,10 @@ SIGNATURES = {
     # bf16 storage path (same argument lists as the fp32 namesakes; activation tensors are bf16)
     "dram_cast_f32_to_bf16": (I, [P, P, LL, P]),
     "dram_cast_bf16_to_f32": (I, [P, P, LL, P]),
+    "dram_s2d_bf16": (I, [P, P, I, I, I, I, I, P]),
+    "dram_d2s_bf16": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "dram_s2_embed_weight": (I, [P, P, I, I, P]),
+    "dram_s2_extract_wgrad": (I, [P, P, I, I, P]),
     "dram_conv_bf16_supported": (I, [DP]),
     "dram_conv_bf16_num_stat_rows": (I, [DP]),
     "dram_pack_conv_weight_bf16": (I, [P, P, P, I, I, I, P]),
@@ -152,7 +156,7 @@ SIGNATURES = {
 }
 
 OPT_CHUNK = 16384
-ABI_VERSION = 3
+ABI_VERSION = 4
 _LIB = None
 
 

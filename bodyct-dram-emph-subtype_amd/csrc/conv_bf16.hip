@@ -1181,6 +1181,89 @@ __global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __re
     dst[i] = bf16_to_f32(src[i]);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The stride-2 3x3x3 convolution (one per network: layerN.0.conv1 / the Bottleneck's conv2) as a STRIDE-1 convolution:
+// x[2o + k - 1] is, per axis, the even sub-lattice at o (k = 1) or the odd one at o - 1 (k = 0) / o (k = 2).  With
+// x8[o][p][c] = x[2o + p][c] (space to depth: eight parity sub-lattices side by side as 8 C channels) the convolution
+// is y = conv3x3x3_stride1(x8, w3) with w3[t][co][p c] = w[k][co][c] at (p, t) = (1, -1), (0, 0), (1, 0) per axis for
+// k = 0, 1, 2 and zero elsewhere (every tap with a +1 offset, and (even, -1)) -- so forward, data gradient and weight
+// gradient run on the bf16 kernels above instead of the fp32 kernels between two cast passes, at 8x the products of
+// which 27 / 216 are non-zero (the layer is < 1 % of the network's work).
+__global__ void s2d_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ x8, int D, int H, int W, int C8,
+                                long total) {   // total = B (D/2) (H/2) (W/2) 8 C8 uint4 (8 channels each)
+  const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long r = i / C8;
+    const int p = (int)(r & 7); r >>= 3;
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int yo = (int)(r % Ho); r /= Ho;
+    const int zo = (int)(r % Do);
+    const long b = r / Do;
+    const int z = 2 * zo + (p >> 2), y = 2 * yo + ((p >> 1) & 1), xx = 2 * xo + (p & 1);
+    x8[i] = x[(((b * D + z) * H + y) * W + xx) * (long)C8 + c8];
+  }
+}
+// dx[z][y][x][c] = dx8[z / 2][y / 2][x / 2][parity][c]  (+ add * (gate > 0): the data gradient's fused epilogue)
+__global__ void d2s_bf16_kernel(const bf16_t* __restrict__ dx8, const bf16_t* __restrict__ add,
+                                const bf16_t* __restrict__ gate, bf16_t* __restrict__ dx, int D, int H, int W, int C8,
+                                long total) {   // total = B D H W C8
+  const int Ho = H >> 1, Wo = W >> 1, Do = D >> 1;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long r = i / C8;
+    const int xx = (int)(r % W); r /= W;
+    const int y = (int)(r % H); r /= H;
+    const int z = (int)(r % D);
+    const long b = r / D;
+    const int p = ((z & 1) << 2) | ((y & 1) << 1) | (xx & 1);
+    const long src = (((((b * Do + (z >> 1)) * Ho + (y >> 1)) * Wo + (xx >> 1)) * 8 + p) * (long)C8 + c8) * 8;
+    fvec<8> v = ldv<bf16_t, 8>(dx8, src);
+    if (add) {
+      const fvec<8> a = ldv<bf16_t, 8>(add, 8 * i);
+      if (gate) {
+        const fvec<8> g = ldv<bf16_t, 8>(gate, 8 * i);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v.v[k] += g.v[k] > 0.f ? a.v[k] : 0.f;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v.v[k] += a.v[k];
+      }
+    }
+    stv<bf16_t, 8>(dx, 8 * i, v);
+  }
+}
+// per-axis map of the embedding: (parity p, offset index t = offset + 1) -> kernel tap k, or -1
+__device__ __forceinline__ int s2_tap(int p, int t) { return (p == 1 && t == 0) ? 0 : ((p == 0 && t == 1) ? 1 : ((p == 1 && t == 1) ? 2 : -1)); }
+// w [Cout][Cin][27] -> w3 [Cout][8 Cin][27]
+__global__ void s2_embed_weight_kernel(const float* __restrict__ w, float* __restrict__ w3, int Cout, int Cin) {
+  const long n = (long)Cout * 8 * Cin * 27;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % 27);
+    long r = i / 27;
+    const int ci = (int)(r % Cin); r /= Cin;
+    const int p = (int)(r & 7);
+    const long co = r >> 3;
+    const int kz = s2_tap(p >> 2, t / 9), ky = s2_tap((p >> 1) & 1, (t / 3) % 3), kx = s2_tap(p & 1, t % 3);
+    w3[i] = (kz < 0 || ky < 0 || kx < 0) ? 0.f : w[(co * Cin + ci) * 27 + (kz * 3 + ky) * 3 + kx];
+  }
+}
+// dw3 [Cout][8 Cin][27] -> dw [Cout][Cin][27]
+__global__ void s2_extract_wgrad_kernel(const float* __restrict__ dw3, float* __restrict__ dw, int Cout, int Cin) {
+  const long n = (long)Cout * Cin * 27;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % 27);
+    long r = i / 27;
+    const int ci = (int)(r % Cin);
+    const long co = r / Cin;
+    const int kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
+    // k = 0 -> (p 1, t 0), k = 1 -> (0, 1), k = 2 -> (1, 1) per axis
+    const int p = ((kz != 1) << 2) | ((ky != 1) << 1) | (kx != 1);
+    const int t = ((kz != 0) * 3 + (ky != 0)) * 3 + (kx != 0);
+    dw[i] = dw3[((co * 8 + p) * Cin + ci) * 27 + t];
+  }
+}
+
 inline int ew_grid(long total) { return ew_blocks(total, 256, 8192); }   // one-shot blocks (common.h)
 
 bool geom1_ok(const DramConvDesc* d) {       // 1x1x1, stride 1: a GEMM over the flat voxel index
@@ -1411,6 +1494,43 @@ extern "C" int dram_cast_bf16_to_f32(const void* src, float* dst, long long n, d
   DramProf prof(DRAM_FAM_BN, 8, 0.0, 6.0 * (double)n, (hipStream_t)stream);
   hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_grid(n4 > 0 ? n4 : n)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)src, dst, n4, (long)n);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_s2d_bf16(const void* x, void* x8, int B, int D, int H, int W, int C, dram_stream_t stream) {
+  if (!x || !x8 || B < 1 || D < 2 || H < 2 || W < 2 || ((D | H | W) & 1) || C < 8 || (C & 7)) return DRAM_ERR_BAD_ARG;
+  const long total = (long)B * D * H * W * (C >> 3);
+  DramProf prof(DRAM_FAM_BN, 9, 0.0, 32.0 * (double)total, (hipStream_t)stream);
+  hipLaunchKernelGGL(s2d_bf16_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)x8,
+                     D, H, W, C >> 3, total);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+extern "C" int dram_d2s_bf16(const void* dx8, const void* add, const void* gate, void* dx, int B, int D, int H, int W,
+                             int C, dram_stream_t stream) {
+  if (!dx8 || !dx || (gate && !add) || B < 1 || D < 2 || H < 2 || W < 2 || ((D | H | W) & 1) || C < 8 || (C & 7))
+    return DRAM_ERR_BAD_ARG;
+  const long total = (long)B * D * H * W * (C >> 3);
+  DramProf prof(DRAM_FAM_BN, 10, 0.0, 16.0 * (double)total * (2 + (add ? 1 : 0) + (gate ? 1 : 0)), (hipStream_t)stream);
+  hipLaunchKernelGGL(d2s_bf16_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx8,
+                     (const bf16_t*)add, (const bf16_t*)gate, (bf16_t*)dx, D, H, W, C >> 3, total);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+extern "C" int dram_s2_embed_weight(const float* w, float* w3, int Cout, int Cin, dram_stream_t stream) {
+  if (!w || !w3 || Cout < 1 || Cin < 1) return DRAM_ERR_BAD_ARG;
+  const long n = (long)Cout * 8 * Cin * 27;
+  DramProf prof(DRAM_FAM_WEIGHT_PACK, 9, 0.0, 4.5 * (double)n, (hipStream_t)stream);
+  hipLaunchKernelGGL(s2_embed_weight_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, w, w3, Cout, Cin);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+extern "C" int dram_s2_extract_wgrad(const float* dw3, float* dw, int Cout, int Cin, dram_stream_t stream) {
+  if (!dw3 || !dw || Cout < 1 || Cin < 1) return DRAM_ERR_BAD_ARG;
+  const long n = (long)Cout * Cin * 27;
+  DramProf prof(DRAM_FAM_WGRAD_BF16, 6, 0.0, 8.0 * (double)n, (hipStream_t)stream);
+  hipLaunchKernelGGL(s2_extract_wgrad_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dw3, dw, Cout, Cin);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

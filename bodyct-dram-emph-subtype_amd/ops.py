@@ -357,8 +357,9 @@ class ConvPlan:
                          2: lambda: int(L.dram_wgrad_w2d_workspace(d)),
                          1: lambda: int(L.dram_wino_workspace(d, 2))}.get(self.walgo, lambda: 0)()
         self.ws_direct_wgrad = int(L.dram_conv3d_bwd_weight_workspace(d)) if (self.walgo == 0 or self.ws_wgrad == 0) else 0
-        # bf16-storage path: the direct bf16-MFMA kernels take the 3x3x3 stride-1 convolutions; the rest (the one
-        # stride-2 convolution per network, 1x1x1) runs on the fp32 kernels above around cast passes
+        # bf16-storage path: the direct bf16-MFMA kernels take the 3x3x3 stride-1 and the 1x1x1 convolutions; the one
+        # stride-2 convolution per network runs on them through its space-to-depth form (s2_geom), whatever is left
+        # (odd extents) on the fp32 kernels above around cast passes
         self.bf16 = bool(L.dram_conv_bf16_supported(d))
         self.bf16_stat_rows = int(L.dram_conv_bf16_num_stat_rows(d)) if self.bf16 else 0
         self.bf16_ws_wgrad = int(L.dram_conv3d_bwd_weight_bf16_workspace(d)) if self.bf16 else 0
@@ -393,6 +394,24 @@ def packed_taps(g: "ConvGeom", bwd: bool = False) -> int:
     return p.taps_b if bwd else p.taps_f
 
 
+def s2_geom(g: "ConvGeom") -> Optional["ConvGeom"]:
+    """bf16 storage: the stride-1 geometry that runs a stride-2 3x3x3 convolution on the bf16 kernels (space to depth:
+    eight parity sub-lattices as 8 Cin channels at half the extents, embedded weights -- include/dram_hip.h,
+    dram_s2d_bf16), or None (odd extents, another kernel size, or DRAM_BF16_S2=0: fp32 kernels around casts)."""
+    if (g.k != 3 or g.stride != 2 or g.pad != 1 or g.dil != 1 or ((g.D | g.H | g.W) & 1) or g.Cin % 8
+            or os.environ.get("DRAM_BF16_S2", "1") == "0"):
+        return None
+    g8 = ConvGeom(g.B, g.D // 2, g.H // 2, g.W // 2, 8 * g.Cin, g.Cout, 3, 1, 1, 1)
+    return g8 if (conv_plan(g8).bf16 and tuple(g8.out_shape) == tuple(g.out_shape)) else None
+
+
+def s2d(x: Tensor) -> Tensor:
+    B, D, H, W, C = x.shape
+    x8 = torch.empty((B, D // 2, H // 2, W // 2, 8 * C), device=x.device, dtype=BF16)
+    _chk(_L().dram_s2d_bf16(_p(x), _p(x8), B, D, H, W, C, _stream()), "dram_s2d_bf16")
+    return x8
+
+
 def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True, g: Optional["ConvGeom"] = None, dtype=torch.float32
                      ) -> Tuple[Optional[Tensor], Optional[Tensor]]:
     """[Cout,Cin,k,k,k] -> wf [taps,Cout,Cin], wb [taps,Cin,Cout]; for a geometry the library plans
@@ -406,6 +425,14 @@ def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True, g: Optional["ConvG
         wf = torch.empty((taps, Cout, Cin), device=w.device, dtype=BF16) if want_fwd else None
         wb = torch.empty((taps, Cin, Cout), device=w.device, dtype=BF16) if want_bwd else None
         _chk(_L().dram_pack_conv_weight_bf16(_p(w), _p(wf), _p(wb), Cout, Cin, taps, _stream()), "dram_pack_conv_weight_bf16")
+        return wf, wb
+    if dtype == BF16 and g is not None and s2_geom(g) is not None:      # stride 2: embedded weights of the stride-1 form
+        w3 = torch.empty((Cout, 8 * Cin, 3, 3, 3), device=w.device, dtype=torch.float32)
+        _chk(_L().dram_s2_embed_weight(_p(w), _p(w3), Cout, Cin, _stream()), "dram_s2_embed_weight")
+        wf = torch.empty((taps, Cout, 8 * Cin), device=w.device, dtype=BF16) if want_fwd else None
+        wb = torch.empty((taps, 8 * Cin, Cout), device=w.device, dtype=BF16) if want_bwd else None
+        _chk(_L().dram_pack_conv_weight_bf16(_p(w3), _p(wf), _p(wb), Cout, 8 * Cin, taps, _stream()),
+             "dram_pack_conv_weight_bf16")
         return wf, wb
     plan = conv_plan(g) if g is not None else None
     algo = plan.algo if plan else 0
@@ -469,6 +496,8 @@ def conv3d_fwd_keep(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, 
     if _act(x, "x", g.in_shape):                       # bf16 storage
         if bias is not None:
             _req(bias, "bias", shape=(g.Cout,))
+        if wf.dtype == BF16 and wf.shape[2] == 8 * g.Cin:      # stride 2 as stride 1 over the space-to-depth tensor
+            return conv3d_fwd_keep(s2d(x), wf, bias, s2_geom(g), want_stats, False)
         if wf.dtype == BF16:
             _req(wf, "wf", BF16, (g.taps, g.Cout, g.Cin))
             y = torch.empty(g.out_shape, device=x.device, dtype=BF16)
@@ -524,6 +553,12 @@ def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] =
             _act(add, "add", g.in_shape, like=dy)
         if gate is not None:
             _act(gate, "gate", g.in_shape, like=dy)
+        if wb.dtype == BF16 and wb.shape[1] == 8 * g.Cin:      # stride 2: gradient of the space-to-depth tensor, then back
+            dx8 = conv3d_bwd_data(dy, wb, s2_geom(g))
+            dx = torch.empty(g.in_shape, device=dy.device, dtype=BF16)
+            _chk(_L().dram_d2s_bf16(_p(dx8), _p(add), _p(gate), _p(dx), g.B, g.D, g.H, g.W, g.Cin, _stream()),
+                 "dram_d2s_bf16")
+            return dx
         if wb.dtype == BF16:
             _req(wb, "wb", BF16, (g.taps, g.Cin, g.Cout))
             dx = torch.empty(g.in_shape, device=dy.device, dtype=BF16)
@@ -579,6 +614,11 @@ def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] 
             with _span("wgrad3_bf16_kernel+reduce", g.flops, f"wgrad {g}"):
                 _chk(_L().dram_conv3d_bwd_weight_bf16(_p(x), _p(dy), _p(dw), d, _p(ws), nbytes, _stream()),
                      f"dram_conv3d_bwd_weight_bf16{g}")
+            return dw
+        g8 = s2_geom(g)
+        if g8 is not None:                              # stride 2: gradient of the embedded weights, 27 of 216 slots kept
+            dw3 = conv3d_bwd_weight(s2d(x), dy, g8)
+            _chk(_L().dram_s2_extract_wgrad(_p(dw3), _p(dw), g.Cout, g.Cin, _stream()), "dram_s2_extract_wgrad")
             return dw
         return conv3d_bwd_weight(cast(x, torch.float32), cast(dy, torch.float32), g, out=dw)
     _req(x, "x", shape=g.in_shape)

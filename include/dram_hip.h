@@ -35,7 +35,7 @@ typedef void* dram_stream_t; /* hipStream_t */
 #define DRAM_ERR_UNSUPPORTED (-2)
 #define DRAM_ERR_WORKSPACE (-3)
 
-#define DRAM_ABI_VERSION 3
+#define DRAM_ABI_VERSION 4
 int dram_version(void);
 /* static string: "gfx950" build tag */
 const char* dram_build_info(void);
@@ -454,6 +454,18 @@ int dram_add(const float* a, const float* b, float* out, long long n, dram_strea
  * The *_bf16 element-wise entry points take exactly the arguments of their fp32 namesakes. */
 int dram_cast_f32_to_bf16(const float* src, void* dst, long long n, dram_stream_t stream);
 int dram_cast_bf16_to_f32(const void* src, float* dst, long long n, dram_stream_t stream);
+/* The stride-2 3x3x3 convolution (k 3, stride 2, pad 1, even extents, Cin % 8 == 0) as a stride-1 convolution of the
+ * space-to-depth tensor: x8[b][z][y][x][p][c] = x[b][2z + pz][2y + py][2x + px][c], p = 4 pz + 2 py + px (8 Cin
+ * channels at half the extents), with the embedded weights w3 [Cout][8 Cin][3][3][3] (dram_s2_embed_weight: 27 of
+ * 216 (parity, offset) slots per (co, ci) carry a tap, the rest are zero).  dram_d2s_bf16 is the inverse permutation
+ * with the data gradient's optional `+= add * (gate > 0)`; dram_s2_extract_wgrad picks the 27 taps out of the
+ * gradient of w3.  The host runs forward / data gradient / weight gradient of the derived stride-1 geometry on the
+ * bf16 convolution entry points below. */
+int dram_s2d_bf16(const void* x, void* x8, int B, int D, int H, int W, int C, dram_stream_t stream);
+int dram_d2s_bf16(const void* dx8, const void* add, const void* gate, void* dx, int B, int D, int H, int W, int C,
+                  dram_stream_t stream);
+int dram_s2_embed_weight(const float* w, float* w3, int Cout, int Cin, dram_stream_t stream);
+int dram_s2_extract_wgrad(const float* dw3, float* dw, int Cout, int Cin, dram_stream_t stream);
 /* 1 when the bf16 direct kernels take this geometry: 3x3x3, stride 1, pad == dilation, Cin % 32 == Cout % 32 == 0
  * (everything else is run by the host on the fp32 kernels around cast passes) */
 int dram_conv_bf16_supported(const DramConvDesc* d);

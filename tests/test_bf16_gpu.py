@@ -147,11 +147,52 @@ def test_conv1x1_bf16_gemm(ops, case):
     assert torch.equal(dw, ops.conv3d_bwd_weight(nd(x.detach()), nd(gy), g))
 
 
-@pytest.mark.parametrize("case", [(1, 8, 12, 10, 64, 128, 3, 2, 1), (2, 6, 8, 8, 128, 128, 3, 2, 1)], ids=str)
-def test_conv_bf16_fallback_geometries(ops, case):
-    """stride 2 (one convolution per network): outside the bf16 kernels -> fp32 kernels around cast passes,
-    bf16 in / bf16 out."""
-    B, D, H, W, Cin, Cout, k, stride, dil = case
+@pytest.mark.parametrize("case", [(1, 8, 12, 10, 64, 128), (2, 6, 8, 8, 128, 128), (1, 4, 8, 6, 32, 64)], ids=str)
+def test_conv_bf16_stride2_as_space_to_depth(ops, case):
+    """The stride-2 3x3x3 convolution (one per network) on the bf16 kernels: stride 1 over the space-to-depth tensor
+    with the embedded weights (dram_s2d_bf16 / dram_s2_embed_weight / dram_d2s_bf16 / dram_s2_extract_wgrad).  Same
+    bars as the stride-1 kernels, against the fp64 convolution of the same bf16 operands."""
+    B, D, H, W, Cin, Cout = case
+    x = r16(rnd(B, Cin, D, H, W, seed=1)).requires_grad_(True)
+    w32 = rnd(Cout, Cin, 3, 3, 3, seed=2) * 0.1
+    w = r16(w32).requires_grad_(True)
+    bias = rnd(Cout, seed=3)
+    y_ref = F.conv3d(x.double(), w.double(), bias.double(), 2, 1, 1)
+    gy = r16(rnd(*y_ref.shape, seed=4))
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, [x, w], gy.double())
+    g = ops.ConvGeom(B, D, H, W, Cin, Cout, 3, 2, 1, 1)
+    g8 = ops.s2_geom(g)
+    assert not ops.conv_plan(g).bf16 and g8 is not None and g8.Cin == 8 * Cin
+    wf, wb = ops.pack_conv_weight(w32.to(DEV), True, True, g, BF)
+    assert wf.dtype == BF and tuple(wf.shape) == (27, Cout, 8 * Cin) and tuple(wb.shape) == (27, 8 * Cin, Cout)
+    # 27 of the 216 (parity, offset) slots of a (co, ci) pair carry a tap
+    assert int((wf.float() != 0).sum()) <= 27 * Cout * Cin
+    y, stats, _ = ops.conv3d_fwd_keep(nd(x.detach()), wf, bias.to(DEV), g, True, False)
+    assert y.dtype == BF and tuple(y.shape) == tuple(g.out_shape) and rel_l2(nc(y), y_ref.detach()) < 2e-3
+    s = ops.reduce_partials(stats).cpu()
+    yr = nc(y).double()
+    assert torch.allclose(s[0], yr.sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[1], (yr * yr).sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    dx = ops.conv3d_bwd_data(nd(gy), wb, g)
+    assert dx.dtype == BF and tuple(dx.shape) == tuple(g.in_shape) and rel_l2(nc(dx), gx_ref) < 2e-3
+    add, gate = r16(rnd(B, Cin, D, H, W, seed=5)), r16(rnd(B, Cin, D, H, W, seed=6))
+    # (the shortcut-gradient epilogue is applied by the depth-to-space pass on the ROUNDED gradient: two roundings)
+    dx2 = ops.conv3d_bwd_data(nd(gy), wb, g, nd(add), nd(gate))
+    assert rel_l2(nc(dx2), gx_ref + (add * (gate > 0).float()).double()) < 3e-3
+    dx3 = ops.conv3d_bwd_data(nd(gy), wb, g, nd(add), None)
+    assert rel_l2(nc(dx3), gx_ref + add.double()) < 3e-3
+    dw = ops.conv3d_bwd_weight(nd(x.detach()), nd(gy), g)
+    assert dw.dtype == torch.float32 and tuple(dw.shape) == (Cout, Cin, 3, 3, 3) and rel_l2(dw.cpu(), gw_ref) < 2e-5
+    assert torch.equal(dw, ops.conv3d_bwd_weight(nd(x.detach()), nd(gy), g))
+
+
+@pytest.mark.parametrize("case", [(1, 8, 12, 10, 64, 128, 3, 2, 1, "0"), (2, 6, 8, 8, 128, 128, 3, 2, 1, "0"),
+                                  (1, 7, 8, 9, 64, 64, 3, 2, 1, "1")], ids=str)
+def test_conv_bf16_fallback_geometries(ops, case, monkeypatch):
+    """Outside the bf16 kernels (stride 2 with the space-to-depth form switched off, or with odd extents) -> fp32
+    kernels around cast passes, bf16 in / bf16 out."""
+    B, D, H, W, Cin, Cout, k, stride, dil, s2 = case
+    monkeypatch.setenv("DRAM_BF16_S2", s2)
     pad = dil * (k - 1) // 2
     x = r16(rnd(B, Cin, D, H, W, seed=1)).requires_grad_(True)
     w = (rnd(Cout, Cin, k, k, k, seed=2) * 0.1).requires_grad_(True)
@@ -159,7 +200,7 @@ def test_conv_bf16_fallback_geometries(ops, case):
     gy = r16(rnd(*y_ref.shape, seed=4))
     gx_ref, gw_ref = torch.autograd.grad(y_ref, [x, w], gy)
     g = ops.ConvGeom(B, D, H, W, Cin, Cout, k, stride, pad, dil)
-    assert not ops.conv_plan(g).bf16
+    assert not ops.conv_plan(g).bf16 and ops.s2_geom(g) is None
     wf, wb = ops.pack_conv_weight(w.detach().to(DEV), True, True, g, BF)
     assert wf.dtype == torch.float32
     y, stats, _ = ops.conv3d_fwd_keep(nd(x.detach()), wf, None, g, True, False)
@@ -361,7 +402,10 @@ def test_network_train_step_bf16_storage(factory, shape, mode):
         if e_ref != e_ref:          # the reference's autocast backward overflowed to NaN on this tensor
             e_ref = float("inf")
         worst = max(worst, (e, e_ref, n))
-        assert e <= max(1e-1, 1.5 * e_ref), f"{n}: bf16-storage gradient vs decision-pinned fp64 oracle {e:.2e} (reference autocast vs its fp32 self: {e_ref:.2e})"
+        # (2x the reference autocast's own distance where that is larger: every convolution, the strided one included,
+        # multiplies bf16 operands here and every activation is ROUNDED to bf16 between layers, which the reference's
+        # CPU autocast -- fp32 BatchNorm outputs -- does not do; 1.5x held while the strided convolution ran in fp32)
+        assert e <= max(1e-1, 2.0 * e_ref), f"{n}: bf16-storage gradient vs decision-pinned fp64 oracle {e:.2e} (reference autocast vs its fp32 self: {e_ref:.2e})"
     print(f"[{factory} bf16] worst gradient vs decision-pinned fp64 oracle (hip, reference-autocast-vs-fp32, tensor): {worst}")
 
 
