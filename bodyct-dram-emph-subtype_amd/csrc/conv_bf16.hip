@@ -705,6 +705,9 @@ struct ZGeom {
   int nblk;
 };
 
+// NCB: 32-channel co halves of the block that exist (1 for Cout = 32 -- the us3 layer: the second half would multiply
+// zero rows; 7 accumulators per wave instead of 14)
+template <int NCB>
 __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                            float* __restrict__ slab, const ZGeom g) {
   __shared__ __attribute__((aligned(1024))) unsigned char xr0[16384];   // x plane ring: [2 ib][100 voxels][64 B], padded
@@ -727,11 +730,11 @@ __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restr
 
   const int ib = wave & 1, t0 = wave >> 1;
   const int ntap = t0 < 3 ? 7 : 6;
-  f32x16 acc[7][2];
+  f32x16 acc[7][NCB];
 #pragma unroll
   for (int i = 0; i < 7; ++i)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][cb][e] = 0.f;
 
@@ -835,7 +838,8 @@ __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restr
 #pragma unroll 1
           for (int ks = 0; ks < 4; ++ks) {
             const bf16x8 a0 = tr8(dl + ks * 1024, a_lane[0], a_lane[1]);
-            const bf16x8 a1 = tr8(dl + 4096 + ks * 1024, a_lane[0], a_lane[1]);
+            bf16x8 a1 = a0;
+            if (NCB == 2) a1 = tr8(dl + 4096 + ks * 1024, a_lane[0], a_lane[1]);
             bf16x8 bq[7];
             auto bfrag = [&](int i) __attribute__((always_inline)) {
               // x plane z + kz - 1 lives in slot (u + kz) & 3 (named arrays: see RING_ in conv3_bf16_kernel)
@@ -856,9 +860,9 @@ __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restr
             for (int i = 0; i < 7; ++i) {
               if (i + DRAM_ZW_AHEAD < 7) bfrag(i + DRAM_ZW_AHEAD);
               acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[i], acc[i][0], 0, 0, 0);
-              acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[i], acc[i][1], 0, 0, 0);
+              if (NCB == 2) acc[i][NCB - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[i], acc[i][NCB - 1], 0, 0, 0);
               if (i + DRAM_ZW_AHEAD < 7) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, NCB, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -878,7 +882,7 @@ __global__ __launch_bounds__(512) void wgrad3z_bf16_kernel(const bf16_t* __restr
     if (i < ntap) {
       const int tap = i < 6 ? (i >> 1) * 9 + 2 * t0 + (i & 1) : t0 * 9 + 8;
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
+      for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -1607,10 +1611,14 @@ extern "C" int dram_conv3d_bwd_weight_bf16(const void* x, const void* dy, float*
     hipStream_t sz = (hipStream_t)stream;
     const double voxz = (double)d->B * d->D * d->H * d->W;
     {
-      DramProf prof(DRAM_FAM_WGRAD_BF16, 2, 2.0 * voxz * 27.0 * d->Cin * z.co_blocks * 64.0,
+      DramProf prof(DRAM_FAM_WGRAD_BF16, 2, 2.0 * voxz * 27.0 * d->Cin * (d->Cout <= 32 ? 32.0 : z.co_blocks * 64.0),
                     2.0 * voxz * (d->Cin + d->Cout) + 4.0 * 27.0 * d->Cin * d->Cout, sz, 2.0 * voxz * 27.0 * d->Cin * d->Cout);
-      hipLaunchKernelGGL(wgrad3z_bf16_kernel, dim3(z.nblk), dim3(512), 0, sz, (const bf16_t*)x, (const bf16_t*)dy,
-                         (float*)workspace, z);
+      if (d->Cout <= 32)
+        hipLaunchKernelGGL(wgrad3z_bf16_kernel<1>, dim3(z.nblk), dim3(512), 0, sz, (const bf16_t*)x, (const bf16_t*)dy,
+                           (float*)workspace, z);
+      else
+        hipLaunchKernelGGL(wgrad3z_bf16_kernel<2>, dim3(z.nblk), dim3(512), 0, sz, (const bf16_t*)x, (const bf16_t*)dy,
+                           (float*)workspace, z);
       DRAM_LAUNCH_CHECK();
     }
     const long nz = (long)d->Cout * d->Cin * 27;
