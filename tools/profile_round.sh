@@ -11,7 +11,7 @@ rm -rf $O && mkdir -p $O
 cd $R
 python bench.py --steps 20 --warmup 5 > $O/bench_config1.json.log 2>$O/bench_config1.err
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --detail $O/bench_config1_per_layer.txt > $O/bench_config1_detail.json.log 2>/dev/null
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --timeline off > $O/bench_config1_no_timeline.json.log 2>/dev/null
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --timeline off --no-graph > $O/bench_config1_no_timeline.json.log 2>/dev/null
 for c in 0 3 5; do python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config$c.json.log 2>/dev/null; done
 python bench.py --config 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_config2.json.log 2>/dev/null          # bf16, as specified
 python bench.py --config 2 --dtype f32 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config2_f32.json.log 2>/dev/null
@@ -22,15 +22,15 @@ cd /tmp && export TMPDIR=/tmp
 # overlapping the data-gradient chain on a second stream, per-kernel durations contain the time a kernel shared its
 # CUs with the other stream's kernel and would not be comparable
 export DRAM_WGRAD_STREAM=0
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --timeline off > $O/bench_config1_under_rocprofv3.json.log 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --timeline off > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --timeline off > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --timeline off > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --timeline off --no-graph > $O/bench_config1_under_rocprofv3.json.log 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --timeline off --no-graph > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --timeline off --no-graph > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --timeline off --no-graph > /dev/null 2>&1
 # the same four passes for BASELINE configs[2] as specified (bf16 storage path)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c2 -- python3 $R/bench.py --config 2 --steps 5 --warmup 2 --no-cpu-baseline --timeline off > $O/bench_config2_under_rocprofv3.json.log 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_c2 -- python3 $R/bench.py --config 2 --steps 3 --warmup 1 --no-cpu-baseline --timeline off > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_c2 -- python3 $R/bench.py --config 2 --steps 3 --warmup 1 --no-cpu-baseline --timeline off > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq_c2 -- python3 $R/bench.py --config 2 --steps 3 --warmup 1 --no-cpu-baseline --timeline off > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c2 -- python3 $R/bench.py --config 2 --steps 5 --warmup 2 --no-cpu-baseline --timeline off --no-graph > $O/bench_config2_under_rocprofv3.json.log 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_c2 -- python3 $R/bench.py --config 2 --steps 3 --warmup 1 --no-cpu-baseline --timeline off --no-graph > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_c2 -- python3 $R/bench.py --config 2 --steps 3 --warmup 1 --no-cpu-baseline --timeline off --no-graph > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq_c2 -- python3 $R/bench.py --config 2 --steps 3 --warmup 1 --no-cpu-baseline --timeline off --no-graph > /dev/null 2>&1
 # keep only the small csv files (kernel traces of the PMC passes are not needed)
 find $O -name "*agent_info.csv" -delete
 find $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_fetch_c2 $O/pmc_write_c2 $O/pmc_sq_c2 -name "*kernel_trace.csv" -delete
