@@ -19,7 +19,7 @@ is_dma = lambda l: "global_load_lds" in l or ("buffer_load" in l and l.rstrip().
 for f in files:
     out = f"/tmp/isa_{os.path.basename(f)}.s"
     r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-                        "--offload-device-only", "-S", f, "-o", out], capture_output=True, text=True)
+                        "-DDRAM_ABI_HASH=\"isa\"", "--offload-device-only", "-S", f, "-o", out], capture_output=True, text=True)
     if r.returncode:
         print(f"{f}: compile failed\n{r.stderr[-400:]}")
         continue
