@@ -646,17 +646,22 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 
 // dw[co][ci][27] = G^T (sum over splits of slab[split][xi][co][ci]) G   (3-D), fixed order.
 // One workgroup = 64 (co, ci) elements x 8 point groups (512 threads): every thread sums every 8th of
-// the NP points over the splits (coalesced over elements), then 64 threads apply G^T . G (3-D).
+// the NP points over the splits (coalesced over elements); then wave a transforms z plane a in x and y (G^T . G of a
+// 6 x 6 plane -> 3 x 3), waves 0..2 the z columns, and all threads store the 64 x 27 results as ONE contiguous run.
+// (The first version left all of G^T . G . G to one wave per workgroup -- 630 flops and 216 LDS reads per lane in
+// 128 registers: 48 spilled -- and stored 27 floats per lane 108 bytes apart.)
 template <int NZ, int NY, int NX>
 __global__ __launch_bounds__(512) void wino_wgrad_out_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                                const int Cout, const int Cin, const int nsplit) {
   constexpr int NI = NZ + 2, NJ = NY + 2, NK = NX + 2, NP = NI * NJ * NK;
   __shared__ float us[NP][64];
+  __shared__ float qs[NI][9][64];
+  __shared__ float rs[64][28];
   const long n = (long)Cout * Cin;
   const int e = threadIdx.x & 63, gq = threadIdx.x >> 6;
   const long i = blockIdx.x * 64L + e;   // (co, ci), ci fastest
   constexpr int PPT = NP / 8;            // points per thread (NP is a multiple of 8 for every tiling)
-  static_assert(NP % 8 == 0, "points per group");
+  static_assert(NP % 8 == 0 && NI <= 8, "points per group; one wave per z plane");
   float acc[PPT];
 #pragma unroll
   for (int j = 0; j < PPT; ++j) acc[j] = 0.f;
@@ -668,10 +673,8 @@ __global__ __launch_bounds__(512) void wino_wgrad_out_kernel(const float* __rest
 #pragma unroll
   for (int j = 0; j < PPT; ++j) us[gq + 8 * j][e] = acc[j];
   __syncthreads();
-  if (gq != 0 || i >= n) return;
-  float q[NI][3][3], r[3][3][3];
-#pragma unroll
-  for (int a = 0; a < NI; ++a) {
+  if (gq < NI) {                          // plane a = gq: x then y
+    const int a = gq;
     float p[NJ][3];
 #pragma unroll
     for (int b = 0; b < NJ; ++b) {
@@ -686,22 +689,25 @@ __global__ __launch_bounds__(512) void wino_wgrad_out_kernel(const float* __rest
 #pragma unroll
       for (int b = 0; b < NJ; ++b) col[b] = p[b][k];
       gtz<NY>(col, rr);
-      q[a][0][k] = rr[0]; q[a][1][k] = rr[1]; q[a][2][k] = rr[2];
+      qs[a][0 * 3 + k][e] = rr[0]; qs[a][1 * 3 + k][e] = rr[1]; qs[a][2 * 3 + k][e] = rr[2];
     }
   }
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
+  __syncthreads();
+  if (gq < 3) {                           // z columns (j = gq, k = 0..2)
+    const int j = gq;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       float col[NI], rr[3];
 #pragma unroll
-      for (int a = 0; a < NI; ++a) col[a] = q[a][j][k];
+      for (int a = 0; a < NI; ++a) col[a] = qs[a][j * 3 + k][e];
       gtz<NZ>(col, rr);
-      r[0][j][k] = rr[0]; r[1][j][k] = rr[1]; r[2][j][k] = rr[2];
+      rs[e][0 * 9 + j * 3 + k] = rr[0]; rs[e][1 * 9 + j * 3 + k] = rr[1]; rs[e][2 * 9 + j * 3 + k] = rr[2];
     }
-  float* dst = dw + i * 27;
-#pragma unroll
-  for (int a = 0; a < 27; ++a) dst[a] = (&r[0][0][0])[a];
+  }
+  __syncthreads();
+  const long base = blockIdx.x * 64L * 27, lim = n * 27;
+  for (int idx = threadIdx.x; idx < 64 * 27; idx += 512)
+    if (base + idx < lim) dw[base + idx] = rs[idx / 27][idx % 27];
 }
 
 // ------------------------------------------------------------------------------------------
