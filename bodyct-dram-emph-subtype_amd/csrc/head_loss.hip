@@ -42,6 +42,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
 #pragma unroll
   for (int c = 0; c <= NOT; ++c) acc[c] = 0.f;
   for (long v = blockIdx.x * 256L + tid; v < vps; v += (long)gridDim.x * 256L) {
+    // the weights are re-read from LDS for every voxel: left alone the compiler hoists all 32 NOT reads out of this
+    // loop -- 366 VGPRs for the 9-output head, one wave per SIMD under a kernel that lives on loads in flight
+    asm volatile("" ::: "memory");
     float4 xv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) xv[k] = ld4<T>(x, (b * vps + v) * 32 + 4 * k);

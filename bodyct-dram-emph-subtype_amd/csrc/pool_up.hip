@@ -324,10 +324,12 @@ __global__ void upcat_bwd_src_kernel(const T* __restrict__ dcat, T* __restrict__
     fvec<VW> acc;
 #pragma unroll
     for (int k = 0; k < VW; ++k) acc.v[k] = 0.f;
-#pragma unroll 1
+    // (both loops fully unrolled: indexed with a loop variable the weight tables were moved to LDS by the compiler --
+    // 56 KB per workgroup, two workgroups per CU for a kernel that lives on loads in flight)
+#pragma unroll
     for (int jz = 0; jz < 6; ++jz) {
       if (tz.w[jz] == 0.f) continue;
-#pragma unroll 1
+#pragma unroll
       for (int jy = 0; jy < 6; ++jy) {
         const float wzy = tz.w[jz] * ty.w[jy];
         if (wzy == 0.f) continue;
@@ -340,7 +342,7 @@ __global__ void upcat_bwd_src_kernel(const T* __restrict__ dcat, T* __restrict__
         for (int jx = 0; jx < 6; ++jx) {
           const float w_ = wzy * tx.w[jx];
 #pragma unroll
-          for (int k = 0; k < VW; ++k) acc.v[k] += w_ * g[jx].v[k];
+          for (int k = 0; k < VW; ++k) acc.v[k] = __builtin_fmaf(w_, g[jx].v[k], acc.v[k]);   // (explicit: every instantiation contracts alike)
         }
       }
     }
