@@ -293,3 +293,29 @@ def test_every_python_source_compiles_and_has_no_merge_markers():
         src = open(f).read()
         compile(src, f, "exec")
         assert not any(ln.startswith(("<" * 7 + " ", ">" * 7 + " ")) for ln in src.splitlines()), f
+
+
+def test_streaming_kernels_carry_no_hidden_lds_or_spills():
+    """tools/isa_waits.py --table on the pool / up-sampling kernels (one hipcc -S, ~15 s): the kernels that declare no
+    __shared__ memory must use none -- a private array indexed by a loop variable is silently moved to LDS by the
+    compiler (upcat_bwd_src_kernel once carried 56 KB per workgroup that way: two workgroups per CU) -- and nothing
+    may spill (scratch reloads count on vmcnt and drain prefetches)."""
+    import shutil
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not present")
+    src = os.path.join(ROOT, "bodyct-dram-emph-subtype_amd", "csrc", "pool_up.hip")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_waits.py"), "--table", src],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l.split() for l in r.stdout.splitlines() if " vgpr " in l]
+    assert len(rows) >= 12, r.stdout
+    for l in r.stdout.splitlines():
+        if " vgpr " not in l:
+            continue
+        name = l.split("vgpr")[0].split(None, 1)[1].strip()
+        vgpr, lds, spills = (int(l.split(k)[1].split()[0]) for k in ("vgpr", "lds", "spills"))
+        assert spills == 0, l
+        if not name.startswith(("upcat_fwd_tiled_kernel", "upproject_kernel")):       # the two kernels that declare LDS
+            assert lds == 0, l
+        assert vgpr <= 128, l
