@@ -146,6 +146,39 @@ def make_step(factory, module, opt, batch):
     return step
 
 
+_ENV_SAVED = {}
+
+
+def single_stream(on: bool):
+    """Run the following steps on ONE stream (the engine's A/B switch DRAM_WGRAD_STREAM=0, which counts under
+    DRAM_TUNING=1 only), or restore what the environment held before."""
+    if on:
+        for k, v in (("DRAM_TUNING", "1"), ("DRAM_WGRAD_STREAM", "0")):
+            _ENV_SAVED[k] = os.environ.get(k)
+            os.environ[k] = v
+    else:
+        for k, v in _ENV_SAVED.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        _ENV_SAVED.clear()
+
+
+def host_cpu_share():
+    """(CPUs the job owns, threads to run CPU work on).  cgroup v2 `cpu.max` = "<quota> <period>" or "max ..."; without
+    a quota the job owns every visible CPU."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(n, -(-int(quota) // int(period))))
+            return cores, max(1, min(n, 2 * cores))
+    except (OSError, ValueError):
+        pass
+    return n, n
+
+
 def cpu_baseline(factory, dims):
     """Oracle train steps (fwd + loss + bwd + Adam) on the host cores: 1 warm-up + 2 timed steps of ONE
     volume of the benchmarked shape (BASELINE.md §3 plan).  Bounded: dims are capped at 128x256x256."""
@@ -159,7 +192,11 @@ def cpu_baseline(factory, dims):
     names = [n for n, _ in m.named_parameters()]
     image, lung, em, cle, pse = synth_batch(1, dims, 0, "cpu")
     mom = {n: (torch.zeros_like(sd[n]), torch.zeros_like(sd[n])) for n in names}
-    cores = torch.get_num_threads()
+    # `cores` = CPUs this job OWNS (cgroup cpu.max quota; the GPU box shows all 128 hardware threads of the host but
+    # grants 16 CPUs), `threads` = intra-op threads the oracle ran on (2 x the share: measured fastest,
+    # tools/cpu_threads_probe.py -- torch's default of one thread per visible hardware thread oversubscribes 8x)
+    cores, threads = host_cpu_share()
+    torch.set_num_threads(threads)
     times = []
     for it in range(3):
         t0 = time.perf_counter()
@@ -177,10 +214,11 @@ def cpu_baseline(factory, dims):
                 sd[n] = p
         times.append(time.perf_counter() - t0)
     dt = (times[1] + times[2]) / 2
-    return {"value": 1.0 / dt, "unit": "volumes/sec", "cores": cores, "kind": "port",
+    return {"value": 1.0 / dt, "unit": "volumes/sec", "cores": cores, "threads": threads, "kind": "port",
             "sample": f"{factory} train step (oracle, torch CPU ops, fwd+loss+bwd+Adam), batch 1 of "
                       f"1x{dims[0]}x{dims[1]}x{dims[2]}: 1 warm-up ({times[0]:.1f} s) + 2 timed steps "
-                      f"({times[1]:.1f} s, {times[2]:.1f} s), {cores} host threads"}
+                      f"({times[1]:.1f} s, {times[2]:.1f} s), {threads} threads on the {cores} CPUs the job owns "
+                      f"(cgroup cpu.max; {os.cpu_count()} hardware threads visible)"}
 
 
 def family_table(fams, steps, step_s, bf16_mfma=("conv_bf16", "wgrad_bf16")):
@@ -380,6 +418,13 @@ def main():
     barrier()
     timeline = ops.KernelTimeline(max_records=max(4096, 2048 * args.steps)) if (args.timeline != "off" and rank == 0) else None
     prof = None
+    if args.detail:
+        # per-call table: ONE stream (with the weight-gradient kernels overlapping the data-gradient chain on the
+        # second stream a call's event interval would contain the time it shared the CUs with the other stream's
+        # kernel: round 3's table summed conv_wgrad_w2d to 8.8 ms against 4.1 ms in the single-stream timeline)
+        single_stream(True)
+        step()
+        barrier()
     if args.detail and rank == 0:
         prof = ops.KernelProfiler()
         ops.set_profiler(prof)
@@ -398,6 +443,8 @@ def main():
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_step_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     ops.set_profiler(None)
+    if args.detail:
+        single_stream(False)
     tl_step_s = dt / args.steps
     if args.graph:
         step = eager_step                   # the timeline pass brackets individual launches: eager
@@ -407,7 +454,7 @@ def main():
         # runs the step on ONE stream (DRAM_WGRAD_STREAM=0): with the weight-gradient kernels overlapping the
         # data-gradient chain on a second stream a kernel's event interval would also contain the time it
         # shared its CUs with the other stream's kernel, and per-family fractions would mean nothing.
-        os.environ["DRAM_WGRAD_STREAM"] = "0"
+        single_stream(True)
         step()
         barrier()
         if dctx is not None:
@@ -419,7 +466,7 @@ def main():
             step()
         barrier()
         tl_step_s = (time.perf_counter() - t1) / args.steps
-        os.environ.pop("DRAM_WGRAD_STREAM", None)
+        single_stream(False)
         if dctx is not None:
             exposed_ms = dctx.exposed_ms() / args.steps
             dctx.timing = False
@@ -432,6 +479,8 @@ def main():
     if rank == 0 and prof is not None:
         rows = sorted(prof.by_launch().items(), key=lambda kv: -kv[1]["ms"])
         with open(args.detail, "w") as f:
+            f.write(f"# bench.py --config {args.config} --dtype {args.dtype} --detail: per-call hipEvent intervals, SINGLE-STREAM "
+                    f"pass (DRAM_WGRAD_STREAM=0), {args.steps} steps; TF = direct-convolution FLOPs / time\n")
             for (fam, det), v in rows:
                 tf = (v["flops"] / 1e12) / (v["ms"] / 1e3) if v["ms"] > 0 else 0.0
                 f.write(f"{v['ms'] / args.steps:9.3f} ms/step  {v['launches'] // args.steps:3d}x  {tf:7.1f} TF  {fam}  {det}\n")
@@ -457,6 +506,7 @@ def main():
                                    f"{'fp32' if args.dtype == 'f32' else 'bf16 storage / fp32 accumulation, statistics and parameters'}, "
                                    f"inputs resident in HBM",
                        "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(args.graph),
+                       "streams": 1 if (args.detail or args.graph or ops.tuning_env("DRAM_WGRAD_STREAM", "1") == "0") else 2,
                        "train_gflop_per_volume": gflop_per_vol},
             "loss": float(loss.detach()),
             "peak_hbm_gb": torch.cuda.max_memory_allocated(device) / 1e9,
@@ -470,7 +520,7 @@ def main():
                 out["exposed_collective_ms"] = exposed_ms
         if timeline:
             fams = timeline.families()
-            bf16_fams = ("conv_bf16", "wgrad_bf16") + (("stem",) if (args.dtype == "bf16" and os.environ.get("DRAM_STEM_BF16", "1") != "0") else ())
+            bf16_fams = ("conv_bf16", "wgrad_bf16") + (("stem",) if (args.dtype == "bf16" and ops.tuning_env("DRAM_STEM_BF16", "1") != "0") else ())
             rows = family_table(fams, args.steps, tl_step_s, bf16_fams)
             default_dtype = "bf16" if args.config in BF16_CONFIGS else "f32"
             traffic, tsrc = measured_traffic(args.config) if (args.config in (1, 2) and args.dtype == default_dtype) else (None, None)

@@ -58,7 +58,8 @@ def source_hash() -> str:
 
 def _flags():
     # DRAM_EXTRA_HIPCC_FLAGS: ablation builds of the tuning tools (e.g. -DDRAM_BF16_ABL=3); part of the object keys
-    extra = os.environ.get("DRAM_EXTRA_HIPCC_FLAGS", "").split()
+    # (honoured under DRAM_TUNING=1 only: the ablation macros produce garbage results by design)
+    extra = os.environ.get("DRAM_EXTRA_HIPCC_FLAGS", "").split() if os.environ.get("DRAM_TUNING", "0") == "1" else []
     return ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", f'-DDRAM_ABI_HASH="{abi_hash()}"',
             "-I", INCLUDE, "-I", CSRC] + extra
 

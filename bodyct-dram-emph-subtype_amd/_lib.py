@@ -103,6 +103,12 @@ SIGNATURES = {
     "dram_maxpool_bwd": (I, [P, P, P, I, P, I, I, I, I, I, P]),
     "dram_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "dram_upcat_bwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "dram_upmix_stat_rows": (I, [LL]),
+    "dram_upmix_axis_fwd": (I, [P, I, P, LL, I, I, I, P]),
+    "dram_upmix_axis_fwd_final": (I, [P, P, P, I, P, LL, I, I, I, P]),
+    "dram_upmix_axis_bwd": (I, [P, I, P, I, LL, I, I, I, P]),
+    "dram_upmix_split_weight": (I, [P, P, P, I, I, I, P]),
+    "dram_upmix_merge_wgrad": (I, [P, P, P, I, I, I, P]),
     "dram_head_nblk": (I, [LL]),
     "dram_head_fwd": (I, [P, P, P, P, I, I, I, P, P, I, I, I, I, I, I, P]),
     "dram_head_bwd_nparts": (I, [LL]),
@@ -156,7 +162,7 @@ SIGNATURES = {
 }
 
 OPT_CHUNK = 16384
-ABI_VERSION = 4
+ABI_VERSION = 5
 _LIB = None
 
 

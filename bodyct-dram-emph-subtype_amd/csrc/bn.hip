@@ -488,7 +488,7 @@ static int bn_apply_impl(const T* y, const float* scale, const float* shift, con
   DramProf prof(DRAM_FAM_BN, 2, 0.0, 4.0 * sizeof(T) * (double)total4 * (2.0 + res_frac), s);
   const int Q = C >> 2;
   const bool identity = residual && rs == 1 && Cr == C && Dr == D && Hr == H && Wr == W;
-  static const int ew_u = getenv("DRAM_EW_U") ? atoi(getenv("DRAM_EW_U")) : 4;      // A/B switch (tools/ew_bench.py)
+  static const int ew_u = tune_env("DRAM_EW_U") ? atoi(tune_env("DRAM_EW_U")) : 4;      // A/B switch (tools/ew_bench.py)
   if ((!residual || identity) && 256 % Q == 0 && ew_u > 0 && ew_shape() > 0) {
     const int g1 = ew_blocks(total4, 1024, 0);
 #define BN_SHOT_(RES_, NT_) hipLaunchKernelGGL((bn_apply_shot_kernel<RES_, T, NT_>), dim3(g1), dim3(256), 0, s, y, scale, \

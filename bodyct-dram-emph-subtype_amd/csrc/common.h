@@ -128,12 +128,20 @@ template <> __device__ __forceinline__ void st4s<bf16_t>(bf16_t* p, long off, fl
   __builtin_nontemporal_store(t, reinterpret_cast<u32x2_nt*>(p + off));
 }
 
+// Test / A-B switches (DRAM_CONV_ALGO, DRAM_W2D_V, DRAM_WINO_TILING, DRAM_EW_SHAPE, ...) are read from the environment
+// ONLY when DRAM_TUNING=1 is set as well (tests/conftest.py and the tools set it): a stray DRAM_* variable in a user's
+// environment cannot silently change which kernel variant the product path runs.
+static inline const char* tune_env(const char* name) {
+  static const bool on = [] { const char* t = getenv("DRAM_TUNING"); return t && t[0] == '1'; }();
+  return on ? getenv(name) : nullptr;
+}
+
 // Launch shape of the streaming element-wise kernels: ONE-SHOT blocks (block b owns elements [b * per, (b + 1) * per),
 // no grid-stride loop) -- the dispatcher hands blocks out in order, so the chip sweeps a narrow moving window of each
 // tensor; a capped grid with a grid-stride loop reads + writes 1 GiB at 4.6-5.0 TB/s, one-shot blocks at 6.0-6.2
 // (tools/stream_probe.hip).  DRAM_EW_SHAPE=0 restores the capped grid (A/B).
 static inline int ew_shape() {
-  static const int v = getenv("DRAM_EW_SHAPE") ? atoi(getenv("DRAM_EW_SHAPE")) : 2;   // 0 capped, 1 one-shot, 2 + nt
+  static const int v = tune_env("DRAM_EW_SHAPE") ? atoi(tune_env("DRAM_EW_SHAPE")) : 2;   // 0 capped, 1 one-shot, 2 + nt
   return v;
 }
 // streaming cache policy only for tensors that cannot stay in the 256 MiB Infinity Cache anyway: on a 67 MB tensor
@@ -155,6 +163,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   const int q = nblk >> 3, r = nblk & 7;
   const int xcd = bid & 7, idx = bid >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// Trilinear source index -- PyTorch area_pixel_compute_source_index with align_corners=True:
+//   scale = (in-1)/(out-1) (float; 0 when out == 1), src = scale*dst, i0 = (int)src,
+//   i1 = i0 + (i0 < in-1), w1 = src - i0, w0 = 1 - w1.   (pool_up.hip, upmix.hip)
+__device__ __forceinline__ void lin_src(int dst, float scale, int in, int& i0, int& i1, float& w0, float& w1) {
+  const float s = scale * (float)dst;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  w1 = s - (float)i0;
+  w0 = 1.f - w1;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -1312,7 +1312,7 @@ void fill_tiles(const DramConvDesc* d, int& Tz, int& Ty, int& Tx, long long& nti
 // it feeds zeros to the matrix pipe.
 int pick_nw(const DramConvDesc* d, int n_tiles) {
   (void)d; (void)n_tiles;
-  if (const char* e = getenv("DRAM_BF16_NW")) {
+  if (const char* e = tune_env("DRAM_BF16_NW")) {
     const int v = atoi(e);
     if (v == 4 || v == 8) return v;
   }
@@ -1363,7 +1363,7 @@ void plan_wgrad(const DramConvDesc* d, WGeom& g) {
   // buffering), at most 256 slabs: a slab is 27 x 2048 floats per (pair, split) and the reduce reads them all
   // (512 -> 512 @ 2x16x32x32, ms: 1024 workgroups 0.69, 512 0.55, 256 0.56; 256 -> 256: 0.40 / 0.26 / 0.19)
   // ... and 576 -> 64 @ 2x32x64x64 (1,024 tiles, 18 pairs): 0.73 / - / 0.93 -- large volumes want the finer split
-  const int wgs = getenv("DRAM_BF16_WGRAD_WGS") ? atoi(getenv("DRAM_BF16_WGRAD_WGS")) : (g.ntile >= 512 ? 1024 : 256);
+  const int wgs = tune_env("DRAM_BF16_WGRAD_WGS") ? atoi(tune_env("DRAM_BF16_WGRAD_WGS")) : (g.ntile >= 512 ? 1024 : 256);
   int ns = (wgs + g.npairs - 1) / g.npairs;
   if (ns > g.ntile / 2) ns = g.ntile / 2;
   if (ns > 256) ns = 256;
@@ -1390,7 +1390,7 @@ void launch_reduce(const float* slab, float* dw, int Cout, int Cin, int ci_block
 
 bool use_zwalk(const DramConvDesc* d) {
   if (d->Cin % 64 != 0) return false;
-  const char* e = getenv("DRAM_BF16_WGRAD");
+  const char* e = tune_env("DRAM_BF16_WGRAD");
   if (e && !strcmp(e, "tile")) return false;
   if (e && !strcmp(e, "zwalk")) return true;
   const int lz = (d->D + d->dil - 1) / d->dil;
@@ -1409,7 +1409,7 @@ void plan_zwalk(const DramConvDesc* d, ZGeom& g) {
   const long long cols = (long long)d->B * d->dil * d->dil * d->dil * g.Ty * g.Tx;
   // z segments: enough workgroups for two per CU, never shorter than 4 planes (each segment re-reads 2 halo planes)
   int nzs = 1;
-  static const int zw_wgs = getenv("DRAM_BF16_ZWALK_WGS") ? atoi(getenv("DRAM_BF16_ZWALK_WGS")) : 512;     // A/B
+  static const int zw_wgs = tune_env("DRAM_BF16_ZWALK_WGS") ? atoi(tune_env("DRAM_BF16_ZWALK_WGS")) : 512;     // A/B
   while (cols * nzs * g.npairs < zw_wgs && g.Lz / (nzs * 2) >= 4) nzs *= 2;
   g.nzs = nzs;
   g.lseg = (g.Lz + nzs - 1) / nzs;
@@ -1636,7 +1636,7 @@ extern "C" int dram_conv3d_bwd_weight_bf16(const void* x, const void* dy, float*
   {
     DramProf prof(DRAM_FAM_WGRAD_BF16, 0, 2.0 * (double)g.ntile * 256.0 * 27.0 * g.ci_blocks * 32.0 * g.co_blocks * 64.0,
                   2.0 * vox * (d->Cin + d->Cout) + 4.0 * 27.0 * d->Cin * d->Cout, s, 2.0 * vox * 27.0 * d->Cin * d->Cout);
-    static const bool old_form = getenv("DRAM_BF16_WGRAD_TILE") && !strcmp(getenv("DRAM_BF16_WGRAD_TILE"), "old");   // A/B
+    static const bool old_form = tune_env("DRAM_BF16_WGRAD_TILE") && !strcmp(tune_env("DRAM_BF16_WGRAD_TILE"), "old");   // A/B
     if (old_form)
       hipLaunchKernelGGL(wgrad3_bf16_kernel, dim3(g.nblk), dim3(512), 0, s, (const bf16_t*)x, (const bf16_t*)dy,
                          (float*)workspace, g);

@@ -755,7 +755,7 @@ int pick_bn(int N) {
 int igemm_version() {   // DRAM_IGEMM_V: 0 auto, 1 register-staged, 2 LDS-DMA tiles, 3 LDS-resident halo
   static int ver = -1;
   if (ver < 0) {
-    const char* v = getenv("DRAM_IGEMM_V");
+    const char* v = tune_env("DRAM_IGEMM_V");
     ver = v ? atoi(v) : 0;
   }
   return ver;
@@ -768,7 +768,7 @@ bool plan_v3(const DramConvDesc* d, int N, int Do, int Ho, int Wo, V3Plan& p) {
   const int ver = igemm_version();
   if (ver != 0 && ver != 3) return false;
   if (d->k != 3 || d->stride != 1 || d->pad != d->dil) return false;
-  if (const char* f = getenv("DRAM_IGEMM_V3_FORCE")) {   // tests / tuning: "tz3,bn", e.g. "4,256"
+  if (const char* f = tune_env("DRAM_IGEMM_V3_FORCE")) {   // tests / tuning: "tz3,bn", e.g. "4,256"
     int tz = 0, bn = 0;
     if (sscanf(f, "%d,%d", &tz, &bn) == 2 && (tz == 4 || tz == 8) && N % bn == 0 &&
         ((tz == 8 && (bn == 32 || bn == 64)) || (tz == 4 && (bn == 128 || bn == 256)))) {

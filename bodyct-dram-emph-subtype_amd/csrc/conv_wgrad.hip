@@ -421,7 +421,7 @@ bool make_plan(const DramConvDesc* d, Plan& p) {
 
 // z-walking plan (v2): stride 1, dilation 1, 3x3x3, pad 1, channels multiple of 32
 bool make_plan2(const DramConvDesc* d, W2Geom& g) {
-  if (const char* e = getenv("DRAM_WGRAD_V")) { if (e[0] == '1') return false; }
+  if (const char* e = tune_env("DRAM_WGRAD_V")) { if (e[0] == '1') return false; }
   if (!d || d->k != 3 || d->stride != 1 || d->dil != 1 || d->pad != 1) return false;
   if (d->Cin % 32 != 0 || d->Cout % 32 != 0) return false;
   g.B = d->B; g.D = d->D; g.H = d->H; g.W = d->W; g.Cin = d->Cin; g.Cout = d->Cout;

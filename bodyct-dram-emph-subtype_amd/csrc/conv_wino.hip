@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(512) void wino_gemm_tn_bf16_kernel(const float* __r
 // operands, three bf16 MFMA products per fp32 product, ~2^-16 per product) | "bf16" (bf16 operands, fp32
 // accumulation).  Read per call, like the other overrides: tests switch it between cases.
 int math_mode() {
-  const char* e = getenv("DRAM_MATH");
+  const char* e = tune_env("DRAM_MATH");
   if (!e) return 0;
   if (!strcmp(e, "bf16x3")) return 1;
   if (!strcmp(e, "bf16")) return 2;
@@ -1311,7 +1311,7 @@ long long tiles_for(const DramConvDesc* d, int nz, int ny, int nx) {
 // instantiated tilings: 4x4x4, 4x4x2, 4x2x2, 2x2x2;  DRAM_WINO_TILING = "z,y,x" forces one (tests)
 void pick_tiling(const DramConvDesc* d, const int pass, int& nz, int& ny, int& nx) {
   static const int cand[4][3] = {{4, 4, 4}, {4, 4, 2}, {4, 2, 2}, {2, 2, 2}};
-  if (const char* e = getenv("DRAM_WINO_TILING")) {
+  if (const char* e = tune_env("DRAM_WINO_TILING")) {
     int a = 0, b = 0, c = 0;
     if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3)
       for (int i = 0; i < 4; ++i)
@@ -1405,7 +1405,7 @@ bool plan_tn(const DramConvDesc* d, const WinoGeom& g, TnPlan& p) {
 // streaming (non-temporal) cache policy on the Winograd-domain images, which are written once and read once:
 // bit 0 the input transform's stores, bit 1 the output transform's loads   (DRAM_WINO_NT, A/B switch)
 int wino_nt() {
-  static const int v = getenv("DRAM_WINO_NT") ? atoi(getenv("DRAM_WINO_NT")) : 3;
+  static const int v = tune_env("DRAM_WINO_NT") ? atoi(tune_env("DRAM_WINO_NT")) : 3;
   return v;
 }
 
@@ -1422,7 +1422,7 @@ int launch_wino_in(const float* src, float* dst, const WinoGeom& g, const int C,
   const double in_elems = (double)g.B * g.D * g.H * g.W * C;
   DramProf prof(DRAM_FAM_WINO_IN, MODE * 1000 + g.nz * 100 + g.ny * 10 + g.nx, 0.0,
                 4.0 * (in_elems + (double)g.npts * g.Tpad * C), s);
-  static const int half = getenv("DRAM_WINO_HALF") ? atoi(getenv("DRAM_WINO_HALF")) : 1;   // A/B switch (tools)
+  static const int half = tune_env("DRAM_WINO_HALF") ? atoi(tune_env("DRAM_WINO_HALF")) : 1;   // A/B switch (tools)
   if (half && g.nz == 4 && g.ny == 4 && g.nx == 4) {
     if (math) hipLaunchKernelGGL((wino_in444_kernel<MODE, true, false>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C);
     else if (wino_nt() & 1) hipLaunchKernelGGL((wino_in444_kernel<MODE, false, true>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C);
@@ -1458,7 +1458,7 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
     const double cost = (double)((wgs + 255) / 256) * c * (c == 4 ? 1.0 : (c == 2 ? 1.03 : 1.10));
     if (cost < best) { best = cost; nj = c; }
   }
-  if (const char* e = getenv("DRAM_NN_NJ")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && N % (64 * v) == 0) nj = v; }
+  if (const char* e = tune_env("DRAM_NN_NJ")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && N % (64 * v) == 0) nj = v; }
   const int n_tiles = N / (64 * nj);
   const int nblk = g.npts * m_tiles * n_tiles;
   // executed: 2*M*N*K per point; algorithmic bytes: A, U read once, Y written once
@@ -1478,7 +1478,7 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
 #define WNN(NJ_)                                                                                                   \
   hipLaunchKernelGGL((wino_gemm_nn_kernel<NJ_>), dim3(nblk), dim3(512), 0, s, A, U, Y, g.Tpad, N, K, m_tiles, n_tiles, \
                      nblk, g.npts, ep, epi_lds)
-  static const int epi_lds = getenv("DRAM_WINO_EPI") ? atoi(getenv("DRAM_WINO_EPI")) : 1;      // A/B switch
+  static const int epi_lds = tune_env("DRAM_WINO_EPI") ? atoi(tune_env("DRAM_WINO_EPI")) : 1;      // A/B switch
   if (nj == 4) WNN(4);
   else if (nj == 2) WNN(2);
   else WNN(1);
@@ -1667,7 +1667,7 @@ static double direct_rate(const DramConvDesc* d, double N) {
 }
 
 extern "C" int dram_conv_algo(const DramConvDesc* d) {
-  const char* v = getenv("DRAM_CONV_ALGO");   // read per call: tests switch it between cases
+  const char* v = tune_env("DRAM_CONV_ALGO");   // read per call: tests switch it between cases
   const int algo = v ? atoi(v) : 0;
   if (algo == 1) return 0;
   if (c1_ok(d)) return 3;                              // 1x1x1: plain GEMM on the batched-GEMM kernels
@@ -1710,7 +1710,7 @@ constexpr double W2D_WGRAD_RATE = 240e12;   // measured 197-257 TFLOP/s direct-e
 // Cost per voxel: both tile transforms (36 B x (Cin + Cout) at ~4.9 TB/s) + the 64 TN GEMMs
 // (16 Cin Cout flops at ~125 TFLOP/s or their 32 (Cin + Cout) B of operands at ~4.7 TB/s).
 extern "C" int dram_conv_wgrad_algo(const DramConvDesc* d) {
-  const char* v = getenv("DRAM_CONV_ALGO");
+  const char* v = tune_env("DRAM_CONV_ALGO");
   const int algo = v ? atoi(v) : 0;
   if (algo == 1) return 0;
   if (c1_ok(d)) return 3;

@@ -670,7 +670,7 @@ bool w2d_ok(const DramConvDesc* d, int K, int N) {
 // 16-deep tiles would pad the depth more than 8-deep ones or leave the chip under-filled (one workgroup per
 // CU: 128 tiles on 256 CUs run at half rate, 256 half-size tiles do not).  DRAM_W2D_V forces one (tests).
 int w2d_variant(const DramConvDesc* d, int n_tiles, int BN) {
-  if (const char* e = getenv("DRAM_W2D_V")) {
+  if (const char* e = tune_env("DRAM_W2D_V")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 3) return v;
   }

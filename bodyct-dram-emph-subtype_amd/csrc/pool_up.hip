@@ -205,18 +205,7 @@ __global__ void maxpool_bwd_blk_kernel(const T* __restrict__ dy, const uint8_t* 
   }
 }
 
-// ------------------------------------------------------------------ trilinear helpers
-// PyTorch area_pixel_compute_source_index with align_corners=True:
-//   scale = (in-1)/(out-1) (float; 0 when out == 1), src = scale*dst, i0 = (int)src,
-//   i1 = i0 + (i0 < in-1), w1 = src - i0, w0 = 1 - w1.
-__device__ __forceinline__ void lin_src(int dst, float scale, int in, int& i0, int& i1, float& w0, float& w1) {
-  const float s = scale * (float)dst;
-  i0 = (int)s;
-  if (i0 > in - 1) i0 = in - 1;
-  i1 = i0 + (i0 < in - 1 ? 1 : 0);
-  w1 = s - (float)i0;
-  w0 = 1.f - w1;
-}
+// ------------------------------------------------------------------ trilinear helpers: lin_src (common.h)
 
 template <typename T, int VW>
 __global__ void upcat_fwd_kernel(const T* __restrict__ src, const T* __restrict__ skip,
@@ -485,7 +474,7 @@ inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (flo
 // channels per thread: 8 for bf16 storage when every channel count / stride involved is a multiple of 8 (16-B
 // vectors), else 4.  DRAM_POOL_VW=4 forces the narrow form (A/B).
 static inline bool pool_wide(size_t elem, std::initializer_list<long> counts) {
-  static const bool narrow = getenv("DRAM_POOL_VW") && atoi(getenv("DRAM_POOL_VW")) == 4;
+  static const bool narrow = tune_env("DRAM_POOL_VW") && atoi(tune_env("DRAM_POOL_VW")) == 4;
   if (elem != 2 || narrow) return false;
   for (long c : counts)
     if (c & 7) return false;
@@ -534,7 +523,7 @@ static int maxpool_bwd_impl(const T* dy, const uint8_t* argmax, const T* add, in
                 (double)sizeof(T) * 4.0 * total4 * (1.0 + (add ? 1 : 0)) + (1.0 + sizeof(T)) * (double)B * Do * Ho * Wo * C,
                 (hipStream_t)stream);
   const bool wide = pool_wide(sizeof(T), {C, add ? add_stride : 0, (add && ((uintptr_t)add & 15)) ? 1 : 0});
-  static const bool per_voxel = getenv("DRAM_POOL_BWD") && !strcmp(getenv("DRAM_POOL_BWD"), "voxel");     // A/B
+  static const bool per_voxel = tune_env("DRAM_POOL_BWD") && !strcmp(tune_env("DRAM_POOL_BWD"), "voxel");     // A/B
   if (!per_voxel) {
     const long totb = (long)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2) * (C / (wide ? 8 : 4));
     POOL_LAUNCH(wide, maxpool_bwd_blk_kernel, ew_grid(totb), dy, argmax, add, add_stride, dx, D, H, W, C, Do, Ho, Wo, totb);
@@ -569,7 +558,7 @@ static int upcat_fwd_impl(const T* src, const T* skip, T* cat, int B, int Ds, in
                 (double)sizeof(T) * ((double)B * Ds * Hs * Ws * Cu + (double)B * Do * Ho * Wo * Ck + 4.0 * total4),
                 (hipStream_t)stream);
   const bool wide = pool_wide(sizeof(T), {Cu, Ck});
-  if (Cu % 64 == 0 && tiles >= 512 && tiles < (1L << 31) && !getenv("DRAM_UPCAT_UNTILED")) {
+  if (Cu % 64 == 0 && tiles >= 512 && tiles < (1L << 31) && !tune_env("DRAM_UPCAT_UNTILED")) {
     POOL_LAUNCH(wide, upcat_fwd_tiled_kernel, (unsigned)tiles, src, skip, cat, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck, oz, oy, ox,
                 ac_scale(Ds, Do), ac_scale(Hs, Ho), ac_scale(Ws, Wo), (Do + 7) / 8, (Ho + 7) / 8, (Wo + 7) / 8);
     DRAM_LAUNCH_CHECK();

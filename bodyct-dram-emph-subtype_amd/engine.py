@@ -188,8 +188,16 @@ class Engine:
 
     def _wgrad(self, st: _State, c: dict, dy: Tensor):
         out = st.dist.grad_out(c["w"]) if st.dist is not None else None
-        st.grads[c["w"]] = ops.conv3d_bwd_weight(self._input_of(c), dy, c["g"], out=out, v_cache=c.get("v"))
-        c["v"] = None                                   # release the cached Winograd-domain input
+        if c.get("kind") == "upmix":
+            # low-resolution mixing GEMM's weight gradient (taps as output channels) + the skip channels' 3x3x3 one,
+            # merged into the reference layout [Co][Cu+Cs][27]
+            dwlo = ops.conv3d_bwd_weight(c["src"], c["h"], c["g_lo"])
+            dws = ops.conv3d_bwd_weight(c["skip"], dy, c["g_s"])
+            st.grads[c["w"]] = ops.upmix_merge_wgrad(dwlo, dws, out=out)
+            c["h"] = None
+        else:
+            st.grads[c["w"]] = ops.conv3d_bwd_weight(self._input_of(c), dy, c["g"], out=out, v_cache=c.get("v"))
+            c["v"] = None                               # release the cached Winograd-domain input
         if st.dist is not None:
             names = [c["w"], c["bn"] + ".weight", c["bn"] + ".bias"] + ([c["b"]] if c["b"] else [])
             st.dist.grads_ready(st.grads, names)
@@ -203,7 +211,7 @@ class Engine:
         ready = torch.cuda.Event()
         ready.record(main)
         arena = st.dist.grad_out(c["w"]) if st.dist is not None else None     # written by the side stream's kernel
-        for t in (c["x"], dy, c.get("v"), arena) + self._recipe_inputs(c):
+        for t in (c.get("x"), dy, c.get("v"), arena, c.get("src"), c.get("skip"), c.get("h")) + self._recipe_inputs(c):
             if t is not None:
                 t.record_stream(st.side)      # the allocator must not recycle them under the side stream's kernels
         with ops.on_stream(st.side):
@@ -249,7 +257,69 @@ class Engine:
         return self._conv_bn_bwd(st, cs[0], d, need_dx=need_dx, add=dz_out, gate=last["z"])
 
     # ------------------------------------------------------------------ decoder block
+    @staticmethod
+    def _upmix_geoms(src, skip, w):
+        """(low-resolution mixing geometry, skip-convolution geometry) when the first decoder convolution can run
+        without the up-sampled tensor (csrc/upmix.hip), else None: no crop (skip is exactly twice the source), channel
+        counts the GEMM / convolution kernels take, and -- unless forced -- an up-sampled operand wide enough to pay
+        (the gather costs 28.5 FMAs + ~13 elements of traffic per output element whatever Cu; ResNet-18: 512, -50: 2 048)."""
+        mode = ops.upmix_mode()
+        B, Ds, Hs, Ws, Cu = src.shape
+        Co, Cs = w.shape[0], skip.shape[4]
+        if mode == 0 or tuple(skip.shape[1:4]) != (2 * Ds, 2 * Hs, 2 * Ws) or w.shape[1] != Cu + Cs:
+            return None
+        if Cu % 64 or Cs % 32 or Co % 32 or Co > 128:
+            return None
+        if mode == 1 and (Cu < 256 or (B * Ds * Hs * Ws) % 256 or B * Ds * Hs * Ws < 2048):
+            return None                                 # the mixing GEMM wants whole 256-row tiles and a filled chip
+        g_lo = ConvGeom(B, Ds, Hs, Ws, Cu, 27 * Co, 1, 1, 0, 1)
+        g_s = ConvGeom(B, 2 * Ds, 2 * Hs, 2 * Ws, Cs, Co, 3, 1, 1, 1)
+        return g_lo, g_s
+
+    def _upmix_fwd(self, st, src, skip, wname, bname, bnp, geoms):
+        """conv_blocks[0] of a decoder block on (src, skip) directly: y = gather(W_lo . src) + conv_s(skip) + bias."""
+        g_lo, g_s = geoms
+        w = st.P[wname]
+        Cu, Co = src.shape[4], w.shape[0]
+        wlo, ws = ops.upmix_split_weight(w, Cu)
+        wf_lo, wb_lo = ops.pack_conv_weight(wlo, True, st.need_grad, g_lo, st.storage)
+        wf_s, wb_s = ops.pack_conv_weight(ws, True, st.need_grad, g_s, st.storage)
+        b, _ = ops.conv3d_fwd(src, wf_lo, None, g_lo, False)
+        ysk, _ = ops.conv3d_fwd(skip, wf_s, st.P[bname], g_s, False)
+        y, sp = ops.upmix_gather_fwd(b, ysk, Co, st.training)
+        del b
+        z, mean, invstd, count, ss = self._bn_fwd(st, y, sp, bnp, None, 1)
+        c = None
+        if st.need_grad:
+            c = dict(kind="upmix", src=src, skip=skip, y=y, z=None if st.recompute else z, mean=mean, invstd=invstd,
+                     g_lo=g_lo, g_s=g_s, wb_lo=wb_lo, wb_s=wb_s, count=count, w=wname, b=bname, bn=bnp, ss=ss, h=None)
+        return z, c
+
+    def _upmix_bwd(self, st, c, dz):
+        """-> (gradient w.r.t. the low-resolution source, gradient w.r.t. the skip tensor)"""
+        dy = self._bn_bwd(st, c, dz)
+        c["h"] = ops.upmix_gather_bwd(dy)               # read by the weight gradient (side stream) and the data gradient
+        h = c["h"]
+        if st.side is not None:
+            self._wgrad_side(st, c, dy)
+        elif st.dist is not None:
+            st.deferred = (c, dy)
+        else:
+            self._wgrad(st, c, dy)
+        dsrc = ops.conv3d_bwd_data(h, c["wb_lo"], c["g_lo"])
+        dskip = ops.conv3d_bwd_data(dy, c["wb_s"], c["g_s"])
+        return dsrc, dskip
+
     def _up_fwd(self, st, src, skip, p):
+        geoms = self._upmix_geoms(src, skip, st.P[f"{p}.conv_blocks.0.0.weight"])
+        if geoms is not None:
+            za, ca = self._upmix_fwd(st, src, skip, f"{p}.conv_blocks.0.0.weight", f"{p}.conv_blocks.0.0.bias",
+                                     f"{p}.conv_blocks.0.1", geoms)
+            zb, cb = self._conv_bn_fwd(st, za, f"{p}.conv_blocks.1.0.weight", f"{p}.conv_blocks.1.0.bias",
+                                       f"{p}.conv_blocks.1.1", 3, 1, 1, 1, xr=("bn", ca))
+            if st.recompute and cb is not None:
+                cb["z"] = zb
+            return zb, (ca, cb, tuple(src.shape), tuple(skip.shape))
         cat = ops.upcat_fwd(src, skip)
         za, ca = self._conv_bn_fwd(st, cat, f"{p}.conv_blocks.0.0.weight", f"{p}.conv_blocks.0.0.bias",
                                    f"{p}.conv_blocks.0.1", 3, 1, 1, 1, xr=("upcat", src, skip))
@@ -262,6 +332,8 @@ class Engine:
     def _up_bwd(self, st, ctx, dz, skip_view=False):
         ca, cb, src_shape, skip_shape = ctx
         dza = self._conv_bn_bwd(st, cb, dz)
+        if ca.get("kind") == "upmix":
+            return self._upmix_bwd(st, ca, dza)
         dcat = self._conv_bn_bwd(st, ca, dza)
         if skip_view and tuple(skip_shape[1:4]) == tuple(dcat.shape[1:4]):
             # no crop: the consumer reads the skip half of dcat in place (a channel-slice view) instead of a copy
@@ -292,7 +364,7 @@ class Engine:
         of the activations).  From the second step of an input shape on they all run on the engine's second
         stream at the start of forward, under the stem convolution, instead of in front of each layer."""
         plan = self._conv_lists.get(key)
-        if plan is None or os.environ.get("DRAM_WGRAD_STREAM", "1") == "0" or torch.cuda.is_current_stream_capturing():
+        if plan is None or ops.tuning_env("DRAM_WGRAD_STREAM", "1") == "0" or torch.cuda.is_current_stream_capturing():
             return
         side = ops.side_stream(key[-1])
         main = torch.cuda.current_stream()
@@ -368,7 +440,7 @@ class Engine:
         st: _State = saved["st"]
         if st.dist is not None:
             st.dist.begin_backward(saved["dense"].device)
-        if os.environ.get("DRAM_WGRAD_STREAM", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+        if ops.tuning_env("DRAM_WGRAD_STREAM", "1") != "0" and not torch.cuda.is_current_stream_capturing():
             st.side = ops.side_stream(saved["dense"].device.index)
         n0, n1 = saved["n0"], saved["n1"]
         NO = n0 + n1

@@ -50,6 +50,14 @@ def launch_scope(device):
             _TLS.scope = prev
 
 
+def tuning_env(name: str, default: str) -> str:
+    """A/B and test switches (DRAM_WGRAD_STREAM, DRAM_BF16_S2, DRAM_STEM_BF16, DRAM_SIDE_PRIORITY and the kernel-variant
+    switches read inside the library) count ONLY under DRAM_TUNING=1 (tests/conftest.py, tools/, bench.py set it): a
+    stray DRAM_* variable cannot change which kernels the product path runs.  User-facing settings --
+    DRAM_STORAGE, DRAM_RECOMPUTE, DRAM_DIST_FORCE -- are read directly (README)."""
+    return os.environ.get(name, default) if os.environ.get("DRAM_TUNING", "0") == "1" else default
+
+
 _SIDE: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -58,7 +66,7 @@ def side_stream(device_index: int) -> "torch.cuda.Stream":
     data-gradient chain on the caller's stream)."""
     s = _SIDE.get(device_index)
     if s is None:
-        prio = int(os.environ.get("DRAM_SIDE_PRIORITY", "0"))     # A/B switch (tools): HIP stream priority of the side stream
+        prio = int(tuning_env("DRAM_SIDE_PRIORITY", "0"))     # A/B switch (tools): HIP stream priority of the side stream
         s = _SIDE[device_index] = torch.cuda.Stream(device=device_index, priority=prio)
     return s
 
@@ -399,7 +407,7 @@ def s2_geom(g: "ConvGeom") -> Optional["ConvGeom"]:
     eight parity sub-lattices as 8 Cin channels at half the extents, embedded weights -- include/dram_hip.h,
     dram_s2d_bf16), or None (odd extents, another kernel size, or DRAM_BF16_S2=0: fp32 kernels around casts)."""
     if (g.k != 3 or g.stride != 2 or g.pad != 1 or g.dil != 1 or ((g.D | g.H | g.W) & 1) or g.Cin % 8
-            or os.environ.get("DRAM_BF16_S2", "1") == "0"):
+            or tuning_env("DRAM_BF16_S2", "1") == "0"):
         return None
     g8 = ConvGeom(g.B, g.D // 2, g.H // 2, g.W // 2, 8 * g.Cin, g.Cout, 3, 1, 1, 1)
     return g8 if (conv_plan(g8).bf16 and tuple(g8.out_shape) == tuple(g.out_shape)) else None
@@ -678,7 +686,7 @@ def stem_fwd(x: Tensor, w: Tensor, want_stats: bool, out_dtype=torch.float32):
         nt = _L().dram_stem_num_tiles(B, Do, Ho, Wo)
         stats = torch.empty((nt, 2, 64), device=x.device, dtype=torch.float32)
     with _span("stem_fwd_kernel", 2.0 * B * Do * Ho * Wo * 64 * 343):
-        sfx = "" if out_dtype != BF16 else ("_bf16mm" if os.environ.get("DRAM_STEM_BF16", "1") != "0" else "_bf16")
+        sfx = "" if out_dtype != BF16 else ("_bf16mm" if tuning_env("DRAM_STEM_BF16", "1") != "0" else "_bf16")
         _chk(_fn("dram_stem_fwd", sfx)(_p(x), _p(w), _p(y), _p(stats), B, D, H, W, _stream()), "dram_stem_fwd" + sfx)
     return y, stats
 
@@ -692,7 +700,7 @@ def stem_bwd_weight(x: Tensor, dy: Tensor, out: Optional[Tensor] = None) -> Tens
     dw = out if out is not None else torch.empty((64, 1, 7, 7, 7), device=x.device, dtype=torch.float32)
     _req(dw, "dw", shape=(64, 1, 7, 7, 7))
     with _span("stem_wgrad_kernel+reduce", 2.0 * dy.numel() * 343):
-        if sfx and os.environ.get("DRAM_STEM_BF16", "1") != "0":
+        if sfx and tuning_env("DRAM_STEM_BF16", "1") != "0":
             sfx = "_bf16mm"                          # bf16 matrix cores (the "_bf16" form: fp32 MFMA on the up-cast dy)
         _chk(_fn("dram_stem_bwd_weight", sfx)(_p(x), _p(dy), _p(dw), B, D, H, W, _p(ws), nbytes, _stream()),
              "dram_stem_bwd_weight" + sfx)
@@ -896,6 +904,87 @@ def upcat_bwd(dcat: Tensor, src_shape, skip_shape, need_src=True, need_skip=True
     _chk(_fn("dram_upcat_bwd", sfx)(_p(dcat), _p(dsrc), _p(dskip), B, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck, _stream()),
          "dram_upcat_bwd")
     return dsrc, dskip
+
+
+# --------------------------------------------------------------------------- us1.0 without the up-sampled tensor
+def upmix_mode() -> int:
+    """0 = never, 1 = where it pays (default), 2 = wherever the geometry allows (tests): DRAM_UPMIX under DRAM_TUNING=1."""
+    return int(tuning_env("DRAM_UPMIX", "1"))
+
+
+def upmix_split_weight(w: Tensor, Cu: int) -> Tuple[Tensor, Tensor]:
+    """w [Co, Cu+Cs, 3,3,3] -> (wlo [27*Co, Cu, 1,1,1]: the low-resolution mixing GEMM's weight, row t*Co + co;
+    ws [Co, Cs, 3,3,3]: the skip channels' convolution weight).  csrc/upmix.hip."""
+    _req(w, "w")
+    Co, Ct = w.shape[0], w.shape[1]
+    Cs = Ct - Cu
+    if tuple(w.shape[2:]) != (3, 3, 3) or Cu < 1 or Cs < 1:
+        raise ValueError(f"upmix_split_weight: weight {tuple(w.shape)}, Cu={Cu}")
+    wlo = torch.empty((27 * Co, Cu, 1, 1, 1), device=w.device, dtype=torch.float32)
+    ws = torch.empty((Co, Cs, 3, 3, 3), device=w.device, dtype=torch.float32)
+    _chk(_L().dram_upmix_split_weight(_p(w), _p(wlo), _p(ws), Co, Cu, Cs, _stream()), "dram_upmix_split_weight")
+    return wlo, ws
+
+
+def upmix_merge_wgrad(dwlo: Tensor, dws: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    Co, Cs = dws.shape[0], dws.shape[1]
+    Cu = dwlo.shape[1]
+    _req(dwlo, "dwlo", shape=(27 * Co, Cu, 1, 1, 1))
+    _req(dws, "dws", shape=(Co, Cs, 3, 3, 3))
+    dw = out if out is not None else torch.empty((Co, Cu + Cs, 3, 3, 3), device=dws.device, dtype=torch.float32)
+    _req(dw, "dw", shape=(Co, Cu + Cs, 3, 3, 3))
+    _chk(_L().dram_upmix_merge_wgrad(_p(dwlo), _p(dws), _p(dw), Co, Cu, Cs, _stream()), "dram_upmix_merge_wgrad")
+    return dw
+
+
+def upmix_gather_fwd(b: Tensor, base: Optional[Tensor], Co: int, want_stats: bool, out_dtype=None):
+    """b [B,Ds,Hs,Ws,27*Co] (tap-major: column t*Co + co) -> y [B,2Ds,2Hs,2Ws,Co] = sum over the 27 taps of the
+    trilinearly up-sampled tap images, shifted by the tap (zero outside the volume), + base (written IN PLACE into
+    base when given).  Three separable passes; intermediates fp32.  Returns (y, BatchNorm partial sums or None)."""
+    bf = _act(b, "b") != ""
+    B, Ds, Hs, Ws, N = b.shape
+    if N != 27 * Co:
+        raise ValueError(f"upmix_gather_fwd: {N} columns for Co={Co}")
+    dev = b.device
+    if base is not None:
+        _act(base, "base", (B, 2 * Ds, 2 * Hs, 2 * Ws, Co))
+        y = base
+    else:
+        y = torch.empty((B, 2 * Ds, 2 * Hs, 2 * Ws, Co), device=dev, dtype=out_dtype or b.dtype)
+    L = _L()
+    with _span("upmix_gather", 0.0, f"fwd {tuple(b.shape)}"):
+        q1 = torch.empty((B, Ds, Hs, 2 * Ws, 9, Co), device=dev, dtype=torch.float32)
+        _chk(L.dram_upmix_axis_fwd(_p(b), int(bf), _p(q1), B * Ds * Hs, Ws, 9, Co, _stream()), "dram_upmix_axis_fwd[x]")
+        q2 = torch.empty((B, Ds, 2 * Hs, 2 * Ws, 3, Co), device=dev, dtype=torch.float32)
+        _chk(L.dram_upmix_axis_fwd(_p(q1), 0, _p(q2), B * Ds, Hs, 2 * Ws * 3, Co, _stream()), "dram_upmix_axis_fwd[y]")
+        del q1
+        nvox = B * 8 * Ds * Hs * Ws
+        stats = torch.empty((L.dram_upmix_stat_rows(nvox), 2, Co), device=dev, dtype=torch.float32) if want_stats else None
+        _chk(L.dram_upmix_axis_fwd_final(_p(q2), _p(base), _p(y), int(y.dtype == BF16), _p(stats), B, Ds, 4 * Hs * Ws, Co,
+                                         _stream()), "dram_upmix_axis_fwd_final")
+    return y, stats
+
+
+def upmix_gather_bwd(dy: Tensor, out_dtype=None) -> Tensor:
+    """Transpose of upmix_gather_fwd: dy [B,2Ds,2Hs,2Ws,Co] -> h [B,Ds,Hs,Ws,27*Co] (storage type of dy unless given)."""
+    gbf = _act(dy, "dy") != ""
+    B, Do, Ho, Wo, Co = dy.shape
+    if (Do | Ho | Wo) & 1:
+        raise ValueError(f"upmix_gather_bwd: odd extents {tuple(dy.shape)}")
+    Ds, Hs, Ws = Do // 2, Ho // 2, Wo // 2
+    dev = dy.device
+    odt = out_dtype or dy.dtype
+    L = _L()
+    with _span("upmix_gather", 0.0, f"bwd {tuple(dy.shape)}"):
+        g2 = torch.empty((B, Ds, Ho, Wo, 3, Co), device=dev, dtype=torch.float32)
+        _chk(L.dram_upmix_axis_bwd(_p(dy), int(gbf), _p(g2), 0, B, Ds, Ho * Wo, Co, _stream()), "dram_upmix_axis_bwd[z]")
+        g1 = torch.empty((B, Ds, Hs, Wo, 9, Co), device=dev, dtype=torch.float32)
+        _chk(L.dram_upmix_axis_bwd(_p(g2), 0, _p(g1), 0, B * Ds, Hs, Wo * 3, Co, _stream()), "dram_upmix_axis_bwd[y]")
+        del g2
+        h = torch.empty((B, Ds, Hs, Ws, 27 * Co), device=dev, dtype=odt)
+        _chk(L.dram_upmix_axis_bwd(_p(g1), 0, _p(h), int(odt == BF16), B * Ds * Hs, Ws, 9, Co, _stream()),
+             "dram_upmix_axis_bwd[x]")
+    return h
 
 
 def upproject(dense: Tensor, ess: Tensor, size):

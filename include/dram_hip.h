@@ -35,7 +35,7 @@ typedef void* dram_stream_t; /* hipStream_t */
 #define DRAM_ERR_UNSUPPORTED (-2)
 #define DRAM_ERR_WORKSPACE (-3)
 
-#define DRAM_ABI_VERSION 4
+#define DRAM_ABI_VERSION 5
 int dram_version(void);
 /* static string: "gfx950" build tag */
 const char* dram_build_info(void);
@@ -323,6 +323,32 @@ int dram_upcat_fwd(const float* src, const float* skip, float* cat, int B, int D
  * = dcat[..., Cu:].  Either output may be NULL. */
 int dram_upcat_bwd(const float* dcat, float* dsrc, float* dskip, int B, int Ds, int Hs, int Ws, int Cu,
                    int Dk, int Hk, int Wk, int Ck, dram_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* First decoder convolution of us1 WITHOUT the up-sampled tensor (csrc/upmix.hip) -- med3d.py:83-87 with
+ * conv_blocks[0] (med3d.py:67): conv(concat(up(a), s)) = sum_t up(W_up[t] . a) shifted by tap t + conv_s(s).
+ * The channel mixing W_up[t] . a is a plain GEMM at the LOW resolution (the 1x1x1 entry points, Cout = 27 Co);
+ * what these entry points add is the tap/trilinear gather, separable per axis, and the weight split / merge.
+ *
+ * dram_upmix_axis_fwd:  In[outer][Ni][m][3][C] (float, or bf16 when in_bf16) -> Out[outer][2 Ni][m][C] (float):
+ *   Out[o][v][m][c] = sum_k [0 <= u = v+k-1 < 2Ni] (w0(u) In[o][i0(u)][m][k][c] + w1(u) In[o][i1(u)][m][k][c]),
+ *   (i0, i1, w0, w1)(u) = PyTorch's align_corners source index of destination u, scale (Ni-1)/(2Ni-1).
+ *   Three calls: X (outer = B Ds Hs, Ni = Ws, m = 9), Y (outer = B Ds, Ni = Hs, m = 2Ws 3), Z = ..._final.
+ * dram_upmix_axis_fwd_final: the same pass, + base (NULL, or the skip convolution's output; may alias out), stored
+ *   as float / bf16, with BatchNorm partial sums of the stored values: stats [dram_upmix_stat_rows(nvox)][2][C]
+ *   (NULL: none), nvox = outer 2Ni m, C <= 128.
+ * dram_upmix_axis_bwd: the exact transpose, G[outer][2Ni][m][C] -> H[outer][Ni][m][3][C] (gather form, no atomics).
+ * dram_upmix_split_weight: w [Co][Cu+Cs][27] -> wlo [27 Co][Cu] (row t Co + co) and ws [Co][Cs][27];
+ * dram_upmix_merge_wgrad: the inverse, for the two weight gradients. */
+int dram_upmix_stat_rows(long long nvox);
+int dram_upmix_axis_fwd(const void* in, int in_bf16, float* out, long long outer, int Ni, int m, int C,
+                        dram_stream_t stream);
+int dram_upmix_axis_fwd_final(const float* in, const void* base, void* out, int out_bf16, float* stats, long long outer,
+                              int Ni, int m, int C, dram_stream_t stream);
+int dram_upmix_axis_bwd(const void* g, int g_bf16, void* h, int h_bf16, long long outer, int Ni, int m, int C,
+                        dram_stream_t stream);
+int dram_upmix_split_weight(const float* w, float* wlo, float* ws, int Co, int Cu, int Cs, dram_stream_t stream);
+int dram_upmix_merge_wgrad(const float* dwlo, const float* dws, float* dw, int Co, int Cu, int Cs, dram_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* Heads -- med3d.py:283-284 (cls) / :382-387 (reg).

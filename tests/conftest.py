@@ -4,6 +4,10 @@ import sys
 import pytest
 import torch
 
+# the tests force kernel variants (DRAM_CONV_ALGO, DRAM_W2D_V, DRAM_WINO_TILING, ...); the library and the host code
+# read those switches only under DRAM_TUNING=1 (tests/test_host.py checks that they are ignored without it)
+os.environ["DRAM_TUNING"] = "1"
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -86,6 +86,34 @@ def test_conv_plan_is_host_side_and_consistent(monkeypatch):
     assert lib.dram_wino_applicable(ctypes.byref(odd)) == 0 and lib.dram_wino2d_applicable(ctypes.byref(odd)) == 1
 
 
+def test_stray_switches_are_ignored_without_dram_tuning():
+    """A/B / test switches count under DRAM_TUNING=1 only: with a stray DRAM_CONV_ALGO (and friends) in the
+    environment but no DRAM_TUNING the library answers with its own plan, and the host-side switches keep their
+    defaults (clean interpreter: the library caches DRAM_TUNING at first use)."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, os\n"
+        "from bodyct_dram_emph_subtype_amd import _lib, ops\n"
+        "lib = _lib.load()\n"
+        "d = _lib.DramConvDesc(2, 16, 32, 32, 512, 16, 32, 32, 512, 3, 1, 4, 4)\n"
+        "print(lib.dram_conv_algo(ctypes.byref(d)), lib.dram_wino_num_points(ctypes.byref(d)),\n"
+        "      ops.tuning_env('DRAM_WGRAD_STREAM', '1'))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("DRAM_")}
+        env.update(extra, PYTHONPATH=root)
+        return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+
+    plain = run({})
+    stray = run({"DRAM_CONV_ALGO": "1", "DRAM_WINO_TILING": "2,2,2", "DRAM_WGRAD_STREAM": "0"})
+    tuned = run({"DRAM_CONV_ALGO": "1", "DRAM_WINO_TILING": "2,2,2", "DRAM_WGRAD_STREAM": "0", "DRAM_TUNING": "1"})
+    assert plain == ["1", "216", "1"]
+    assert stray == plain
+    assert tuned == ["0", "64", "0"]
+
+
 def test_factories_conf_and_state_dict_contract():
     from bodyct_dram_emph_subtype_amd import med3d, utils
     m = utils.get_model_by_name("med3ddram18")

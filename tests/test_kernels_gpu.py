@@ -515,6 +515,67 @@ def test_upcat_tiled_forward(ops, monkeypatch):
     assert rel_l2(cat2.cpu(), cat.cpu()) < 2e-6 and torch.equal(cat2[..., Cu:], cat[..., Cu:])
 
 
+UPMIX_CASES = [
+    # B, Ds, Hs, Ws, Cu, Cs, Co      (us1.0: conv3x3x3(concat(up(src), skip)) -- med3d.py:83-87 / :67)
+    (1, 2, 4, 4, 512, 64, 64),        # the golden fixtures' geometry (16x32x32 input): M = 32, direct 1x1x1 kernel
+    (2, 4, 4, 8, 128, 64, 64),        # M = 256: the batched-GEMM 1x1x1 kernels
+    (1, 3, 5, 2, 64, 32, 32),         # odd / tiny low-resolution extents (scale 2/5, 4/9, 1/3), 32 output channels
+    (1, 1, 2, 3, 64, 32, 64),         # Ds = 1: scale 0 along z
+]
+
+
+@pytest.mark.parametrize("case", UPMIX_CASES, ids=[str(c) for c in UPMIX_CASES])
+def test_upmix_lowres_mixing_equals_conv_of_upsampled_concat(ops, case):
+    """The first decoder convolution without the up-sampled tensor (csrc/upmix.hip): low-resolution GEMM + separable
+    tap/trilinear gather + skip convolution against the fp64 convolution of concat(upsample(src), skip) -- forward
+    (rel-L2 <= 1e-5), BatchNorm partial sums, both data gradients and the merged weight gradient (<= 1e-5), and the
+    gather passes as exact transposes of each other."""
+    B, Ds, Hs, Ws, Cu, Cs, Co = case
+    src = rnd(B, Cu, Ds, Hs, Ws, seed=1).double().requires_grad_(True)
+    skip = rnd(B, Cs, 2 * Ds, 2 * Hs, 2 * Ws, seed=2).double().requires_grad_(True)
+    w = (rnd(Co, Cu + Cs, 3, 3, 3, seed=3) * 0.05).double().requires_grad_(True)
+    bias = rnd(Co, seed=4).double()
+    up = F.interpolate(src, scale_factor=2, mode="trilinear", align_corners=True)
+    y_ref = F.conv3d(torch.cat([up, skip], 1), w, bias, 1, 1)
+    gy = rnd(*y_ref.shape, seed=5).double()
+    gsrc_ref, gskip_ref, gw_ref = torch.autograd.grad(y_ref, [src, skip, w], gy)
+
+    wd = w.detach().float().to(DEV)
+    wlo, ws = ops.upmix_split_weight(wd, Cu)
+    assert torch.equal(wlo.reshape(27, Co, Cu).cpu(), w.detach().float()[:, :Cu].reshape(Co, Cu, 27).permute(2, 0, 1))
+    assert torch.equal(ws.cpu(), w.detach().float()[:, Cu:])
+    g_lo = ops.ConvGeom(B, Ds, Hs, Ws, Cu, 27 * Co, 1, 1, 0, 1)
+    g_s = ops.ConvGeom(B, 2 * Ds, 2 * Hs, 2 * Ws, Cs, Co, 3, 1, 1, 1)
+    wf_lo, wb_lo = ops.pack_conv_weight(wlo, True, True, g_lo)
+    wf_s, wb_s = ops.pack_conv_weight(ws, True, True, g_s)
+    a = to_ndhwc(src.detach().float())
+    sk = to_ndhwc(skip.detach().float())
+    b, _ = ops.conv3d_fwd(a, wf_lo, None, g_lo, False)
+    ysk, _ = ops.conv3d_fwd(sk, wf_s, bias.float().to(DEV), g_s, False)
+    y, stats = ops.upmix_gather_fwd(b, ysk, Co, True)
+    assert y.data_ptr() == ysk.data_ptr()                      # in place
+    assert rel_l2(to_ncdhw(y).double(), y_ref.detach()) < 1e-5
+    s = ops.reduce_partials(stats).cpu()
+    yd = to_ncdhw(y).double()
+    assert torch.allclose(s[0], yd.sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[1], (yd * yd).sum((0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+
+    gyd = to_ndhwc(gy.float())
+    h = ops.upmix_gather_bwd(gyd)
+    # exact transposes: <gather(b), gy> == <b, gather^T(gy)>
+    y0, _ = ops.upmix_gather_fwd(b, None, Co, False)
+    lhs = float((y0.double() * gyd.double()).sum())
+    rhs = float((b.double() * h.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0)
+    dsrc = ops.conv3d_bwd_data(h, wb_lo, g_lo)
+    dskip = ops.conv3d_bwd_data(gyd, wb_s, g_s)
+    assert rel_l2(to_ncdhw(dsrc).double(), gsrc_ref) < 1e-5
+    assert rel_l2(to_ncdhw(dskip).double(), gskip_ref) < 1e-5
+    if Cu % 64 == 0 and Cs % 64 == 0:
+        dw = ops.upmix_merge_wgrad(ops.conv3d_bwd_weight(a, h, g_lo), ops.conv3d_bwd_weight(sk, gyd, g_s))
+        assert rel_l2(dw.cpu().double(), gw_ref) < 1e-5
+
+
 @pytest.mark.parametrize("mode", ["cls", "reg", "reg_nolungs"])
 def test_head(ops, mode):
     B, D, H, W = 2, 4, 6, 5

@@ -1,6 +1,7 @@
 """Single-layer micro-benchmark of the conv kernels (HIP events), for A/B tuning.
    python tools/conv_bench.py B D H W Cin Cout k stride dil [fwd|dgrad|wgrad] [iters]"""
 import os, sys
+os.environ.setdefault("DRAM_TUNING", "1")   # tuning tool: the A/B switches below count
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bodyct_dram_emph_subtype_amd import ops

@@ -5,6 +5,7 @@
 # layers on the 4-wave 256-voxel kernel.   gpurun -- 'bash tools/conv_bf16_ablate.sh'
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
+export DRAM_TUNING=1   # ablation builds + A/B switches count under DRAM_TUNING=1 only
 export DRAM_BF16_NW=4
 for a in ${ABLS:-0 1 2 3 4 5 6 7 8}; do
   export DRAM_EXTRA_HIPCC_FLAGS="-DDRAM_BF16_ABL=$a"

@@ -1,6 +1,7 @@
 """GPU box: per-layer rate of the bf16-storage convolution kernels (HIP events) on the 3x3x3 stride-1 layers of
 BASELINE configs[2] (ResNet-18 + dRAM head, batch 2, 1x128x256x256).   python tools/conv_bf16_bench.py [iters]"""
 import os
+os.environ.setdefault("DRAM_TUNING", "1")   # tuning tool: the A/B switches below count
 import sys
 
 import torch

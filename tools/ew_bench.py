@@ -1,6 +1,7 @@
 """GPU box: achieved HBM GB/s of the element-wise kernels at the config-1 / config-2 shapes, fp32 and bf16
 storage.   python tools/ew_bench.py   (DRAM_EW_U=0|1|2|4 selects the bn_apply variant)"""
 import os
+os.environ.setdefault("DRAM_TUNING", "1")   # tuning tool: the A/B switches below count
 import sys
 
 import torch

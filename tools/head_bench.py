@@ -1,5 +1,6 @@
 """GPU box: time of the head kernels at config 1 / 2 shape (HIP events).   python tools/head_bench.py"""
 import os, sys
+os.environ.setdefault("DRAM_TUNING", "1")   # tuning tool: the A/B switches below count
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bodyct_dram_emph_subtype_amd import ops  # noqa: E402

@@ -1,6 +1,7 @@
 """Rounding error of the Winograd pipeline per math mode (DRAM_MATH) and tiling against an fp64 convolution.
    python tools/math_check.py  [B D H W Cin Cout dil]"""
 import os, sys
+os.environ.setdefault("DRAM_TUNING", "1")   # tuning tool: the A/B switches below count
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -21,7 +21,7 @@ cd /tmp && export TMPDIR=/tmp
 # the profiled passes run the step on ONE stream, like bench.py's timeline pass: with the weight-gradient kernels
 # overlapping the data-gradient chain on a second stream, per-kernel durations contain the time a kernel shared its
 # CUs with the other stream's kernel and would not be comparable
-export DRAM_WGRAD_STREAM=0
+export DRAM_TUNING=1 DRAM_WGRAD_STREAM=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --timeline off --no-graph > $O/bench_config1_under_rocprofv3.json.log 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --timeline off --no-graph > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --timeline off --no-graph > /dev/null 2>&1

@@ -3,6 +3,7 @@
 prints, per (family, variant, flops, bytes) group: launches/step, avg us, executed TFLOP/s, algorithmic GB/s."""
 import collections
 import os
+os.environ.setdefault("DRAM_TUNING", "1")   # tuning tool: the A/B switches below count
 import sys
 
 import torch
