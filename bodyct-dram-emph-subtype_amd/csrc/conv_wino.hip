@@ -820,27 +820,92 @@ __global__ __launch_bounds__(512) void wino_gemm_nn_kernel(const float* __restri
   }
 
   const bool fused = ep.bias || ep.add || ep.stats;       // uniform
-  if (NJ <= 2 && !fused && epi_lds) {     // (NJ = 4: the eight regions would not fit beside nothing: 139 KB)
-    // Plain store of the tile (every Winograd-domain GEMM of the pipeline): the 32x32 accumulator layout gives a lane
-    // ONE column, so direct stores are 32 dword stores per accumulator in 128-B pieces -- 64 vector-memory instructions
-    // per wave behind only 128 MFMAs when K = 64.  Each wave turns its 32 x 32 NJ half-tile through a private LDS
-    // region (row pitch 32 NJ + 8 floats: the two row groups of a write land in different bank halves) and stores
-    // 16 B per lane: a quarter of the store instructions, 128 NJ-byte pieces.
-    constexpr int P = 32 * NJ + 8;
+  if (epi_lds) {
+    // Store through LDS (every Winograd-domain GEMM of the pipeline, and the 1x1x1 convolutions with their fused
+    // epilogues): the 32x32 accumulator layout gives a lane ONE column, so direct stores are 32 dword stores per
+    // accumulator in 128-B pieces -- 64 vector-memory instructions per wave behind only 128 MFMAs when K = 64 -- and
+    // the shortcut-gradient epilogue adds two dword loads per element (ResNet-50's 1024->256 data gradient: 186 us
+    // against 81 us for the forward of the same layer).  Each wave turns 32 rows x 64 (32) columns at a time through
+    // a private LDS region (row pitch + 8 floats: the two row groups of a write land in different bank halves) and
+    // moves 16 B per lane: a quarter of the memory instructions, whole 256-B (128-B) row pieces.
+    constexpr int CW = NJ >= 2 ? 64 : 32;                 // columns per round
+    constexpr int NR = NJ >= 2 ? NJ / 2 : 1;              // column rounds
+    constexpr int P = CW + 8;
+    constexpr int Q = CW / 4;                             // 4-column groups per row
     __syncthreads();                                      // every wave is done with the last operand stage
     float* reg = lds + wave * (32 * P);
+    const int cq = lane % Q, rs = lane / Q;
+    float s1[NR][4], s2[NR][4];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int cr = 0; cr < NR; ++cr)
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
+      for (int j = 0; j < 4; ++j) { s1[cr][j] = 0.f; s2[cr][j] = 0.f; }
 #pragma unroll
-        for (int nj = 0; nj < NJ; ++nj) reg[((e & 3) + 8 * (e >> 2) + 4 * lh) * P + nj * 32 + li] = acc[mi][nj][e];
+    for (int cr = 0; cr < NR; ++cr) {
+      const int col = nt * BN + wn * NJ * 32 + cr * CW + 4 * cq;          // column of Y (and of bias)
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (ep.bias) bv = *reinterpret_cast<const f32x4*>(ep.bias + col);
 #pragma unroll
-      for (int r = 0; r < 4 * NJ; ++r) {
-        const int idx = r * 64 + lane;
-        const int row = idx / (8 * NJ), cq = idx % (8 * NJ);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * P + 4 * cq);
-        *reinterpret_cast<f32x4*>(Yb + (long)(wm * 64 + mi * 32 + row) * N + wn * NJ * 32 + 4 * cq) = v;
+      for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+#pragma unroll
+          for (int j = 0; j < CW / 32; ++j)
+            reg[((e & 3) + 8 * (e >> 2) + 4 * lh) * P + j * 32 + li] = acc[mi][cr * (CW / 32) + j][e];
+#pragma unroll
+        for (int r = 0; r < 32 / (64 / Q); ++r) {
+          const int row = r * (64 / Q) + rs;
+          f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * P + 4 * cq);
+          float* o = Yb + (long)(wm * 64 + mi * 32 + row) * N + wn * NJ * 32 + cr * CW + 4 * cq;
+          if (fused) {
+            v += bv;
+            if (ep.add) {
+              const long oo = o - Y;
+              const f32x4 av = *reinterpret_cast<const f32x4*>(ep.add + oo);
+              if (ep.gate) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(ep.gate + oo);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += gv[j] > 0.f ? av[j] : 0.f;
+              } else {
+                v += av;
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[cr][j] += v[j]; s2[cr][j] += v[j] * v[j]; }
+          }
+          *reinterpret_cast<f32x4*>(o) = v;
+        }
+      }
+    }
+    if (ep.stats) {
+#pragma unroll
+      for (int cr = 0; cr < NR; ++cr)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int o = Q; o < 64; o <<= 1) {
+            s1[cr][j] += __shfl_xor(s1[cr][j], o, 64);
+            s2[cr][j] += __shfl_xor(s2[cr][j], o, 64);
+          }
+      __syncthreads();                                    // every wave is done with its turn region
+      float* red = lds;  // [8 waves][2][32 * NJ]
+      if (rs == 0) {
+#pragma unroll
+        for (int cr = 0; cr < NR; ++cr)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            red[(wave * 2 + 0) * 32 * NJ + cr * CW + 4 * cq + j] = s1[cr][j];
+            red[(wave * 2 + 1) * 32 * NJ + cr * CW + 4 * cq + j] = s2[cr][j];
+          }
+      }
+      __syncthreads();
+      if (tid < 2 * BN) {
+        const int which = tid / BN, cc = tid - which * BN;       // column within the workgroup's BN
+        const int cwn = cc / (32 * NJ), c2 = cc - cwn * 32 * NJ;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += red[((cwn * 4 + w) * 2 + which) * 32 * NJ + c2];   // wave = wn * 4 + wm
+        ep.stats[((long)mt * 2 + which) * N + nt * BN + cc] = v;
       }
     }
     return;
@@ -894,6 +959,155 @@ __global__ __launch_bounds__(512) void wino_gemm_nn_kernel(const float* __restri
 #pragma unroll
       for (int w = 0; w < 4; ++w) v += red[((cwn * 4 + w) * 2 + which) * 32 * NJ + c2];   // wave = wn * 4 + wm
       ep.stats[((long)mt * 2 + which) * N + nt * BN + cc] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Streaming form of the NN batched GEMM for the launches that are HBM-bound whatever the tile: few channels on both
+// sides (K <= 128 and N <= 128 -- the 128->64 decoder convolution on 2 x 64 x 128 x 128 voxels moves 5.4 GB through
+// each of its GEMMs for 116 GFLOP).  wino_gemm_nn_kernel gives such a launch one or two 40-48 KB stages in flight per
+// CU and a cold pipeline every K / 32 = 2-4 iterations (a workgroup lives for one 256-row tile): 3.5-3.8 TB/s.  Here a
+// workgroup is PERSISTENT: it owns a contiguous run of (point, 64-row tile) items, keeps the point's whole B operand in
+// REGISTERS (64 per lane, re-read from a 32-KB LDS image only when the point changes), and streams 64 x K A tiles
+// through a ring of S LDS stages filled by LDS-DMA S - 1 items ahead (2-3 x 16-32 KB in flight per CU the whole time;
+// counted s_waitcnt vmcnt + one barrier per item).  Results leave through a wave-private LDS turn (16 B per lane).
+// LDS rows are K floats; 16-B slot s of row r lives at slot (s & ~15) | ((s ^ r) & 15) (applied on the DMA source
+// side and on the reads: the 16 lanes of a ds_read_b128 group hit 16 different 16-B columns).
+template <int NJ, int KT, int S>
+__global__ __launch_bounds__(256, 1) void wino_gemm_nn_stream_kernel(const float* __restrict__ A,
+                                                                    const float* __restrict__ Bw, float* __restrict__ Y,
+                                                                    const int npts, const int m64, const int per_wg,
+                                                                    const int total) {
+  constexpr int N = 64 * NJ;
+  constexpr int STG = 64 * KT;                     // floats per A stage
+  constexpr int SPR = KT / 4;                      // 16-B slots per row
+  constexpr int RPI = 64 / SPR;                    // rows per DMA instruction (1 KB)
+  constexpr int IPW = 64 / RPI / 4;                // A DMA instructions per wave and stage
+  constexpr int BPW = N / RPI / 4;                 // B DMA instructions per wave
+  constexpr int KG = KT / 8;                       // k-groups (one ds_read_b128 per lane each)
+  constexpr int P = 32 * NJ + 8;
+  static_assert(S == 3 || S == 4, "ring depth");
+  // separate LDS objects per stage (the wait-count pass tells DMA targets apart by object)
+  __shared__ __attribute__((aligned(1024))) float st0[STG], st1[STG], st2[STG], st3[S == 4 ? STG : 64];
+  __shared__ __attribute__((aligned(1024))) float bt[N * KT];
+  __shared__ __attribute__((aligned(16))) float turn[4 * 32 * P];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int i0 = blockIdx.x * per_wg;
+  const int n = (i0 + per_wg <= total ? per_wg : total - i0);
+  if (n <= 0) return;
+
+  // per-lane DMA source offsets (floats) inside a 64 x KT (A) / N x KT (B) tile
+  int aoff[IPW], boff[BPW];
+#pragma unroll
+  for (int j = 0; j < IPW; ++j) {
+    const int row = RPI * (wave + 4 * j) + lane / SPR, ph = lane % SPR;
+    aoff[j] = row * KT + ((ph & ~15) | ((ph ^ row) & 15)) * 4;
+  }
+#pragma unroll
+  for (int j = 0; j < BPW; ++j) {
+    const int row = RPI * (wave + 4 * j) + lane / SPR, ph = lane % SPR;
+    boff[j] = row * KT + ((ph & ~15) | ((ph ^ row) & 15)) * 4;
+  }
+  auto a_src = [&](int item) __attribute__((always_inline)) {
+    const int xi = item / m64, t = item - xi * m64;
+    return A + (((long)(t >> 2) * npts + xi) * 256 + (t & 3) * 64) * KT;
+  };
+  auto issue_a = [&](int item, float* stage) __attribute__((always_inline)) {
+    const float* src = a_src(item);
+#pragma unroll
+    for (int j = 0; j < IPW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + aoff[j]),
+                                       (__attribute__((address_space(3))) void*)(stage + (wave + 4 * j) * 256), 16, 0, 0);
+  };
+  auto stage_of = [&](int k) __attribute__((always_inline)) -> float* {
+    return k == 0 ? st0 : (k == 1 ? st1 : (k == 2 ? st2 : st3));
+  };
+
+  const int r0 = 32 * (wave & 1), c0 = 32 * NJ * (wave >> 1);
+  const int arow = r0 + li;
+  f32x4 bfr[NJ][KG];
+  auto load_b = [&](int xi) __attribute__((always_inline)) {
+    __syncthreads();                               // (no wave still reads the previous point's image)
+    const float* src = Bw + (long)xi * N * KT;
+#pragma unroll
+    for (int j = 0; j < BPW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + boff[j]),
+                                       (__attribute__((address_space(3))) void*)(bt + (wave + 4 * j) * 256), 16, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+    asm volatile("" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+      const int brow = c0 + nj * 32 + li;
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) {
+        const int sl = 2 * kg + lh;
+        bfr[nj][kg] = *reinterpret_cast<const f32x4*>(bt + brow * KT + ((sl & ~15) | ((sl ^ brow) & 15)) * 4);
+      }
+    }
+  };
+
+  int xi_cur = i0 / m64;
+  // prologue: S - 1 stages ahead (the B load below waits for them too: once per point)
+#pragma unroll
+  for (int k = 0; k < S - 1; ++k)
+    if (k < n) issue_a(i0 + k, stage_of(k));
+  load_b(xi_cur);
+
+  float* reg = turn + wave * (32 * P);
+  constexpr int Q = 8 * NJ;                        // 4-column groups per row of the wave's 32 NJ columns
+  const int cq = lane % Q, rs = lane / Q;
+
+  for (int itb = 0; itb < n; itb += S) {
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+      const int it = itb + k;
+      if (it < n) {                                // uniform
+        const int item = i0 + it;
+        const int xi = item / m64, t = item - xi * m64;
+        if (xi != xi_cur) {                        // next point: its B operand (rare: a run spans 1-3 points)
+          xi_cur = xi;
+          load_b(xi);                              // (its vmcnt(0) also covers the stages in flight)
+        }
+        // stage `it` has landed for this wave when at most the S - 2 younger stages are outstanding (loads complete
+        // in order; stores in between only make the wait stricter); in the tail nothing younger was issued
+        if (it + S - 2 < n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((IPW * (S - 2)) & 15) | (((IPW * (S - 2)) >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // ... and for every wave; all waves are done with stage it - 1
+        if (it + S - 1 < n) issue_a(item + S - 1, stage_of((k + S - 1) % S));
+        const float* stg = stage_of(k);
+        f32x16 acc[NJ];
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[nj][e] = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+          const int sl = 2 * kg + lh;
+          const f32x4 af = *reinterpret_cast<const f32x4*>(stg + arow * KT + ((sl & ~15) | ((sl ^ arow) & 15)) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+              acc[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bfr[nj][kg][e], acc[nj], 0, 0, 0);
+        }
+        // turn through the wave's private LDS region, 16 B per lane
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+#pragma unroll
+          for (int nj = 0; nj < NJ; ++nj) reg[((e & 3) + 8 * (e >> 2) + 4 * lh) * P + nj * 32 + li] = acc[nj][e];
+        float* yb = Y + (((long)(t >> 2) * npts + xi) * 256 + (t & 3) * 64 + r0) * N + c0;
+#pragma unroll
+        for (int r = 0; r < Q / 2; ++r) {
+          const int row = r * (64 / Q) + rs;
+          *reinterpret_cast<f32x4*>(yb + (long)row * N + 4 * cq) = *reinterpret_cast<const f32x4*>(reg + row * P + 4 * cq);
+        }
+      }
     }
   }
 }
@@ -1479,6 +1693,29 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
   hipLaunchKernelGGL((wino_gemm_nn_kernel<NJ_>), dim3(nblk), dim3(512), 0, s, A, U, Y, g.Tpad, N, K, m_tiles, n_tiles, \
                      nblk, g.npts, ep, epi_lds)
   static const int epi_lds = tune_env("DRAM_WINO_EPI") ? atoi(tune_env("DRAM_WINO_EPI")) : 1;      // A/B switch
+  // HBM-bound shapes of the pipeline (no epilogue, whole K in one stage): the persistent streaming form
+  const char* se = tune_env("DRAM_NN_STREAM");           // 0 off, 1 from 4 096 items on (default), 2 always (tests)
+  const int stream_on = se ? atoi(se) : 1;
+  const bool fused = ep.bias || ep.add || ep.gate || ep.stats;
+  if (stream_on && !fused && g.npts > 1 && g.Tpad % 256 == 0 &&
+      ((N == 64 && (K == 128 || K == 64)) || (N == 128 && K == 64))) {
+    const int m64 = g.Tpad / 64;
+    const long total = (long)g.npts * m64;
+    if (total < (1L << 31) && (total >= 4096 || stream_on == 2)) {
+      const int wgs = 256;                                           // one persistent workgroup per CU
+      const int per_wg = (int)((total + wgs - 1) / wgs);
+      const int grid = (int)((total + per_wg - 1) / per_wg);
+#define WNS(NJ_, KT_, S_)                                                                                          \
+  hipLaunchKernelGGL((wino_gemm_nn_stream_kernel<NJ_, KT_, S_>), dim3(grid), dim3(256), 0, s, A, U, Y, g.npts, m64, \
+                     per_wg, (int)total)
+      if (N == 64 && K == 128) WNS(1, 128, 3);
+      else if (N == 64) WNS(1, 64, 4);
+      else WNS(2, 64, 4);
+#undef WNS
+      DRAM_LAUNCH_CHECK();
+      return DRAM_OK;
+    }
+  }
   if (nj == 4) WNN(4);
   else if (nj == 2) WNN(2);
   else WNN(1);

@@ -249,6 +249,30 @@ def test_conv3d_winograd_path(ops, monkeypatch, case, tiling):
     assert rel_l2(y.cpu(), y1.cpu()) < tol
 
 
+@pytest.mark.parametrize("case", WINO_CASES[:3], ids=[str(c) for c in WINO_CASES[:3]])
+def test_winograd_streaming_gemm_equals_tiled_gemm(ops, monkeypatch, case):
+    """The persistent streaming form of the Winograd-domain NN GEMM (K, N <= 128: whole B operand in registers, A tiles
+    through an LDS ring; the library takes it from 4 096 (point, 64-row tile) items on) accumulates in the order of the
+    tiled kernel: forward and data gradient are bit-identical to it, on every tiling -- (N, K) = (64, 64), (128, 64)
+    and (64, 128) are its three instantiations."""
+    monkeypatch.setenv("DRAM_CONV_ALGO", "2")
+    B, D, H, W, Cin, Cout, dil = case
+    x = to_ndhwc(rnd(B, Cin, D, H, W, seed=1))
+    gy = to_ndhwc(rnd(B, Cout, D, H, W, seed=4))
+    w = (rnd(Cout, Cin, 3, 3, 3, seed=2) * 0.1).to(DEV)
+    g = ops.ConvGeom(B, D, H, W, Cin, Cout, 3, 1, dil, dil)
+    for tiling in ("2,2,2", "4,4,4"):
+        monkeypatch.setenv("DRAM_WINO_TILING", tiling)
+        wf, wb = ops.pack_conv_weight(w, True, True, g)
+        res = {}
+        for mode in ("0", "2"):
+            monkeypatch.setenv("DRAM_NN_STREAM", mode)
+            res[mode] = (ops.conv3d_fwd(x, wf, None, g, False)[0], ops.conv3d_bwd_data(gy, wb, g))
+        assert torch.equal(res["0"][0], res["2"][0]) and torch.equal(res["0"][1], res["2"][1])
+    ref = F.conv3d(rnd(B, Cin, D, H, W, seed=1).double(), w.cpu().double(), None, 1, dil, dil)
+    assert rel_l2(to_ncdhw(res["2"][0]).double(), ref) < 3e-5
+
+
 MATH_TOL = {  # measured rel-L2 vs fp64 (tools/math_check.py): fp32 6.5e-7 / 1.1e-5, bf16x3 9.8e-6 / 1.7e-4, bf16 5.2e-3 / 9e-2
     ("bf16x3", "2,2,2"): 3e-5, ("bf16x3", "4,4,4"): 5e-4, ("bf16", "2,2,2"): 1.5e-2, ("bf16", "4,4,4"): 0.25}
 

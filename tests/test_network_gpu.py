@@ -441,6 +441,15 @@ def test_full_size_train_step_vs_oracle(config):
         worst = max(worst, (e, n))
         assert e <= bar, f"{n}: full-size gradient vs decision-pinned fp64 oracle {e:.2e}"
     print(f"[config {config} full size] loss {loss_hip:.6f}; worst gradient vs decision-pinned fp64 oracle {worst}")
+    if config == 1:
+        # decision INDEPENDENCE at full size (the headline configuration, where the full-size-only launch shapes run):
+        # the free-running fp32 oracle's own ReLU / max-pool decisions against the ones the HIP forward took -- every
+        # difference must be a rounding tie (audit_decisions), so the pinned comparison above cannot have pinned the
+        # oracle to a wrong activation
+        del lv, d, o, pairs
+        flips, total, mp, nmp, margin = audit_decisions(pins, sd0, x, lungs, factory)
+        print(f"[config 1 full size] {flips} of {total} ReLU decisions and {mp} of {nmp} max-pool taps differ from the "
+              f"free-running fp32 oracle; worst flip margin {margin:.2e} x max|pre-activation|")
 
 
 def test_inference_weight_cache_tracks_weight_identity_and_updates():
