@@ -449,7 +449,9 @@ def main():
     if args.graph:
         step = eager_step                   # the timeline pass brackets individual launches: eager
     # every rank runs the second pass (its steps contain collectives); rank 0 records the timeline
-    if args.timeline == "after":
+    if args.timeline == "after" or (dctx is not None and args.timeline == "off"):
+        # (data parallel with --timeline off: the second pass still runs, without the kernel timeline, so that EVERY N > 1
+        # line carries exposed_collective_ms)
         # same K steps again, every kernel launch bracketed by hipEvents on its launch stream.  The timeline pass
         # runs the step on ONE stream (DRAM_WGRAD_STREAM=0): with the weight-gradient kernels overlapping the
         # data-gradient chain on a second stream a kernel's event interval would also contain the time it
@@ -514,7 +516,7 @@ def main():
         if dctx is not None:
             ran = args.warmup + args.steps + (args.steps + 1 if args.timeline == "after" else 0)
             out["collectives_per_step"] = {k: v / ran for k, v in dctx.stats.items()}
-            if args.timeline == "after":
+            if args.timeline in ("after", "off"):
                 # time the data path's stream sat between issuing a SyncBN statistic exchange and continuing, per step
                 # (single-stream pass; the gradient buckets are asynchronous and not part of it)
                 out["exposed_collective_ms"] = exposed_ms

@@ -92,6 +92,9 @@ SIGNATURES = {
     "dram_stem_bwd_weight": (I, [P, P, P, I, I, I, I, P, SZ, P]),
     "dram_reduce_partials_stages": (I, [I]),
     "dram_reduce_partials": (I, [P, P, P, I, I, I, D, I, P]),
+    "dram_fold_partials_stages": (I, [I]),
+    "dram_fold_partials": (I, [P, P, P, P, I, I, I, D, I, P]),
+    "dram_bn_fold_finalize": (I, [P, P, P, I, I, D, P, P, P, P, F, F, I, P, P, P, P, P]),
     "dram_bn_finalize": (I, [P, D, P, P, P, P, P, F, F, I, P, P, P, P, I, P]),
     "dram_bn_apply": (I, [P, P, P, P, I, I, I, I, I, P, I, I, I, I, I, I, P]),
     "dram_colsum_nparts": (I, [LL, I]),

@@ -8,6 +8,7 @@
 // caller may all-reduce the [2][C] doubles across ranks (SyncBatchNorm), then
 // dram_bn_finalize produces mean / invstd / fused scale+shift and the running-stat update.
 #include <stdlib.h>
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -62,6 +63,86 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   invstd[c] = (float)is;
   scale[c] = sc;
   shift[c] = (float)((double)beta[c] - m * (double)gamma[c] * is);
+}
+
+// One-launch fold (+ BatchNorm finalize): the stage-1 blocks of reduce_partials_kernel, and the LAST block to finish
+// (a ticket counter) folds the S stage rows in fixed order -- deterministic whichever block that is -- writes the
+// double sums, optionally a float copy (the BatchNorm parameter gradients), and optionally runs bn_finalize on them.
+// A ResNet-50 step issued 114 + 76 + 54 launches of 4-6 us for what is 108 launches now.
+struct FoldFinalize {               // gamma == NULL: no finalize
+  double count;
+  const float* gamma; const float* beta; float* rmean; float* rvar;
+  float momentum, eps; int update;
+  float* mean; float* invstd; float* scale; float* shift;
+};
+constexpr int FOLD_SLOTS = 256, FOLD_XMAX = 512;
+__device__ unsigned g_fold_ticket[FOLD_SLOTS * FOLD_XMAX];
+
+// grid (column groups, S stage rows), 1 024 threads = 16 part lanes x 64 columns.  A block owns 64 columns: plain mode 64 consecutive ones; finalize mode the
+// sum AND the sum of squares of 32 channels (columns c and C + c), so that the block which completes a column group
+// can finalize its channels by itself.  S == 1: every block is complete on its own (no ticket).  S > 1: one ticket
+// per column group, the last of its S blocks folds the S stage rows (independent agent-scope loads, fixed order).
+__global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __restrict__ partial, double* scratch,
+                                                             double* __restrict__ sums, float* __restrict__ sums_f32,
+                                                             const int nparts, const int RC, const double tail,
+                                                             const int has_tail, const int slot, const FoldFinalize ff) {
+  __shared__ double sm[1024];
+  __shared__ double tot[64];
+  __shared__ unsigned s_ticket;
+  const int t64 = threadIdx.x & 63, lane4 = threadIdx.x >> 6;      // 16 part lanes x 64 columns
+  const int C = RC >> 1;
+  const int col = ff.gamma ? (t64 >> 5) * C + blockIdx.x * 32 + (t64 & 31) : blockIdx.x * 64 + t64;
+  const bool live = ff.gamma ? (blockIdx.x * 32 + (t64 & 31) < C) : (col < RC);
+  const int S = gridDim.y, sidx = blockIdx.y;
+  double s = 0.0;
+  if (live)
+    for (int p = sidx + S * lane4; p < nparts; p += 16 * S) s += (double)partial[(long)p * RC + col];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  double total = 0.0;
+  if (lane4 == 0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) total += sm[t64 + 64 * j];        // fixed order
+  }
+  if (S > 1) {
+    if (lane4 == 0 && live) scratch[(long)sidx * RC + col] = total;
+    __threadfence();                                 // this block's stage row is visible device-wide ...
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&g_fold_ticket[slot * FOLD_XMAX + blockIdx.x], 1u);   // ... before its ticket
+    __syncthreads();
+    if (s_ticket != (unsigned)S - 1) return;
+    __threadfence();
+    if (threadIdx.x == 0) g_fold_ticket[slot * FOLD_XMAX + blockIdx.x] = 0;    // free for the next launch / graph replay
+    if (lane4 == 0 && live) {
+      total = 0.0;
+      for (int k = 0; k < S; ++k)                    // written by other CUs: agent-scope loads, all in flight together
+        total += __hip_atomic_load(scratch + (long)k * RC + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (lane4 == 0 && live) {
+    sums[col] = total;
+    if (sums_f32) sums_f32[col] = (float)total;
+  }
+  if (has_tail && blockIdx.x == 0 && threadIdx.x == 0) sums[RC] = tail;
+  if (!ff.gamma) return;
+  if (lane4 == 0) tot[t64] = total;
+  __syncthreads();
+  const int c = blockIdx.x * 32 + threadIdx.x;
+  if (threadIdx.x < 32 && c < C) {
+    const double m = tot[threadIdx.x] / ff.count;
+    double v = tot[32 + threadIdx.x] / ff.count - m * m;
+    if (v < 0.0) v = 0.0;
+    if (ff.update) {
+      const double unb = ff.count > 1.0 ? v * (ff.count / (ff.count - 1.0)) : v;
+      ff.rmean[c] = (float)((1.0 - (double)ff.momentum) * (double)ff.rmean[c] + (double)ff.momentum * m);
+      ff.rvar[c] = (float)((1.0 - (double)ff.momentum) * (double)ff.rvar[c] + (double)ff.momentum * unb);
+    }
+    const double is = 1.0 / sqrt(v + (double)ff.eps);
+    ff.mean[c] = (float)m;
+    ff.invstd[c] = (float)is;
+    ff.scale[c] = (float)((double)ff.gamma[c] * is);
+    ff.shift[c] = (float)((double)ff.beta[c] - m * (double)ff.gamma[c] * is);
+  }
 }
 
 // z = act(y*scale + shift + residual)
@@ -457,6 +538,46 @@ extern "C" int dram_reduce_partials(const float* partial, double* sums, double* 
   }
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
+}
+
+extern "C" int dram_fold_partials_stages(int nparts) {
+  // one block of 16 part lanes folds up to 1 024 partial rows by itself (every layer below the 64 x 128 x 128 grid:
+  // no ticket, no second pass); above that, stage rows of 512 parts each
+  if (nparts <= 1024) return 1;
+  const int s = (nparts + 511) / 512;
+  return s > 64 ? 64 : s;
+}
+
+static int fold_launch(const float* partial, double* sums, double* scratch, float* sums_f32, int nparts, int RC,
+                       double tail, int has_tail, const FoldFinalize& ff, hipStream_t st) {
+  static std::atomic<unsigned> next_slot{0};         // host-side round robin: launches in flight together (two
+  const int slot = (int)(next_slot.fetch_add(1) % FOLD_SLOTS);   // streams, two host threads) use different tickets
+  const int S = dram_fold_partials_stages(nparts);
+  const int gx = ff.gamma ? (RC / 2 + 31) / 32 : (RC + 63) / 64;
+  if (S > 1 && gx > FOLD_XMAX) return DRAM_ERR_UNSUPPORTED;        // (no such layer: S > 1 goes with few channels)
+  DramProf prof(DRAM_FAM_BN, 0, 0.0, 4.0 * (double)nparts * RC + 8.0 * RC, st);
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(gx, S), dim3(1024), 0, st, partial, scratch, sums, sums_f32, nparts, RC,
+                     tail, has_tail, slot, ff);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_fold_partials(const float* partial, double* sums, double* scratch, float* sums_f32, int nparts, int R,
+                                  int C, double tail, int has_tail, dram_stream_t stream) {
+  if (!partial || !sums || !scratch || nparts < 1 || R < 1 || C < 1) return DRAM_ERR_BAD_ARG;
+  FoldFinalize ff{};
+  return fold_launch(partial, sums, scratch, sums_f32, nparts, R * C, tail, has_tail, ff, (hipStream_t)stream);
+}
+
+extern "C" int dram_bn_fold_finalize(const float* partial, double* sums, double* scratch, int nparts, int C, double count,
+                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                     float momentum, float eps, int update_running, float* mean, float* invstd,
+                                     float* scale, float* shift, dram_stream_t stream) {
+  if (!partial || !sums || !scratch || nparts < 1 || C < 1 || count <= 0.0) return DRAM_ERR_BAD_ARG;
+  if (!gamma || !beta || !mean || !invstd || !scale || !shift) return DRAM_ERR_BAD_ARG;
+  if (update_running && (!running_mean || !running_var)) return DRAM_ERR_BAD_ARG;
+  FoldFinalize ff{count, gamma, beta, running_mean, running_var, momentum, eps, update_running, mean, invstd, scale, shift};
+  return fold_launch(partial, sums, scratch, nullptr, nparts, 2 * C, 0.0, 0, ff, (hipStream_t)stream);
 }
 
 extern "C" int dram_bn_finalize(const double* sums, double count, const double* count_dev, const float* gamma,

@@ -77,11 +77,13 @@ class Engine:
                 flat, sums = ops.reduce_partials(sp, tail=count)
                 st.dist.all_reduce_stats(flat)
                 count_dev = flat[-1:]
-            else:
-                sums = ops.reduce_partials(sp)
-            mean, invstd, scale, shift = ops.bn_finalize(sums, count, P[bnp + ".weight"], P[bnp + ".bias"],
-                                                         P[bnp + ".running_mean"], P[bnp + ".running_var"],
-                                                         BN_MOMENTUM, BN_EPS, True, count_dev)
+                mean, invstd, scale, shift = ops.bn_finalize(sums, count, P[bnp + ".weight"], P[bnp + ".bias"],
+                                                             P[bnp + ".running_mean"], P[bnp + ".running_var"],
+                                                             BN_MOMENTUM, BN_EPS, True, count_dev)
+            else:                                       # one launch: fold of the epilogue's partial sums + finalize
+                mean, invstd, scale, shift = ops.bn_fold_finalize(sp, count, P[bnp + ".weight"], P[bnp + ".bias"],
+                                                                  P[bnp + ".running_mean"], P[bnp + ".running_var"],
+                                                                  BN_MOMENTUM, BN_EPS)
             st.nbt.append(P[bnp + ".num_batches_tracked"])      # incremented together at the end of forward
         else:
             mean, invstd, scale, shift = ops.bn_finalize(None, 1.0, P[bnp + ".weight"], P[bnp + ".bias"],
@@ -95,10 +97,9 @@ class Engine:
         bnp = c["bn"]
         zmask, (sc, sh) = (c["z"], (None, None)) if c.get("ss") is None else (None, c["ss"])
         part = ops.bn_bwd_reduce(dz, zmask, c["y"], c["mean"], c["invstd"], True, sc, sh)
-        sums = ops.reduce_partials(part)
         # parameter gradients use the LOCAL sums (DDP averages them afterwards), the input
         # gradient the all-reduced ones -- torch SyncBatchNorm semantics.
-        sf = sums.float()                                  # one conversion; the two gradients are its rows
+        sums, sf = ops.reduce_partials(part, want_f32=True)     # (the float copy: the two parameter gradients, its rows)
         st.grads[bnp + ".weight"] = sf[1]
         st.grads[bnp + ".bias"] = sf[0]
         count, count_dev = c["count"]
@@ -359,12 +360,24 @@ class Engine:
         with ops.launch_scope(saved["dense"].device):
             return self._backward(saved, g_dense, g_outs)
 
+    @staticmethod
+    def _two_streams() -> bool:
+        """Weight-gradient kernels and the per-step weight packing on the engine's second stream?  Eager steps: yes.
+        While the step is being captured into a hipGraph: no -- the two-branch schedule CAN be captured (the side stream
+        forks from the capturing stream by wait_stream / event and rejoins it before the step ends;
+        DRAM_GRAPH_STREAMS=2 under DRAM_TUNING=1), but measured it buys nothing once the launch gaps are gone: config 1
+        42.91 / 42.92 ms, config 3 fp32 41.45 / 41.83, config 2 bf16 17.47 / 18.07, config 3 bf16 17.94 / 18.83 (one /
+        two branches) -- what the second stream wins in the eager step is launch latency, not kernel overlap."""
+        if ops.tuning_env("DRAM_WGRAD_STREAM", "1") == "0":
+            return False
+        return not (torch.cuda.is_current_stream_capturing() and ops.tuning_env("DRAM_GRAPH_STREAMS", "1") != "2")
+
     def _prepack(self, st: _State, key):
         """Training steps repack / re-transform every convolution weight (21 launches for ResNet-18, independent
         of the activations).  From the second step of an input shape on they all run on the engine's second
         stream at the start of forward, under the stem convolution, instead of in front of each layer."""
         plan = self._conv_lists.get(key)
-        if plan is None or ops.tuning_env("DRAM_WGRAD_STREAM", "1") == "0" or torch.cuda.is_current_stream_capturing():
+        if plan is None or not self._two_streams():
             return
         side = ops.side_stream(key[-1])
         main = torch.cuda.current_stream()
@@ -440,7 +453,7 @@ class Engine:
         st: _State = saved["st"]
         if st.dist is not None:
             st.dist.begin_backward(saved["dense"].device)
-        if ops.tuning_env("DRAM_WGRAD_STREAM", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+        if self._two_streams():
             st.side = ops.side_stream(saved["dense"].device.index)
         n0, n1 = saved["n0"], saved["n1"]
         NO = n0 + n1

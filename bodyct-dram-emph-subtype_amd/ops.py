@@ -322,12 +322,14 @@ def _workspace(nbytes: int, device) -> Tensor:
     (device, launch stream): the weight-gradient stream has its own)."""
     device = torch.device(device)
     n = (nbytes + 3) // 4
-    key = (device, _stream().value)
+    # (capturing: a buffer of its own, from the graph's private pool -- an eager call on the same stream that outgrows
+    # the cached buffer later must not free memory a captured graph still writes to on every replay)
+    key = (device, _stream().value, torch.cuda.is_current_stream_capturing())
     ws = _WORKSPACE.pop(key, None)                  # re-inserted below: the dict stays in least-recently-used order
     if ws is None or ws.numel() < n:
         ws = None
         ws = torch.empty((n,), device=device, dtype=torch.float32)
-        while len(_WORKSPACE) >= 4:                 # caller stream + side stream + a graph-capture stream or two; streams
+        while len(_WORKSPACE) >= 6:                 # caller stream + side stream + a graph-capture stream or two; streams
             _WORKSPACE.pop(next(iter(_WORKSPACE)))  # that went away (old captures) must not pin up to 0.7 GB each
     _WORKSPACE[key] = ws
     return ws
@@ -335,7 +337,7 @@ def _workspace(nbytes: int, device) -> Tensor:
 
 # environment switches the library's plan functions read (tests flip them between cases): part of the plan-cache key
 _PLAN_ENV = ("DRAM_CONV_ALGO", "DRAM_WINO_TILING", "DRAM_MATH", "DRAM_W2D_V", "DRAM_IGEMM_V", "DRAM_IGEMM_V3_FORCE",
-             "DRAM_WGRAD_V", "DRAM_BF16_NW", "DRAM_BF16_WGRAD")
+             "DRAM_WGRAD_V", "DRAM_BF16_NW", "DRAM_BF16_WGRAD", "DRAM_W2D_MARGIN")
 
 
 class ConvPlan:
@@ -708,22 +710,43 @@ def stem_bwd_weight(x: Tensor, dy: Tensor, out: Optional[Tensor] = None) -> Tens
 
 
 # --------------------------------------------------------------------------- batch norm
-def reduce_partials(partial: Tensor, tail: Optional[float] = None):
-    """[P,R,C] float32 -> [R,C] float64.  With `tail` (SyncBN: the rank's element count) returns
-    (flat [R*C+1] float64 whose last element is tail -- the buffer to all-reduce --, its [R,C] view)."""
+def reduce_partials(partial: Tensor, tail: Optional[float] = None, want_f32: bool = False):
+    """[P,R,C] float32 -> [R,C] float64, ONE launch (dram_fold_partials).  With `tail` (SyncBN: the rank's element
+    count) returns (flat [R*C+1] float64 whose last element is tail -- the buffer to all-reduce --, its [R,C] view);
+    with want_f32 additionally a float32 [R,C] copy written by the same kernel (appended to the result)."""
     _req(partial, "partial")
     Pn, R, C = partial.shape
-    stages = _L().dram_reduce_partials_stages(Pn)
+    stages = _L().dram_fold_partials_stages(Pn)
     n = R * C + (1 if tail is not None else 0)
-    buf = torch.empty((n + (stages * R * C if stages > 1 else 0),), device=partial.device, dtype=torch.float64)
+    buf = torch.empty((n + stages * R * C,), device=partial.device, dtype=torch.float64)
     flat = buf[:n]
-    scratch = buf[n:] if stages > 1 else None
-    _chk(_L().dram_reduce_partials(_p(partial), _p(flat), _p(scratch), Pn, R, C,
-                                   float(tail) if tail is not None else 0.0, int(tail is not None), _stream()),
-         "dram_reduce_partials")
-    if tail is not None:
-        return flat, flat[:R * C].view(R, C)
-    return flat.view(R, C)
+    f32 = torch.empty((R, C), device=partial.device, dtype=torch.float32) if want_f32 else None
+    _chk(_L().dram_fold_partials(_p(partial), _p(flat), _p(buf[n:]), _p(f32), Pn, R, C,
+                                 float(tail) if tail is not None else 0.0, int(tail is not None), _stream()),
+         "dram_fold_partials")
+    res = (flat, flat[:R * C].view(R, C)) if tail is not None else (flat.view(R, C),)
+    if want_f32:
+        res = res + (f32,)
+    return res if len(res) > 1 else res[0]
+
+
+def bn_fold_finalize(partial: Tensor, count: float, gamma: Tensor, beta: Tensor, running_mean: Tensor,
+                     running_var: Tensor, momentum: float, eps: float):
+    """Training-mode statistics of a single-process step in ONE launch: fold of the convolution epilogue's
+    [P,2,C] partial sums + bn_finalize (running-statistic update included) -> (mean, invstd, scale, shift)."""
+    _req(partial, "partial")
+    Pn, R, C = partial.shape
+    if R != 2:
+        raise ValueError("bn_fold_finalize: expected [P,2,C] partial sums")
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
+        _req(t, nm, shape=(C,))
+    stages = _L().dram_fold_partials_stages(Pn)
+    buf = torch.empty(((1 + stages) * 2 * C,), device=partial.device, dtype=torch.float64)
+    out = torch.empty((4, C), device=partial.device, dtype=torch.float32)
+    _chk(_L().dram_bn_fold_finalize(_p(partial), _p(buf), _p(buf[2 * C:]), Pn, C, float(count), _p(gamma), _p(beta),
+                                    _p(running_mean), _p(running_var), float(momentum), float(eps), 1, _p(out[0]),
+                                    _p(out[1]), _p(out[2]), _p(out[3]), _stream()), "dram_bn_fold_finalize")
+    return out[0], out[1], out[2], out[3]
 
 
 def bn_finalize(sums: Optional[Tensor], count: float, gamma: Tensor, beta: Tensor, running_mean: Tensor,

@@ -25,12 +25,17 @@ wf, wb = ops.pack_conv_weight(w, True, True, g)
 print("plan: algo", ops.conv_algo(g))
 
 
+V = ops.conv3d_fwd_keep(x, wf, None, g, True, True)[2]      # Winograd pipeline: the forward's transformed input
+if V is not None:
+    print("weight gradient timed WITH the forward's cached Winograd-domain input (as in the train step)")
+
+
 def run(mode):
     if mode == "fwd":
         return ops.conv3d_fwd(x, wf, None, g, True)
     if mode == "dgrad":
         return ops.conv3d_bwd_data(dy, wb, g)
-    return ops.conv3d_bwd_weight(x, dy, g)
+    return ops.conv3d_bwd_weight(x, dy, g, v_cache=V)
 
 
 for mode in modes:
