@@ -197,7 +197,11 @@ template <int MODE, int NZ, int NY, int NX, bool SPLIT>
 __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                       const WinoGeom g, const int C) {
   constexpr int NI = NZ + 2, NJ = NY + 2, NK = NX + 2;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  // wave index as a SCALAR: tile origin, bounds tests and row addresses are wave-uniform and run on the SALU (from
+  // threadIdx.x >> 6 alone the compiler treats them as divergent: 4 000 VALU instructions of address arithmetic per
+  // (tile, 64 channels) in the F(4,3)^3 input transform, more than its loads + transform math)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cblks = C >> 6;
   const long plane0 = 256L * C;           // point stride inside a 256-tile block (see wino_index)
   const long total = (long)g.Tpad * cblks;
@@ -319,31 +323,52 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 // store phases no longer overlap: 2.7 TB/s where the smaller tilings reach the ~5.3 TB/s of a write-dominated
 // HBM stream.  Here a (tile, 64-channel block) is TWO units: unit hx keeps only the x points 3hx .. 3hx + 2
 // of every x row as it is loaded (108 live values); both units read the whole tile, the second from L1/L2.
+// Addressing: everything about a unit except the lane's channel is WAVE-UNIFORM (tile origin, bounds, row and point
+// offsets), so it runs on the scalar unit and the memory instructions are BUFFER loads / stores: a load's per-lane
+// offset is ONE v_add (scalar row offset + the lane's channel bytes; a row outside the volume gets an offset beyond
+// the descriptor's range and reads 0 in hardware: no select, no mask), a store's lane offset is a constant register
+// and its point offset a scalar.  The first form computed 64-bit flat addresses and bounds masks per lane: 4 000 VALU
+// instructions per unit, more than its transform arithmetic (~900) -- the kernel was VALU-bound on address math
+// (tools/isa_mix.py), not on memory.
+constexpr unsigned WINO_OOB = 0xF0000000u;       // beyond any descriptor range (ranges are < 2^31 bytes)
+constexpr int WINO_RSRC_FLAGS = 0x00020000;      // raw buffer, 32-bit data format
+
 template <int MODE, int HX, bool SPLIT, bool NT>
-__device__ __forceinline__ void wino_half444(const float* __restrict__ in, float* __restrict__ o, const WinoGeom& g,
-                                            const int C, const int c, const int lane, const int b, const int z0,
-                                            const int y0, const int x0, const long plane) {
+__device__ __forceinline__ void wino_half444(const float* __restrict__ in, float* __restrict__ out, const WinoGeom& g,
+                                            const int C, const int cb, const int lane, const int t, const int b,
+                                            const int z0, const int y0, const int x0) {
   constexpr int NI = 6, NJ = 6, NK = 6;
   float v[NI][NJ][3];
+  const int d = g.d;
+  // input window: sample b, z planes zb .. zb + nzp - 1
+  const int zb = MODE == 0 ? (z0 - d > 0 ? z0 - d : 0) : z0;
+  int nzp = (MODE == 0 ? z0 + 4 * d : z0 + 3 * d) + 1 - zb;
+  if (nzp > g.D - zb) nzp = g.D - zb;
+  const unsigned row_b = (unsigned)C * 4u, line_b = (unsigned)g.W * row_b, plane_b = (unsigned)g.H * line_b;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(in) + ((long)b * g.D + zb) * ((long)g.H * g.W * C), 0, (int)(nzp * plane_b), WINO_RSRC_FLAGS);
+  const unsigned c4 = (unsigned)(cb + lane) * 4u;
   if (MODE == 0) {
+    unsigned yo[NJ], xo[NK];
+    bool yv[NJ], xv[NK];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int y = y0 + (j - 1) * d, x = x0 + (j - 1) * d;
+      yv[j] = (y >= 0) & (y < g.H); yo[j] = (unsigned)y * line_b;
+      xv[j] = (x >= 0) & (x < g.W); xo[j] = (unsigned)x * row_b;
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int z = z0 + (i - 1) * g.d;
-      const bool zo = (z >= 0) & (z < g.D);
+      const int z = z0 + (i - 1) * d;
+      const bool zv = (z >= 0) & (z < g.D);
+      const unsigned zo = (unsigned)(z - zb) * plane_b;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int y = y0 + (j - 1) * g.d;
-        const bool yo = zo & (y >= 0) & (y < g.H);
         float row[NK];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-          const int x = x0 + (k - 1) * g.d;
-          const bool ok = yo & (x >= 0) & (x < g.W);
-          // branch-free: a wave-uniform "ok ? load : 0" becomes a branch around every load, and the loads of a
-          // row are then waited for one row at a time (6 in flight per wave)
-          const long oo = ok ? ((((long)b * g.D + z) * g.H + y) * g.W + x) * C + c : c;
-          const float ld = in[oo];
-          row[k] = ok ? ld : 0.f;
+          const unsigned so = (zv & yv[j] & xv[k]) ? zo + yo[j] + xo[k] : WINO_OOB;      // scalar
+          row[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)(so + c4), 0, 0));
         }
         bt4(row);
 #pragma unroll
@@ -376,20 +401,26 @@ __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float
       }
   } else {
     float p[4][4][3], q2[4][NJ][3];
+    unsigned yo[4], xo[4];
+    bool yv[4], xv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = y0 + j * d, x = x0 + j * d;
+      yv[j] = y < g.H; yo[j] = (unsigned)y * line_b;
+      xv[j] = x < g.W; xo[j] = (unsigned)x * row_b;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int z = z0 + i * g.d;
+      const int z = z0 + i * d;
+      const bool zv = z < g.D;
+      const unsigned zo = (unsigned)(z - zb) * plane_b;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int y = y0 + j * g.d;
         float u[4], r[NK];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int x = x0 + k * g.d;
-          const bool ok = (z < g.D) & (y < g.H) & (x < g.W);
-          const long oo = ok ? ((((long)b * g.D + z) * g.H + y) * g.W + x) * C + c : c;
-          const float ld = in[oo];
-          u[k] = ok ? ld : 0.f;
+          const unsigned so = (zv & yv[j] & xv[k]) ? zo + yo[j] + xo[k] : WINO_OOB;
+          u[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)(so + c4), 0, 0));
         }
         a4(u, r);
 #pragma unroll
@@ -419,45 +450,51 @@ __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float
         for (int i = 0; i < NI; ++i) v[i][j][kk] = col[i];
       }
   }
+  // output: the tile's [point][t % 256][C] block; lane offset constant, point offset scalar
+  const unsigned pplane = 256u * (unsigned)C * 4u;              // bytes between two points of a tile
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + wino_index(t, g.npts, C), 0,
+                                                                        (int)(216u * pplane), WINO_RSRC_FLAGS);
+  const unsigned co4 = (unsigned)(SPLIT ? cb + split_pos(lane) : cb + lane) * 4u;
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int kk = 0; kk < 3; ++kk)
-      {
+      for (int kk = 0; kk < 3; ++kk) {
         const float val = SPLIT ? split_pack(v[i][j][kk], lane & 1) : v[i][j][kk];
-        if (NT) __builtin_nontemporal_store(val, o + ((i * NJ + j) * NK + 3 * HX + kk) * plane);
-        else o[((i * NJ + j) * NK + 3 * HX + kk) * plane] = val;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, (int)co4,
+                                              (int)(((i * NJ + j) * NK + 3 * HX + kk) * pplane), NT ? 2 : 0);
       }
 }
 
 template <int MODE, bool SPLIT, bool NT>
 __global__ __launch_bounds__(256, 2) void wino_in444_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                          const WinoGeom g, const int C) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: see wino_half444
   const int cblks = C >> 6;
-  const long plane0 = 256L * C;
   const long total = (long)g.Tpad * cblks * 2;
   for (long w2 = blockIdx.x * 4L + wave; w2 < total; w2 += gridDim.x * 4L) {
     const int hx = (int)(w2 & 1);          // the two halves of a tile sit in neighbouring waves: shared L1 lines
     const long w = w2 >> 1;
-    long plane = plane0;                   // opaque per iteration: otherwise the 108 point offsets k * plane are
-    asm volatile("" : "+s"(plane));        // hoisted out of the loop as 64-bit loop invariants and spilled
     const int t = (int)(w / cblks);
-    const int c = (int)(w - (long)t * cblks) * 64 + lane;
-    float* o = out + wino_index(t, g.npts, C) + (SPLIT ? c - lane + split_pos(lane) : c);
-    if (t >= g.T) {
+    const int cb = (int)(w - (long)t * cblks) * 64;
+    if (t >= g.T) {                        // padding rows of the GEMM M tile: zeros (the TN GEMM contracts over t)
+      const unsigned pplane = 256u * (unsigned)C * 4u;
+      const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + wino_index(t, g.npts, C), 0,
+                                                                            (int)(216u * pplane), WINO_RSRC_FLAGS);
+      const unsigned co4 = (unsigned)(cb + lane) * 4u;
 #pragma unroll
       for (int i = 0; i < 36; ++i)
 #pragma unroll
-        for (int kk = 0; kk < 3; ++kk) o[(i * 6 + 3 * hx + kk) * plane] = 0.f;
+        for (int kk = 0; kk < 3; ++kk)
+          __builtin_amdgcn_raw_buffer_store_b32(0u, rout, (int)co4, (int)((i * 6 + 3 * hx + kk) * pplane), 0);
       continue;
     }
     int b, z0, y0, x0;
     tile_origin(g, t, b, z0, y0, x0);
-    if (hx == 0) wino_half444<MODE, 0, SPLIT, NT>(in, o, g, C, c, lane, b, z0, y0, x0, plane);
-    else wino_half444<MODE, 1, SPLIT, NT>(in, o, g, C, c, lane, b, z0, y0, x0, plane);
+    if (hx == 0) wino_half444<MODE, 0, SPLIT, NT>(in, out, g, C, cb, lane, t, b, z0, y0, x0);
+    else wino_half444<MODE, 1, SPLIT, NT>(in, out, g, C, cb, lane, t, b, z0, y0, x0);
   }
 }
 
@@ -476,17 +513,25 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
                                                        const WinoGeom g, const int N) {
   constexpr int NI = NZ + 2, NJ = NY + 2, NK = NX + 2;
   __shared__ float red[4][2][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  // wave index as a SCALAR: tile origin, bounds tests and row addresses are wave-uniform and run on the SALU (from
+  // threadIdx.x >> 6 alone the compiler treats them as divergent: 4 000 VALU instructions of address arithmetic per
+  // (tile, 64 channels) in the F(4,3)^3 input transform, more than its loads + transform math)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cblks = N >> 6;
   const int cb = blockIdx.x % cblks, tb = blockIdx.x / cblks;
   const int c = cb * 64 + lane;
-  const long plane = 256L * N;
   const float bv = bias ? bias[c] : 0.f;
   float s1 = 0.f, s2 = 0.f;
   for (int q = wave; q < WINO_TPB; q += 4) {
     const int t = tb * WINO_TPB + q;
     if (t >= g.T) break;
-    const float* src = mh + wino_index(t, g.npts, N) + c;
+    // the tile's [point][t % 256][N] block of the image: buffer loads, lane offset constant, point offset scalar
+    // (wino_half444: no per-lane address arithmetic)
+    const unsigned pplane = 256u * (unsigned)N * 4u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(mh) + wino_index(t, g.npts, N), 0, (int)((unsigned)(NI * NJ * NK) * pplane), WINO_RSRC_FLAGS);
+    const unsigned c4 = (unsigned)c * 4u;
     float o[NZ][NY][NX];
     constexpr bool ROLLED = NZ == 4 && NY == 4 && NX == 4;
     if (ROLLED) {
@@ -497,12 +542,13 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 #pragma unroll 1
       for (int i = 0; i < NI; ++i) {
         float m[NJ][NK], p[NJ][NX], q2[NY][NX];
-        const float* sp = src + (long)i * (NJ * NK) * plane;
+        const unsigned sp = (unsigned)i * (NJ * NK) * pplane;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int k = 0; k < NK; ++k)
-            m[j][k] = NT ? __builtin_nontemporal_load(sp + (j * NK + k) * plane) : sp[(j * NK + k) * plane];
+            m[j][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)c4, (int)(sp + (j * NK + k) * pplane),
+                                                                                      NT ? 2 : 0));
 #pragma unroll
         for (int j = 0; j < NJ; ++j) atz<NX>(m[j], p[j]);
 #pragma unroll
@@ -530,7 +576,8 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int k = 0; k < NK; ++k) m[j][k] = src[((i * NJ + j) * NK + k) * plane];
+        for (int k = 0; k < NK; ++k)
+          m[j][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)c4, (int)(((i * NJ + j) * NK + k) * pplane), 0));
 #pragma unroll
       for (int j = 0; j < NJ; ++j) atz<NX>(m[j], p[j]);
 #pragma unroll
@@ -558,6 +605,17 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
     }
     int b, z0, y0, x0;
     tile_origin(g, t, b, z0, y0, x0);
+    // output window: sample b, z planes from z0 (descriptors on out / add / gate with the same offsets)
+    const unsigned row_b = (unsigned)N * 4u, line_b = (unsigned)g.W * row_b, plane_b = (unsigned)g.H * line_b;
+    int nzp = (NZ - 1) * g.d + 1;
+    if (nzp > g.D - z0) nzp = g.D - z0;
+    const long wbase = ((long)b * g.D + z0) * ((long)g.H * g.W * N);
+    const int wbytes = (int)((unsigned)nzp * plane_b);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + wbase, 0, wbytes, WINO_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t radd =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(add ? add : out) + wbase, 0, wbytes, WINO_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rgate =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gate ? gate : out) + wbase, 0, wbytes, WINO_RSRC_FLAGS);
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
       const int z = z0 + i * g.d;
@@ -567,14 +625,19 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
           const int x = x0 + k * g.d;
-          if ((z < g.D) & (y < g.H) & (x < g.W)) {
-            const long oo = ((((long)b * g.D + z) * g.H + y) * g.W + x) * N + c;
+          if ((z < g.D) & (y < g.H) & (x < g.W)) {          // wave-uniform
+            const int so = (int)((unsigned)(i * g.d) * plane_b + (unsigned)y * line_b + (unsigned)x * row_b);   // scalar
             float v = o[i][j][k] + bv;
             if (add) {
-              const float av = add[oo];
-              v += gate ? (gate[oo] > 0.f ? av : 0.f) : av;
+              const float av = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)c4, so, 0));
+              if (gate) {
+                const float gv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rgate, (int)c4, so, 0));
+                v += gv > 0.f ? av : 0.f;
+              } else {
+                v += av;
+              }
             }
-            out[oo] = v;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)c4, so, 0);
             s1 += v;
             s2 += v * v;
           }
@@ -1702,7 +1765,8 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
     const int m64 = g.Tpad / 64;
     const long total = (long)g.npts * m64;
     if (total < (1L << 31) && (total >= 4096 || stream_on == 2)) {
-      const int wgs = 256;                                           // one persistent workgroup per CU
+      const int wgs = stream_on == 2 ? 8 : 256;                      // one persistent workgroup per CU (tests: 8 in all,
+                                                                     // so that small cases run the ring too)
       const int per_wg = (int)((total + wgs - 1) / wgs);
       const int grid = (int)((total + per_wg - 1) / per_wg);
 #define WNS(NJ_, KT_, S_)                                                                                          \

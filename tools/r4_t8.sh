@@ -1,0 +1,12 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r4; mkdir -p $O; cd $R
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "winograd or linearity" > $O/t8_kernels.log 2>&1; echo "kernels rc=$?"; tail -2 $O/t8_kernels.log
+export DRAM_TUNING=1
+for spec in "2 64 128 128 128 64 3 1 1" "2 64 128 128 64 64 3 1 1" "2 16 32 32 512 512 3 1 4"; do
+    echo "== $spec pipeline"
+    DRAM_CONV_ALGO=2 python tools/conv_bench.py $spec fwd,dgrad,wgrad 10 2>&1 | grep -E "^fwd|^dgrad|^wgrad" | cut -c1-8,90-130
+done
+unset DRAM_TUNING
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --timeline off > $O/b8_c1.json 2>/dev/null
+python -c "import json;d=json.load(open('$O/b8_c1.json'));print('config 1', round(d['value'],2),'vol/s', round(d['ms_per_step'],3),'ms')"
+bash tools/r4_prof.sh > /dev/null 2>&1
