@@ -514,7 +514,7 @@ def main():
             "peak_hbm_gb": torch.cuda.max_memory_allocated(device) / 1e9,
         }
         if dctx is not None:
-            ran = args.warmup + args.steps + (args.steps + 1 if args.timeline == "after" else 0)
+            ran = args.warmup + args.steps + (args.steps + 1 if args.timeline in ("after", "off") else 0)   # + second pass
             out["collectives_per_step"] = {k: v / ran for k, v in dctx.stats.items()}
             if args.timeline in ("after", "off"):
                 # time the data path's stream sat between issuing a SyncBN statistic exchange and continuing, per step

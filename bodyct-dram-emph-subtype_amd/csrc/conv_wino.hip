@@ -344,6 +344,7 @@ __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float
   const int zb = MODE == 0 ? (z0 - d > 0 ? z0 - d : 0) : z0;
   int nzp = (MODE == 0 ? z0 + 4 * d : z0 + 3 * d) + 1 - zb;
   if (nzp > g.D - zb) nzp = g.D - zb;
+  if (nzp < 0) nzp = 0;            // a tile of an EMPTY residue sub-lattice (dilation > extent: z0 >= D): nothing in range
   const unsigned row_b = (unsigned)C * 4u, line_b = (unsigned)g.W * row_b, plane_b = (unsigned)g.H * line_b;
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(in) + ((long)b * g.D + zb) * ((long)g.H * g.W * C), 0, (int)(nzp * plane_b), WINO_RSRC_FLAGS);
@@ -609,6 +610,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
     const unsigned row_b = (unsigned)N * 4u, line_b = (unsigned)g.W * row_b, plane_b = (unsigned)g.H * line_b;
     int nzp = (NZ - 1) * g.d + 1;
     if (nzp > g.D - z0) nzp = g.D - z0;
+    if (nzp < 0) nzp = 0;          // (tile of an empty residue sub-lattice: every store below is guarded out as well)
     const long wbase = ((long)b * g.D + z0) * ((long)g.H * g.W * N);
     const int wbytes = (int)((unsigned)nzp * plane_b);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + wbase, 0, wbytes, WINO_RSRC_FLAGS);
@@ -1997,13 +1999,16 @@ extern "C" int dram_conv_algo(const DramConvDesc* d) {
     const double rf = d->Cout % 64 == 0 ? 200e12 : 155e12, rb = d->Cin % 64 == 0 ? 200e12 : 155e12;
     const double w2d = vox * zt / d->D * 54.0 * d->Cin * d->Cout * 0.5 * (1.0 / rf + 1.0 / rb);
     const double direct = vox * 54.0 * d->Cin * d->Cout / 135e12;
-    // the fused kernel needs no workspace (the pipeline: 2 x 3.4-4.5x the activation bytes); rounds 1-3 let it keep a
-    // layer unless the pipeline was estimated > 15 % faster.  Round 4: with the streaming Winograd-domain GEMM the
-    // pipeline measures 1.89 / 1.80 ms against 2.09 / 1.92 fused on 64->64 @ 2x64x128x128 (0.270 / 0.276 against
-    // 0.294 / 0.288 at 32x64x64) and hands its transformed input to the weight gradient (1.59 against 1.83 ms),
-    // and 2-4 GB of workspace are nothing on a 288-GB device: the cheaper estimate wins (DRAM_W2D_MARGIN: A/B)
-    const char* me = tune_env("DRAM_W2D_MARGIN");
-    const double margin = me ? atof(me) : 1.0;
+    // the fused kernel needs no workspace (the pipeline: 2 x 3.4-4.5x the activation bytes) and its F(2x2) transforms
+    // round 10x less than F(4,3)^3 (1e-6 against 1.1e-5 per layer); rounds 1-3 let it keep a layer unless the pipeline
+    // was estimated > 15 % faster.  Round 4: with the streaming Winograd-domain GEMM the pipeline measures 1.89 / 1.80
+    // ms against 2.09 / 1.92 fused on 64->64 @ 2x64x128x128 (0.270 / 0.276 against 0.294 / 0.288 at 32x64x64) and
+    // hands its transformed input to the weight gradient (1.59 against 1.83 ms).  The cheaper estimate now wins on the
+    // LAST decoder stage (D >= 64: its rounding reaches the output un-amplified), not below it: with layer1 / us1 of
+    // ResNet-50 on the pipeline the full-size dRAM volumes sit 1.47e-3 from the fp64 oracle (bar 1e-3; 54 BatchNorm
+    // layers amplify an early error), with the margin kept there they pass as before.  (DRAM_W2D_MARGIN[_BIG]: A/B)
+    const char* me = tune_env(d->D >= 64 ? "DRAM_W2D_MARGIN_BIG" : "DRAM_W2D_MARGIN");
+    const double margin = me ? atof(me) : (d->D >= 64 ? 1.0 : 1.15);
     if (w2d < 0.92 * direct && w2d < margin * best) { best = w2d; pick = 2; }
   }
   return pick;
@@ -2050,8 +2055,8 @@ extern "C" int dram_conv_wgrad_algo(const DramConvDesc* d) {
     // same preference as the forward plan: the z-walking kernel keeps a layer unless the pipeline (which
     // here would also have to transform x again: the fused forward kernel leaves no V) is estimated > 15 %
     // faster (64->64 @ 2x64x128x128: measured 1.89 vs 2.51 ms)
-    const char* me = tune_env("DRAM_W2D_MARGIN");
-    const double margin = me ? atof(me) : 1.0;
+    const char* me = tune_env(d->D >= 64 ? "DRAM_W2D_MARGIN_BIG" : "DRAM_W2D_MARGIN");
+    const double margin = me ? atof(me) : (d->D >= 64 ? 1.0 : 1.15);      // as in dram_conv_algo
     if (w2d < 0.92 * direct && w2d < margin * best) { best = w2d; pick = 2; }
   }
   return pick;

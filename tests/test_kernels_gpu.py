@@ -197,6 +197,7 @@ WINO_CASES = [
     (1, 16, 16, 16, 128, 256, 2),       # TN GEMM, 128-column tiles, split over t
     (1, 8, 16, 16, 256, 256, 4),        # layer3/4-like: 256-column tiles, dilation 4
     (2, 4, 8, 8, 192, 320, 1),          # channel counts that are only multiples of 64
+    (1, 2, 5, 3, 64, 64, 4),            # dilation > extent: EMPTY residue sub-lattices (tiles whose origin lies outside)
 ]
 
 
