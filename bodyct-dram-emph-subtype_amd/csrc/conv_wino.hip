@@ -330,7 +330,11 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 // and its point offset a scalar.  The first form computed 64-bit flat addresses and bounds masks per lane: 4 000 VALU
 // instructions per unit, more than its transform arithmetic (~900) -- the kernel was VALU-bound on address math
 // (tools/isa_mix.py), not on memory.
-constexpr unsigned WINO_OOB = 0xF0000000u;       // beyond any descriptor range (ranges are < 2^31 bytes)
+// An out-of-volume coordinate contributes 2^30 to the offset instead of its byte offset: windows are < 2^30 bytes
+// (wino_size_ok), so a sum with any such term lies beyond the descriptor's range whatever the other terms are -- the
+// validity of a row needs no flag and no select, only the two scalar adds of the offset itself (18 scalars per tile;
+// with separate flags the scalar state of the unrolled tile spilled into VGPR lanes: 700 v_readlane / v_writelane).
+constexpr unsigned WINO_OOB = 0x40000000u;
 constexpr int WINO_RSRC_FLAGS = 0x00020000;      // raw buffer, 32-bit data format
 
 template <int MODE, int HX, bool SPLIT, bool NT>
@@ -351,26 +355,23 @@ __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float
   const unsigned c4 = (unsigned)(cb + lane) * 4u;
   if (MODE == 0) {
     unsigned yo[NJ], xo[NK];
-    bool yv[NJ], xv[NK];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int y = y0 + (j - 1) * d, x = x0 + (j - 1) * d;
-      yv[j] = (y >= 0) & (y < g.H); yo[j] = (unsigned)y * line_b;
-      xv[j] = (x >= 0) & (x < g.W); xo[j] = (unsigned)x * row_b;
+      yo[j] = ((y >= 0) & (y < g.H)) ? (unsigned)y * line_b : WINO_OOB;
+      xo[j] = ((x >= 0) & (x < g.W)) ? (unsigned)x * row_b : WINO_OOB;
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int z = z0 + (i - 1) * d;
-      const bool zv = (z >= 0) & (z < g.D);
-      const unsigned zo = (unsigned)(z - zb) * plane_b;
+      const unsigned zo = ((z >= 0) & (z < g.D)) ? (unsigned)(z - zb) * plane_b : WINO_OOB;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         float row[NK];
+        const unsigned zy = zo + yo[j];
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-          const unsigned so = (zv & yv[j] & xv[k]) ? zo + yo[j] + xo[k] : WINO_OOB;      // scalar
-          row[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)(so + c4), 0, 0));
-        }
+        for (int k = 0; k < NK; ++k)
+          row[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)(zy + xo[k] + c4), 0, 0));
         bt4(row);
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) v[i][j][kk] = row[3 * HX + kk];
@@ -403,26 +404,23 @@ __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float
   } else {
     float p[4][4][3], q2[4][NJ][3];
     unsigned yo[4], xo[4];
-    bool yv[4], xv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int y = y0 + j * d, x = x0 + j * d;
-      yv[j] = y < g.H; yo[j] = (unsigned)y * line_b;
-      xv[j] = x < g.W; xo[j] = (unsigned)x * row_b;
+      yo[j] = y < g.H ? (unsigned)y * line_b : WINO_OOB;
+      xo[j] = x < g.W ? (unsigned)x * row_b : WINO_OOB;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int z = z0 + i * d;
-      const bool zv = z < g.D;
-      const unsigned zo = (unsigned)(z - zb) * plane_b;
+      const unsigned zo = z < g.D ? (unsigned)(z - zb) * plane_b : WINO_OOB;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float u[4], r[NK];
+        const unsigned zy = zo + yo[j];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned so = (zv & yv[j] & xv[k]) ? zo + yo[j] + xo[k] : WINO_OOB;
-          u[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)(so + c4), 0, 0));
-        }
+        for (int k = 0; k < 4; ++k)
+          u[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)(zy + xo[k] + c4), 0, 0));
         a4(u, r);
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) p[i][j][kk] = r[3 * HX + kk];
@@ -456,16 +454,23 @@ __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float
   const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + wino_index(t, g.npts, C), 0,
                                                                         (int)(216u * pplane), WINO_RSRC_FLAGS);
   const unsigned co4 = (unsigned)(SPLIT ? cb + split_pos(lane) : cb + lane) * 4u;
+  // the point offset as ONE running scalar (opaque to the optimiser: left alone it precomputes all 108 products
+  // point x pplane up front and the scalar file spills into VGPR lanes)
+  unsigned so = (unsigned)(3 * HX) * pplane;
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NJ; ++j) {
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) {
         const float val = SPLIT ? split_pack(v[i][j][kk], lane & 1) : v[i][j][kk];
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, (int)co4,
-                                              (int)(((i * NJ + j) * NK + 3 * HX + kk) * pplane), NT ? 2 : 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, (int)co4, (int)so, NT ? 2 : 0);
+        so += pplane;
+        asm volatile("" : "+s"(so));
       }
+      so += 3u * pplane;
+      asm volatile("" : "+s"(so));
+    }
 }
 
 template <int MODE, bool SPLIT, bool NT>
@@ -1641,6 +1646,10 @@ bool wino_size_ok(const DramConvDesc* d) {   // int32 offsets inside one xi plan
     const long long T = (long long)g.B * g.d * g.d * g.d * g.Tz * g.Ty * g.Tx;
     if (!(T > 0 && (T + 255) * cmax < (1LL << 31))) return false;
   }
+  // buffer-addressed transforms: a tile's window of input z planes (5 dil + 1 planes), the 216-point block of one tile
+  // and its window of output planes each lie below 2^30 bytes (WINO_OOB)
+  const long long plane_b = (long long)d->H * d->W * cmax * 4;
+  if ((5LL * d->dil + 1) * plane_b >= (1LL << 30) || 216LL * 256 * cmax * 4 >= (1LL << 30)) return false;
   return true;
 }
 
