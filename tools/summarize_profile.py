@@ -20,7 +20,8 @@ FAMILIES = [("conv3_bf16", "conv_bf16"), ("gemm1_bf16", "conv_bf16"), ("wgrad3",
             ("pack_weight", "weight_pack"), ("conv_wgrad_w2d", "conv_wgrad_w2d"), ("wgrad_w2d_reduce", "conv_wgrad_w2d"),
             ("conv_igemm", "conv_igemm"), ("conv_wgrad", "conv_wgrad"), ("wgrad_reduce", "conv_wgrad"),
             ("stem_", "stem"), ("bn_", "bn_elementwise"), ("colreduce", "bn_elementwise"),
-            ("reduce_partials", "bn_elementwise"), ("add_kernel", "bn_elementwise"), ("maxpool", "pool_up"),
+            ("reduce_partials", "bn_elementwise"), ("fold_partials", "bn_elementwise"), ("add_kernel", "bn_elementwise"),
+            ("upmix_axis", "pool_up"), ("upmix_split", "weight_pack"), ("upmix_merge", "weight_pack"), ("maxpool", "pool_up"),
             ("upcat", "pool_up"), ("upproject", "pool_up"), ("head_", "head_loss"), ("segloss", "head_loss"),
             ("adam_multi", "optim"), ("sgd_multi", "optim"), ("window_stats", "prep"), ("prep_", "prep")]
 
@@ -49,7 +50,7 @@ def one_config(cfg, dsfx, fsfx):
         return
     # ---- kernel trace summary -----------------------------------------------------------------
     stats = max(glob.glob(os.path.join(src, "trace" + dsfx, "*", "*kernel_stats.csv")), key=os.path.getmtime)   # newest run
-    shutil.copy(stats, os.path.join(dst, f"{tag}_rocprofv3_kernel_stats_bench_config{cfg}.csv"))
+    shutil.copy(stats, os.path.join(dst, f"{tag}_rocprofv3_kernel_stats_bench_config{cfg}{'_bf16' if 'bf16' in fsfx else ''}.csv"))
     rows = list(csv.DictReader(open(stats)))
     steps = 7.0   # 2 warm-up + 5 timed
     PMC_STEPS = 4.0   # the PMC passes run --steps 3 --warmup 1
@@ -57,7 +58,8 @@ def one_config(cfg, dsfx, fsfx):
     fam = collections.defaultdict(lambda: [0.0, 0])
     with open(os.path.join(dst, f"{tag}_rocprofv3_summary{fsfx}.txt"), "w") as out:
         out.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --timeline off "
-                  f"--no-cpu-baseline --config {cfg}   (one MI355X; DRAM_WGRAD_STREAM=0: single-stream pass)\n")
+                  f"--no-cpu-baseline --no-graph --config {cfg}{' --dtype bf16' if 'bf16' in fsfx else ''}   "
+                  "(one MI355X; DRAM_TUNING=1 DRAM_WGRAD_STREAM=0: single-stream pass)\n")
         out.write(f"# total kernel time {tot / steps / 1e6:.2f} ms/step over 7 steps (2 warm-up + 5 timed); "
                   "columns: ms/step, calls/step, avg us, %, kernel\n")
         for r in rows[:48]:
@@ -72,7 +74,7 @@ def one_config(cfg, dsfx, fsfx):
             out.write(f"# family {k}: {ns / steps / 1e6:.3f} ms/step, {calls / steps:.1f} launches/step, "
                       f"average launch {ns / max(calls, 1) / 1e3:.1f} us\n")
         try:
-            line = [l for l in open(os.path.join(src, f"bench_config{cfg}.json.log")) if l.startswith("{")][-1]
+            line = [l for l in open(os.path.join(src, f"bench_config{cfg}{'_bf16' if 'bf16' in fsfx else ''}.json.log")) if l.startswith("{")][-1]
             j = json.loads(line)
             rf = j["roofline"]
             out.write(f"# bench.py (same build, no rocprofv3): {j['value']:.2f} volumes/s, {j['ms_per_step']:.2f} ms/step; "
@@ -99,6 +101,8 @@ def one_config(cfg, dsfx, fsfx):
 
     fetch, lf = pmc("pmc_fetch")
     write, lw = pmc("pmc_write")
+    if not fetch and not write:          # trace-only configuration (config 3): no counter passes were run
+        return
     traffic = {}
     for fm in sorted(set(fetch) | set(write)):
         n = max(len(lf[fm].get("FETCH_SIZE", ())), len(lw[fm].get("WRITE_SIZE", ())), 1)
@@ -124,4 +128,6 @@ def one_config(cfg, dsfx, fsfx):
 
 one_config(1, "", "")
 one_config(2, "_c2", "_config2")
+one_config(3, "_c3", "_config3")              # ResNet-50 (the reference's default model): kernel traces only
+one_config(3, "_c3bf", "_config3_bf16")
 print("wrote", sorted(os.listdir(dst)))
