@@ -93,7 +93,7 @@ SIGNATURES = {
     "dram_reduce_partials_stages": (I, [I]),
     "dram_reduce_partials": (I, [P, P, P, I, I, I, D, I, P]),
     "dram_fold_partials_stages": (I, [I]),
-    "dram_fold_partials": (I, [P, P, P, P, I, I, I, D, I, P]),
+    "dram_fold_partials": (I, [P, P, P, P, P, I, I, I, D, I, P]),
     "dram_bn_fold_finalize": (I, [P, P, P, I, I, D, P, P, P, P, F, F, I, P, P, P, P, P]),
     "dram_bn_finalize": (I, [P, D, P, P, P, P, P, F, F, I, P, P, P, P, I, P]),
     "dram_bn_apply": (I, [P, P, P, P, I, I, I, I, I, P, I, I, I, I, I, I, P]),

@@ -84,7 +84,8 @@ __device__ unsigned g_fold_ticket[FOLD_SLOTS * FOLD_XMAX];
 // per column group, the last of its S blocks folds the S stage rows (independent agent-scope loads, fixed order).
 __global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __restrict__ partial, double* scratch,
                                                              double* __restrict__ sums, float* __restrict__ sums_f32,
-                                                             const int nparts, const int RC, const double tail,
+                                                             float* __restrict__ f32_row1, const int nparts, const int RC,
+                                                             const double tail,
                                                              const int has_tail, const int slot, const FoldFinalize ff) {
   __shared__ double sm[1024];
   __shared__ double tot[64];
@@ -121,7 +122,12 @@ __global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __rest
   }
   if (lane4 == 0 && live) {
     sums[col] = total;
-    if (sums_f32) sums_f32[col] = (float)total;
+    // float copy (BatchNorm parameter gradients): row 1 may live in its own allocation, so that both rows are
+    // whole tensors autograd can take over without a copy (a row VIEW of one [2][C] tensor is cloned by AccumulateGrad)
+    if (sums_f32) {
+      if (f32_row1 && col >= C) f32_row1[col - C] = (float)total;
+      else sums_f32[col] = (float)total;
+    }
   }
   if (has_tail && blockIdx.x == 0 && threadIdx.x == 0) sums[RC] = tail;
   if (!ff.gamma) return;
@@ -548,25 +554,26 @@ extern "C" int dram_fold_partials_stages(int nparts) {
   return s > 64 ? 64 : s;
 }
 
-static int fold_launch(const float* partial, double* sums, double* scratch, float* sums_f32, int nparts, int RC,
-                       double tail, int has_tail, const FoldFinalize& ff, hipStream_t st) {
+static int fold_launch(const float* partial, double* sums, double* scratch, float* sums_f32, float* f32_row1, int nparts,
+                       int RC, double tail, int has_tail, const FoldFinalize& ff, hipStream_t st) {
   static std::atomic<unsigned> next_slot{0};         // host-side round robin: launches in flight together (two
   const int slot = (int)(next_slot.fetch_add(1) % FOLD_SLOTS);   // streams, two host threads) use different tickets
   const int S = dram_fold_partials_stages(nparts);
   const int gx = ff.gamma ? (RC / 2 + 31) / 32 : (RC + 63) / 64;
   if (S > 1 && gx > FOLD_XMAX) return DRAM_ERR_UNSUPPORTED;        // (no such layer: S > 1 goes with few channels)
   DramProf prof(DRAM_FAM_BN, 0, 0.0, 4.0 * (double)nparts * RC + 8.0 * RC, st);
-  hipLaunchKernelGGL(fold_partials_kernel, dim3(gx, S), dim3(1024), 0, st, partial, scratch, sums, sums_f32, nparts, RC,
-                     tail, has_tail, slot, ff);
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(gx, S), dim3(1024), 0, st, partial, scratch, sums, sums_f32, f32_row1,
+                     nparts, RC, tail, has_tail, slot, ff);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
 
-extern "C" int dram_fold_partials(const float* partial, double* sums, double* scratch, float* sums_f32, int nparts, int R,
-                                  int C, double tail, int has_tail, dram_stream_t stream) {
+extern "C" int dram_fold_partials(const float* partial, double* sums, double* scratch, float* sums_f32, float* f32_row1,
+                                  int nparts, int R, int C, double tail, int has_tail, dram_stream_t stream) {
   if (!partial || !sums || !scratch || nparts < 1 || R < 1 || C < 1) return DRAM_ERR_BAD_ARG;
+  if (f32_row1 && (R != 2 || !sums_f32)) return DRAM_ERR_BAD_ARG;
   FoldFinalize ff{};
-  return fold_launch(partial, sums, scratch, sums_f32, nparts, R * C, tail, has_tail, ff, (hipStream_t)stream);
+  return fold_launch(partial, sums, scratch, sums_f32, f32_row1, nparts, R * C, tail, has_tail, ff, (hipStream_t)stream);
 }
 
 extern "C" int dram_bn_fold_finalize(const float* partial, double* sums, double* scratch, int nparts, int C, double count,
@@ -577,7 +584,7 @@ extern "C" int dram_bn_fold_finalize(const float* partial, double* sums, double*
   if (!gamma || !beta || !mean || !invstd || !scale || !shift) return DRAM_ERR_BAD_ARG;
   if (update_running && (!running_mean || !running_var)) return DRAM_ERR_BAD_ARG;
   FoldFinalize ff{count, gamma, beta, running_mean, running_var, momentum, eps, update_running, mean, invstd, scale, shift};
-  return fold_launch(partial, sums, scratch, nullptr, nparts, 2 * C, 0.0, 0, ff, (hipStream_t)stream);
+  return fold_launch(partial, sums, scratch, nullptr, nullptr, nparts, 2 * C, 0.0, 0, ff, (hipStream_t)stream);
 }
 
 extern "C" int dram_bn_finalize(const double* sums, double count, const double* count_dev, const float* gamma,

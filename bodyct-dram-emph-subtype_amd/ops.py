@@ -713,15 +713,21 @@ def stem_bwd_weight(x: Tensor, dy: Tensor, out: Optional[Tensor] = None) -> Tens
 def reduce_partials(partial: Tensor, tail: Optional[float] = None, want_f32: bool = False):
     """[P,R,C] float32 -> [R,C] float64, ONE launch (dram_fold_partials).  With `tail` (SyncBN: the rank's element
     count) returns (flat [R*C+1] float64 whose last element is tail -- the buffer to all-reduce --, its [R,C] view);
-    with want_f32 additionally a float32 [R,C] copy written by the same kernel (appended to the result)."""
+    with want_f32 additionally a list of R float32 [C] tensors (the rows, separately allocated) written by the same
+    kernel (appended to the result)."""
     _req(partial, "partial")
     Pn, R, C = partial.shape
     stages = _L().dram_fold_partials_stages(Pn)
     n = R * C + (1 if tail is not None else 0)
     buf = torch.empty((n + stages * R * C,), device=partial.device, dtype=torch.float64)
     flat = buf[:n]
-    f32 = torch.empty((R, C), device=partial.device, dtype=torch.float32) if want_f32 else None
-    _chk(_L().dram_fold_partials(_p(partial), _p(flat), _p(buf[n:]), _p(f32), Pn, R, C,
+    # float copy: one tensor PER ROW (whole tensors, which autograd takes over as .grad without a copy; row views of
+    # one [R, C] tensor are cloned by AccumulateGrad -- 108 copies per ResNet-50 step)
+    f32 = [torch.empty((C,), device=partial.device, dtype=torch.float32) for _ in range(R)] if want_f32 else None
+    if want_f32 and R > 2:
+        raise ValueError("reduce_partials: the float copy supports at most two rows")
+    _chk(_L().dram_fold_partials(_p(partial), _p(flat), _p(buf[n:]), _p(f32[0]) if f32 else None,
+                                 _p(f32[1]) if (f32 and R == 2) else None, Pn, R, C,
                                  float(tail) if tail is not None else 0.0, int(tail is not None), _stream()),
          "dram_fold_partials")
     res = (flat, flat[:R * C].view(R, C)) if tail is not None else (flat.view(R, C),)

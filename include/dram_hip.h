@@ -258,12 +258,13 @@ int dram_stem_bwd_weight(const float* x, const float* dy, float* dw, int B, int 
  *   global count (ranks may hold different batch sizes -- torch SyncBatchNorm semantics). */
 int dram_reduce_partials_stages(int nparts);
 /* The same fold in ONE launch (S = dram_fold_partials_stages(nparts) stage rows; for S > 1 the last block of a column
- * group to finish folds them, fixed order): scratch = S*R*C doubles, sums_f32: optional float copy of the sums.
+ * group to finish folds them, fixed order): scratch = S*R*C doubles, sums_f32: optional float copy of the sums
+ * ([R][C]; with f32_row1 != NULL and R == 2, row 1 goes there instead: two separately allocated [C] tensors).
  * dram_bn_fold_finalize: fold of the [nparts][2][C] convolution-epilogue partials + dram_bn_finalize on the result
  * (host-side count) in that launch -- the single-process training forward. */
 int dram_fold_partials_stages(int nparts);
-int dram_fold_partials(const float* partial, double* sums, double* scratch, float* sums_f32, int nparts, int R, int C,
-                       double tail, int has_tail, dram_stream_t stream);
+int dram_fold_partials(const float* partial, double* sums, double* scratch, float* sums_f32, float* f32_row1, int nparts,
+                       int R, int C, double tail, int has_tail, dram_stream_t stream);
 int dram_bn_fold_finalize(const float* partial, double* sums, double* scratch, int nparts, int C, double count,
                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                           float eps, int update_running, float* mean, float* invstd, float* scale, float* shift,
