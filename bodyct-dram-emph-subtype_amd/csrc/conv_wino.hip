@@ -1400,6 +1400,77 @@ __global__ __launch_bounds__(512) void wino_gemm_tn_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------
+// TN GEMM for a 64 x 64 result per point (the 64->64 layers on the pipeline): wino_gemm_tn_kernel's smallest tile with
+// M = 64 is 64 x 128, so half its B loads and MFMAs were padding and a workgroup kept 16 KB of real bytes in flight
+// per stage (3.6 GB in 1.22 ms: 3.0 TB/s).  Here: 64 x 64, K steps of 64 rows (2 x 16 KB per stage, two stages,
+// two workgroups per CU); the eight waves are (row half, column half, K half) -- the two K halves of a 32 x 32
+// block meet through LDS at the end, added in a fixed order.
+__global__ __launch_bounds__(512, 2) void wino_gemm_tn64_kernel(const float* __restrict__ Ah, const float* __restrict__ Bh,
+                                                                float* __restrict__ slab, const int Tpad, const int nsplit,
+                                                                const int kper, const int nblk, const int npts) {
+  constexpr int M = 64, N = 64, KS = 64;
+  constexpr int STAGE = KS * (M + N);                 // floats
+  __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int L = xcd_remap(blockIdx.x, nblk);
+  const int split = L % nsplit;
+  const int xi = L / nsplit;
+  const int t0 = split * kper;
+  const int t1 = (t0 + kper < Tpad) ? t0 + kper : Tpad;
+  // DMA: a piece = 4 rows x 64 floats (1 KB); a stage = 16 pieces of A + 16 of B, two of each per wave
+  const int prow = lane >> 4, pcol = (lane & 15) * 4;
+  auto issue = [&](int it, int stage) __attribute__((always_inline)) {
+    float* as = lds + stage * STAGE;
+    float* bs = as + KS * M;
+    const int tt = t0 + it * KS;            // 64 rows of one 256-tile block: [tt / 256][xi][tt % 256 ..]
+    const long row = ((long)(tt >> 8) * npts + xi) * 256 + (tt & 255);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int p = 2 * wave + j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ah + (row + p * 4 + prow) * M + pcol),
+                                       (__attribute__((address_space(3))) void*)(as + p * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bh + (row + p * 4 + prow) * N + pcol),
+                                       (__attribute__((address_space(3))) void*)(bs + p * 256), 16, 0, 0);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave & 1, wn = (wave >> 1) & 1, kh = wave >> 2;
+  const int niter = (t1 - t0) / KS;
+  if (niter > 0) issue(0, 0);
+  for (int it = 0; it < niter; ++it) {
+    __syncthreads();
+    if (it + 1 < niter) issue(it + 1, (it + 1) & 1);
+    const float* as = lds + (it & 1) * STAGE + (kh * 32) * M + wm * 32 + li;
+    const float* bs = lds + (it & 1) * STAGE + KS * M + (kh * 32) * N + wn * 32 + li;
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+      const int kr = 2 * kk + lh;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[kr * M], bs[kr * N], acc, 0, 0, 0);
+    }
+  }
+  // K halves: kh = 1 hands its block over through LDS, kh = 0 adds (fixed order) and stores
+  __syncthreads();
+  float* ex = lds + (wave & 3) * 1024;
+  if (kh == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ex[e * 64 + lane] = acc[e];
+  }
+  __syncthreads();
+  if (kh == 0) {
+    float* sb = slab + (((long)split * npts + xi) * M) * N;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      sb[(long)row * N + wn * 32 + li] = acc[e] + ex[e * 64 + lane];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // TN batched GEMM on the bf16 matrix cores (weight gradient in the "bf16x3" / "bf16" math modes): both
 // operands are split-bf16 images [t][channel] and the contraction runs over the ROW index t, so an MFMA
 // operand (8 consecutive t of one channel per lane) is a transposed read of the LDS image:
@@ -2187,7 +2258,11 @@ extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache,
       hipLaunchKernelGGL((wino_gemm_tn_kernel<WM_, MI_, NJ_>), dim3(nblk), dim3(512), 0, s, Dh, V, slab, g.Tpad,       \
                          d->Cout, d->Cin, p.m_tiles, p.n_tiles, p.nsplit, p.kper, nblk, g.npts);                       \
   } while (0)
-  if (p.bm == 256 && p.bn == 256) WTN(4, 2, 4);
+  static const int tn64 = tune_env("DRAM_TN64") ? atoi(tune_env("DRAM_TN64")) : 1;      // A/B switch
+  if (tn64 && math == 0 && d->Cout == 64 && d->Cin == 64 && p.kper % 64 == 0 && g.Tpad % 64 == 0)
+    hipLaunchKernelGGL(wino_gemm_tn64_kernel, dim3(g.npts * p.nsplit), dim3(512), 0, s, Dh, V, slab, g.Tpad, p.nsplit,
+                       p.kper, g.npts * p.nsplit, g.npts);
+  else if (p.bm == 256 && p.bn == 256) WTN(4, 2, 4);
   else if (p.bm == 256 && p.bn == 128) WTN(4, 2, 2);
   else if (p.bm == 256 && p.bn == 64) WTN(4, 2, 1);
   else if (p.bm == 128 && p.bn == 256) WTN(2, 2, 2);
