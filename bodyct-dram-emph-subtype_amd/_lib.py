@@ -104,6 +104,8 @@ SIGNATURES = {
     "dram_colsum": (I, [P, P, LL, I, P]),
     "dram_maxpool_fwd": (I, [P, P, P, I, I, I, I, I, P]),
     "dram_maxpool_bwd": (I, [P, P, P, I, P, I, I, I, I, I, P]),
+    "dram_bn_maxpool_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    "dram_bn_maxpool_fwd_bf16": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "dram_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "dram_upcat_bwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "dram_upmix_stat_rows": (I, [LL]),

@@ -71,6 +71,76 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
   }
 }
 
+// Stem: BatchNorm-apply + ReLU + max-pool (+ argmax) in ONE pass over the pre-BN convolution output (reference
+// med3d.py:272-275: bn1, relu, maxpool).  A thread computes z = relu(y * scale + shift) for the 27 taps of its pooling
+// window (the expression and the storage rounding of bn_apply_kernel, so z, the pooled values and the taps are bit-
+// identical to the two-pass form), takes the window maximum, and WRITES z for the 2x2x2 block of inputs it owns
+// (taps k in {1, 2} per axis: inputs 2o, 2o + 1) -- z is still needed (skip connection of us2, ReLU mask of the
+// backward pass); what the fusion saves is the second read of that 537-MB tensor.
+template <typename T, int VW>
+__global__ void bn_maxpool_fwd_kernel(const T* __restrict__ yin, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, T* __restrict__ z, T* __restrict__ pooled,
+                                      uint8_t* __restrict__ amax, int D, int H, int W, int C, int Do, int Ho, int Wo,
+                                      long total) {
+  const int Q = C / VW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    long v = i / Q;
+    const int xo = (int)(v % Wo); v /= Wo;
+    const int yo = (int)(v % Ho); v /= Ho;
+    const int zo = (int)(v % Do);
+    const long b = v / Do;
+    float sc[VW], sh[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) { sc[k] = scale[VW * q + k]; sh[k] = shift[VW * q + k]; }
+    fvec<VW> m;
+    int am[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) { m.v[k] = -INFINITY; am[k] = 0; }
+    bool first = true;
+    for (int kz = 0; kz < 3; ++kz) {
+      const int zi = 2 * zo - 1 + kz;
+      if (zi < 0 || zi >= D) continue;
+      fvec<VW> t[3][3];
+      bool ok[3][3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yi = 2 * yo - 1 + ky, xi = 2 * xo - 1 + kx;
+          ok[ky][kx] = (yi >= 0) & (yi < H) & (xi >= 0) & (xi < W);
+          const int yc = yi < 0 ? 0 : (yi >= H ? H - 1 : yi), xc = xi < 0 ? 0 : (xi >= W ? W - 1 : xi);
+          t[ky][kx] = ldv<T, VW>(yin, (((b * D + zi) * H + yc) * W + xc) * (long)C + VW * q);
+        }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          if (!ok[ky][kx]) continue;
+          const int tap = (kz * 3 + ky) * 3 + kx;
+          fvec<VW> a;
+#pragma unroll
+          for (int k = 0; k < VW; ++k) {
+            float tv = fmaxf(__builtin_fmaf(t[ky][kx].v[k], sc[k], sh[k]), 0.f);
+            if (sizeof(T) == 2) tv = bf16_to_f32(f32_to_bf16(tv));        // the value the two-pass form stores and re-reads
+            a.v[k] = tv;
+            if (first || tv > m.v[k] || tv != tv) { m.v[k] = tv; am[k] = tap; }
+          }
+          first = false;
+          if (kz >= 1 && ky >= 1 && kx >= 1) {                            // an input this window owns
+            const int yi = 2 * yo - 1 + ky, xi = 2 * xo - 1 + kx;
+            stv<T, VW>(z, (((b * D + zi) * H + yi) * W + xi) * (long)C + VW * q, a);
+          }
+        }
+    }
+    stv<T, VW>(pooled, VW * i, m);
+#pragma unroll
+    for (int k = 0; k < VW; k += 4)
+      reinterpret_cast<uchar4*>(amax)[(VW / 4) * i + (k >> 2)] =
+          make_uchar4((unsigned char)am[k], (unsigned char)am[k + 1], (unsigned char)am[k + 2], (unsigned char)am[k + 3]);
+  }
+}
+
 template <typename T, int VW>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ amax,
                                    const T* __restrict__ add, int add_stride, T* __restrict__ dx, int D, int H,
@@ -503,6 +573,31 @@ static int maxpool_fwd_impl(const T* x, T* y, uint8_t* argmax, int B, int D, int
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }
+template <typename T>
+static int bn_maxpool_fwd_impl(const T* y, const float* scale, const float* shift, T* z, T* pooled, uint8_t* argmax, int B,
+                               int D, int H, int W, int C, dram_stream_t stream) {
+  if (!y || !scale || !shift || !z || !pooled || !argmax || B < 1 || D < 1 || H < 1 || W < 1 || C < 4 || (C & 3))
+    return DRAM_ERR_BAD_ARG;
+  const int Do = (D + 2 - 3) / 2 + 1, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total4 = (long)B * Do * Ho * Wo * (C >> 2);
+  DramProf prof(DRAM_FAM_POOL_UP, 6, 0.0, (double)sizeof(T) * (2.0 * (double)B * D * H * W * C + 4.0 * total4) + 4.0 * total4,
+                (hipStream_t)stream);
+  const bool wide = pool_wide(sizeof(T), {C});
+  const long total = wide ? total4 / 2 : total4;
+  POOL_LAUNCH(wide, bn_maxpool_fwd_kernel, ew_grid(total), y, scale, shift, z, pooled, argmax, D, H, W, C, Do, Ho, Wo, total);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+extern "C" int dram_bn_maxpool_fwd(const float* y, const float* scale, const float* shift, float* z, float* pooled,
+                                   uint8_t* argmax, int B, int D, int H, int W, int C, dram_stream_t stream) {
+  return bn_maxpool_fwd_impl<float>(y, scale, shift, z, pooled, argmax, B, D, H, W, C, stream);
+}
+extern "C" int dram_bn_maxpool_fwd_bf16(const void* y, const float* scale, const float* shift, void* z, void* pooled,
+                                        uint8_t* argmax, int B, int D, int H, int W, int C, dram_stream_t stream) {
+  return bn_maxpool_fwd_impl<bf16_t>((const bf16_t*)y, scale, shift, (bf16_t*)z, (bf16_t*)pooled, argmax, B, D, H, W, C,
+                                     stream);
+}
+
 extern "C" int dram_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int B, int D, int H, int W, int C,
                                 dram_stream_t stream) {
   return maxpool_fwd_impl<float>(x, y, argmax, B, D, H, W, C, stream);

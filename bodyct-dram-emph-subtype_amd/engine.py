@@ -66,7 +66,8 @@ class Engine:
         self._conv_lists: Dict[tuple, list] = {}     # input shape -> [(weight name, geometry)] of a forward
 
     # ------------------------------------------------------------------ BN helpers
-    def _bn_fwd(self, st: _State, y: Tensor, sp: Optional[Tensor], bnp: str, residual, rs, relu=True):
+    def _bn_fwd(self, st: _State, y: Tensor, sp: Optional[Tensor], bnp: str, residual, rs, relu=True, pool=False):
+        """pool: the stem's form -- BatchNorm-apply + ReLU + max-pool in one pass; returns (z, pooled, taps) first."""
         P = st.P
         count = float(y.numel() // y.shape[-1])
         count_dev = None
@@ -89,7 +90,10 @@ class Engine:
             mean, invstd, scale, shift = ops.bn_finalize(None, 1.0, P[bnp + ".weight"], P[bnp + ".bias"],
                                                          P[bnp + ".running_mean"], P[bnp + ".running_var"],
                                                          BN_MOMENTUM, BN_EPS, False)
-        z = ops.bn_apply(y, scale, shift, residual, rs, relu)
+        if pool:
+            z = ops.bn_maxpool_fwd(y, scale, shift)       # (z, pooled, taps)
+        else:
+            z = ops.bn_apply(y, scale, shift, residual, rs, relu)
         # without a residual the backward pass re-derives the ReLU mask from y (scale, shift) instead of reading z
         return z, mean, invstd, (count, count_dev), (None if residual is not None else (scale, shift))
 
@@ -403,8 +407,8 @@ class Engine:
         lungs4 = None if lungs is None else lungs.reshape(B, *lungs.shape[-3:]).contiguous()
 
         y0, sp0 = ops.stem_fwd(x4, P["conv1.weight"], training, storage)
-        xs, mean0, invstd0, count0, ss0 = self._bn_fwd(st, y0, sp0, "bn1", None, 1)
-        xp, amax = ops.maxpool_fwd(xs)
+        # stem BatchNorm-apply + ReLU + max-pool: one pass (K9, med3d.py:272-275)
+        (xs, xp, amax), mean0, invstd0, count0, ss0 = self._bn_fwd(st, y0, sp0, "bn1", None, 1, pool=True)
 
         h = xp
         inplanes = 64

@@ -890,6 +890,22 @@ def maxpool_fwd(x: Tensor):
     return y, am
 
 
+def bn_maxpool_fwd(y: Tensor, scale: Tensor, shift: Tensor):
+    """Stem (med3d.py:272-275): z = relu(y*scale + shift), max-pool 3/2/1 of z and its taps in ONE pass over y --
+    bit-identical to bn_apply(...) + maxpool_fwd(...).  -> (z, pooled, argmax)."""
+    sfx = _act(y, "y")
+    B, D, H, W, C = y.shape
+    _req(scale, "scale", shape=(C,))
+    _req(shift, "shift", shape=(C,))
+    shape = (B, pool_out(D), pool_out(H), pool_out(W), C)
+    z = torch.empty_like(y)
+    pooled = torch.empty(shape, device=y.device, dtype=y.dtype)
+    am = torch.empty(shape, device=y.device, dtype=torch.uint8)
+    _chk(_fn("dram_bn_maxpool_fwd", sfx)(_p(y), _p(scale), _p(shift), _p(z), _p(pooled), _p(am), B, D, H, W, C, _stream()),
+         "dram_bn_maxpool_fwd")
+    return z, pooled, am
+
+
 def maxpool_bwd(dy: Tensor, argmax: Tensor, in_shape, add_: Optional[Tensor] = None) -> Tensor:
     B, D, H, W, C = in_shape
     oshape = (B, pool_out(D), pool_out(H), pool_out(W), C)

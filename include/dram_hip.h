@@ -320,6 +320,11 @@ int dram_colsum(const float* a, float* partial, long long rows, int C, dram_stre
  * of the decoder's concat gradient read in place). */
 int dram_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int B, int D, int H, int W, int C,
                      dram_stream_t stream);
+/* Stem: BatchNorm-apply + ReLU + max-pool in one pass over the pre-BN tensor y (med3d.py:272-275): writes z =
+ * relu(y*scale + shift) (full resolution: skip connection, ReLU mask), the pooled tensor and the taps -- bit-identical to
+ * dram_bn_apply followed by dram_maxpool_fwd, one read of the tensor less. */
+int dram_bn_maxpool_fwd(const float* y, const float* scale, const float* shift, float* z, float* pooled, uint8_t* argmax,
+                        int B, int D, int H, int W, int C, dram_stream_t stream);
 int dram_maxpool_bwd(const float* dy, const uint8_t* argmax, const float* add, int add_stride, float* dx,
                      int B, int D, int H, int W, int C, dram_stream_t stream);
 
@@ -544,6 +549,8 @@ int dram_bn_bwd_apply_bf16(const void* dz, const void* z, const void* y, const f
 int dram_colsum_bf16(const void* a, float* partial, long long rows, int C, dram_stream_t stream);
 int dram_maxpool_fwd_bf16(const void* x, void* y, uint8_t* argmax, int B, int D, int H, int W, int C,
                           dram_stream_t stream);
+int dram_bn_maxpool_fwd_bf16(const void* y, const float* scale, const float* shift, void* z, void* pooled, uint8_t* argmax,
+                             int B, int D, int H, int W, int C, dram_stream_t stream);
 int dram_maxpool_bwd_bf16(const void* dy, const uint8_t* argmax, const void* add, int add_stride, void* dx, int B, int D,
                           int H, int W, int C, dram_stream_t stream);
 int dram_upcat_fwd_bf16(const void* src, const void* skip, void* cat, int B, int Ds, int Hs, int Ws, int Cu, int Dk,

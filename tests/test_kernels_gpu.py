@@ -511,6 +511,21 @@ def test_maxpool(ops, shape):
         assert torch.equal(ops.maxpool_bwd(to_ndhwc(gy), am, tuple(xd.shape), wide[..., 4:]), dx)
 
 
+@pytest.mark.parametrize("shape", [(1, 8, 8, 8, 64), (2, 6, 10, 7, 64), (1, 5, 7, 9, 8)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_stem_bn_relu_maxpool_one_pass(ops, shape, dtype):
+    """K9 (med3d.py:272-275): BatchNorm-apply + ReLU + max-pool of the stem in ONE pass over the pre-BN tensor is
+    bit-identical to bn_apply followed by maxpool_fwd -- z, pooled values and taps; odd extents included."""
+    B, D, H, W, C = shape
+    y = rnd(B, D, H, W, C, seed=1).to(DEV).to(dtype)
+    scale = (rnd(C, seed=2).abs() + 0.5).to(DEV)
+    shift = rnd(C, seed=3).to(DEV) * 0.3
+    z_ref = ops.bn_apply(y, scale, shift, None, 1, True)
+    p_ref, a_ref = ops.maxpool_fwd(z_ref)
+    z, p, a = ops.bn_maxpool_fwd(y, scale, shift)
+    assert torch.equal(z, z_ref) and torch.equal(p, p_ref) and torch.equal(a, a_ref)
+
+
 @pytest.mark.parametrize("case", [(1, 3, 4, 5, 8, 6, 8, 10, 4), (2, 2, 4, 4, 16, 5, 9, 8, 8), (1, 4, 4, 4, 64, 8, 8, 8, 64)])
 def test_upcat(ops, case):
     B, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck = case
