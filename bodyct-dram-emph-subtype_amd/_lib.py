@@ -84,6 +84,8 @@ SIGNATURES = {
     "dram_wino_num_stat_rows": (I, [DP]),
     "dram_wino_v_elems": (SZ, [DP]),
     "dram_wino_conv3d_fwd": (I, [P, P, P, P, P, P, DP, P, SZ, P]),
+    "dram_wino_prologue_supported": (I, [DP]),
+    "dram_wino_conv3d_fwd_bn": (I, [P, P, P, P, P, P, P, P, DP, P, SZ, P]),
     "dram_wino_conv3d_bwd_data": (I, [P, P, P, P, P, DP, P, SZ, P]),
     "dram_wino_conv3d_bwd_weight": (I, [P, P, P, P, DP, P, SZ, P]),
     "dram_stem_num_tiles": (I, [I, I, I, I]),

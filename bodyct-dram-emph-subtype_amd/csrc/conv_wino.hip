@@ -93,14 +93,16 @@ __device__ __forceinline__ void bt2(float* a) {
   const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
   a[0] = a0 - a2; a[1] = a1 + a2; a[2] = a2 - a1; a[3] = a1 - a3;
 }
+// (explicit fma chains: with `a * b + c` left to the compiler's contraction, two instantiations of a transform kernel --
+// with and without the BatchNorm prologue -- fused differently and their images differed in the last bit)
 __device__ __forceinline__ void bt4(float* a) {
   const float d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3], d4 = a[4], d5 = a[5];
-  a[0] = 4.f * d0 - 5.f * d2 + d4;
-  a[1] = -4.f * (d1 + d2) + d3 + d4;
-  a[2] = 4.f * (d1 - d2) - d3 + d4;
-  a[3] = -2.f * d1 - d2 + 2.f * d3 + d4;
-  a[4] = 2.f * d1 - d2 - 2.f * d3 + d4;
-  a[5] = 4.f * d1 - 5.f * d3 + d5;
+  a[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+  a[1] = __builtin_fmaf(-4.f, d1 + d2, d3 + d4);
+  a[2] = __builtin_fmaf(4.f, d1 - d2, d4 - d3);
+  a[3] = __builtin_fmaf(2.f, d3 - d1, d4 - d2);
+  a[4] = __builtin_fmaf(2.f, d1 - d3, d4 - d2);
+  a[5] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
 }
 // A^T m   (n + 2 -> n)
 __device__ __forceinline__ void at2(const float* m, float* r) {
@@ -337,10 +339,15 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 constexpr unsigned WINO_OOB = 0x40000000u;
 constexpr int WINO_RSRC_FLAGS = 0x00020000;      // raw buffer, 32-bit data format
 
-template <int MODE, int HX, bool SPLIT, bool NT>
+// PRO (MODE 0): the input is the PRE-BatchNorm output of the producing convolution and the BatchNorm-apply + ReLU of
+// that unit runs here, on the way in (reference med3d.py:121-124 / :153-156: bn, relu, next conv): x -> max(x * scale +
+// shift, 0) with bn_apply_kernel's expression, zero outside the volume (the scalar offset says so) -- the activation
+// tensor between the two convolutions is never written.
+template <int MODE, int HX, bool SPLIT, bool NT, bool PRO = false>
 __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float* __restrict__ out, const WinoGeom& g,
                                             const int C, const int cb, const int lane, const int t, const int b,
-                                            const int z0, const int y0, const int x0) {
+                                            const int z0, const int y0, const int x0, const float* __restrict__ pscale = nullptr,
+                                            const float* __restrict__ pshift = nullptr) {
   constexpr int NI = 6, NJ = 6, NK = 6;
   float v[NI][NJ][3];
   const int d = g.d;
@@ -353,6 +360,8 @@ __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(in) + ((long)b * g.D + zb) * ((long)g.H * g.W * C), 0, (int)(nzp * plane_b), WINO_RSRC_FLAGS);
   const unsigned c4 = (unsigned)(cb + lane) * 4u;
+  float psc = 1.f, psh = 0.f;
+  if (PRO) { psc = pscale[cb + lane]; psh = pshift[cb + lane]; }
   if (MODE == 0) {
     unsigned yo[NJ], xo[NK];
 #pragma unroll
@@ -370,8 +379,11 @@ __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float
         float row[NK];
         const unsigned zy = zo + yo[j];
 #pragma unroll
-        for (int k = 0; k < NK; ++k)
-          row[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)(zy + xo[k] + c4), 0, 0));
+        for (int k = 0; k < NK; ++k) {
+          const unsigned so = zy + xo[k];
+          row[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)(so + c4), 0, 0));
+          if (PRO) row[k] = so < WINO_OOB ? fmaxf(__builtin_fmaf(row[k], psc, psh), 0.f) : 0.f;     // (scalar condition)
+        }
         bt4(row);
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) v[i][j][kk] = row[3 * HX + kk];
@@ -473,9 +485,11 @@ __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float
     }
 }
 
-template <int MODE, bool SPLIT, bool NT>
+template <int MODE, bool SPLIT, bool NT, bool PRO = false>
 __global__ __launch_bounds__(256, 2) void wino_in444_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                         const WinoGeom g, const int C) {
+                                                         const WinoGeom g, const int C,
+                                                         const float* __restrict__ pscale = nullptr,
+                                                         const float* __restrict__ pshift = nullptr) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: see wino_half444
   const int cblks = C >> 6;
@@ -499,8 +513,8 @@ __global__ __launch_bounds__(256, 2) void wino_in444_kernel(const float* __restr
     }
     int b, z0, y0, x0;
     tile_origin(g, t, b, z0, y0, x0);
-    if (hx == 0) wino_half444<MODE, 0, SPLIT, NT>(in, out, g, C, cb, lane, t, b, z0, y0, x0);
-    else wino_half444<MODE, 1, SPLIT, NT>(in, out, g, C, cb, lane, t, b, z0, y0, x0);
+    if (hx == 0) wino_half444<MODE, 0, SPLIT, NT, PRO>(in, out, g, C, cb, lane, t, b, z0, y0, x0, pscale, pshift);
+    else wino_half444<MODE, 1, SPLIT, NT, PRO>(in, out, g, C, cb, lane, t, b, z0, y0, x0, pscale, pshift);
   }
 }
 
@@ -1775,17 +1789,29 @@ int grid_for(long waves) {
 
 // tile transform into the Winograd domain (MODE 0: B^T x B, MODE 1: A dy A^T), fp32 or split-bf16 image
 template <int MODE>
-int launch_wino_in(const float* src, float* dst, const WinoGeom& g, const int C, const int math, hipStream_t s) {
+int launch_wino_in(const float* src, float* dst, const WinoGeom& g, const int C, const int math, hipStream_t s,
+                   const float* pscale = nullptr, const float* pshift = nullptr) {
   const long units = (long)g.Tpad * (C / 64);
+  if (pscale) {                                  // BatchNorm-apply + ReLU prologue: the F(4,3)^3 input transform only
+    if (MODE != 0 || math || !pshift || !(g.nz == 4 && g.ny == 4 && g.nx == 4)) return DRAM_ERR_UNSUPPORTED;
+    const double in_elems = (double)g.B * g.D * g.H * g.W * C;
+    DramProf prof(DRAM_FAM_WINO_IN, 9444, 0.0, 4.0 * (in_elems + (double)g.npts * g.Tpad * C), s);
+    if constexpr (MODE == 0) {
+      if (wino_nt() & 1) hipLaunchKernelGGL((wino_in444_kernel<0, false, true, true>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C, pscale, pshift);
+      else hipLaunchKernelGGL((wino_in444_kernel<0, false, false, true>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C, pscale, pshift);
+    }
+    DRAM_LAUNCH_CHECK();
+    return DRAM_OK;
+  }
   // algorithmic bytes: the activation read once + the Winograd-domain image written once
   const double in_elems = (double)g.B * g.D * g.H * g.W * C;
   DramProf prof(DRAM_FAM_WINO_IN, MODE * 1000 + g.nz * 100 + g.ny * 10 + g.nx, 0.0,
                 4.0 * (in_elems + (double)g.npts * g.Tpad * C), s);
   static const int half = tune_env("DRAM_WINO_HALF") ? atoi(tune_env("DRAM_WINO_HALF")) : 1;   // A/B switch (tools)
   if (half && g.nz == 4 && g.ny == 4 && g.nx == 4) {
-    if (math) hipLaunchKernelGGL((wino_in444_kernel<MODE, true, false>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C);
-    else if (wino_nt() & 1) hipLaunchKernelGGL((wino_in444_kernel<MODE, false, true>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C);
-    else hipLaunchKernelGGL((wino_in444_kernel<MODE, false, false>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C);
+    if (math) hipLaunchKernelGGL((wino_in444_kernel<MODE, true, false>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C, nullptr, nullptr);
+    else if (wino_nt() & 1) hipLaunchKernelGGL((wino_in444_kernel<MODE, false, true>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C, nullptr, nullptr);
+    else hipLaunchKernelGGL((wino_in444_kernel<MODE, false, false>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C, nullptr, nullptr);
     DRAM_LAUNCH_CHECK();
     return DRAM_OK;
   }
@@ -1873,14 +1899,14 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
 // shared by forward (x, uf) and data gradient (dy, ub): in[..., K] -> out[..., N]
 int run_conv(const float* in, const float* U, const float* bias, const float* add, const float* gate, float* out,
              float* stats, float* v_keep, const DramConvDesc* d, int pass, int K, int N, void* ws, size_t ws_bytes,
-             hipStream_t s) {
+             hipStream_t s, const float* pscale = nullptr, const float* pshift = nullptr) {
   const WinoGeom g = make_geom(d, pass);
   const size_t need = (size_t)g.npts * g.Tpad * ((size_t)K + N) * sizeof(float);
   if (!ws || ws_bytes < need) return DRAM_ERR_WORKSPACE;
   float* V = v_keep ? v_keep : (float*)ws;          // kept for the weight gradient when the caller asks
   float* Mh = (float*)ws + (size_t)g.npts * g.Tpad * K;
   const int math = math_mode();
-  { const int rc0 = launch_wino_in<0>(in, V, g, K, math, s); if (rc0 != DRAM_OK) return rc0; }
+  { const int rc0 = launch_wino_in<0>(in, V, g, K, math, s, pscale, pshift); if (rc0 != DRAM_OK) return rc0; }
   const int rc = run_nn(V, U, Mh, g, N, K, s, GemmEpilogue{nullptr, nullptr, nullptr, nullptr}, math);
   if (rc != DRAM_OK) return rc;
   const int ntb = (g.T + WINO_TPB - 1) / WINO_TPB;
@@ -2203,6 +2229,21 @@ extern "C" int dram_wino_conv3d_fwd(const float* x, const float* uf, const float
   if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
   return run_conv(x, uf, bias, nullptr, nullptr, y, stats_partial, v_keep, d, 0, d->Cin, d->Cout, workspace,
                   workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int dram_wino_prologue_supported(const DramConvDesc* d) {
+  if (!dram_wino_applicable(d) || math_mode()) return 0;
+  const WinoGeom g = make_geom(d, 0);
+  return (g.nz == 4 && g.ny == 4 && g.nx == 4) ? 1 : 0;
+}
+
+extern "C" int dram_wino_conv3d_fwd_bn(const float* x_pre, const float* pscale, const float* pshift, const float* uf,
+                                       const float* bias, float* y, float* stats_partial, float* v_keep,
+                                       const DramConvDesc* d, void* workspace, size_t workspace_bytes, dram_stream_t stream) {
+  if (!x_pre || !pscale || !pshift || !uf || !y) return DRAM_ERR_BAD_ARG;
+  if (!dram_wino_prologue_supported(d)) return DRAM_ERR_UNSUPPORTED;
+  return run_conv(x_pre, uf, bias, nullptr, nullptr, y, stats_partial, v_keep, d, 0, d->Cin, d->Cout, workspace,
+                  workspace_bytes, (hipStream_t)stream, pscale, pshift);
 }
 
 extern "C" size_t dram_wino_v_elems(const DramConvDesc* d) {

@@ -66,8 +66,10 @@ class Engine:
         self._conv_lists: Dict[tuple, list] = {}     # input shape -> [(weight name, geometry)] of a forward
 
     # ------------------------------------------------------------------ BN helpers
-    def _bn_fwd(self, st: _State, y: Tensor, sp: Optional[Tensor], bnp: str, residual, rs, relu=True, pool=False):
-        """pool: the stem's form -- BatchNorm-apply + ReLU + max-pool in one pass; returns (z, pooled, taps) first."""
+    def _bn_fwd(self, st: _State, y: Tensor, sp: Optional[Tensor], bnp: str, residual, rs, relu=True, pool=False,
+                apply=True):
+        """pool: the stem's form -- BatchNorm-apply + ReLU + max-pool in one pass; returns (z, pooled, taps) first.
+        apply=False: statistics / scale / shift only, z = None (the consumer applies them on its way in)."""
         P = st.P
         count = float(y.numel() // y.shape[-1])
         count_dev = None
@@ -90,7 +92,9 @@ class Engine:
             mean, invstd, scale, shift = ops.bn_finalize(None, 1.0, P[bnp + ".weight"], P[bnp + ".bias"],
                                                          P[bnp + ".running_mean"], P[bnp + ".running_var"],
                                                          BN_MOMENTUM, BN_EPS, False)
-        if pool:
+        if not apply:
+            z = None
+        elif pool:
             z = ops.bn_maxpool_fwd(y, scale, shift)       # (z, pooled, taps)
         else:
             z = ops.bn_apply(y, scale, shift, residual, rs, relu)
@@ -123,12 +127,25 @@ class Engine:
                                 True, sc, sh, count_dev=count_dev)
 
     # ------------------------------------------------------------------ conv + BN unit
-    def _conv_bn_fwd(self, st: _State, x: Tensor, wname: str, bname: Optional[str], bnp: str, k: int, stride: int,
-                     pad: int, dil: int, residual=None, rs: int = 1, xr=None):
+    def _conv_bn_fwd(self, st: _State, x, wname: str, bname: Optional[str], bnp: str, k: int, stride: int,
+                     pad: int, dil: int, residual=None, rs: int = 1, xr=None, defer_z: bool = False):
         """xr: how to RE-DERIVE x in backward (activation-recompute mode): ('bn', ctx of the unit whose BN+ReLU output
         x is) or ('upcat', src, skip).  With st.recompute the context then holds neither x nor the cached
-        Winograd-domain image of x, and a unit without residual does not hold its z (its consumer re-derives it)."""
+        Winograd-domain image of x, and a unit without residual does not hold its z (its consumer re-derives it).
+        x may be a DEFERRED input {'y', 'ss'}: the pre-BatchNorm output of the producing unit whose BatchNorm-apply + ReLU
+        was left to this consumer (reference med3d.py:121-124: bn, relu, conv).  Where the convolution can apply them
+        on its way in (the fp32 Winograd pipeline, ops.conv_prologue_ok) the activation tensor in between is never
+        written; elsewhere it is materialised here, as before.  defer_z: leave THIS unit's BatchNorm-apply to its (only)
+        consumer the same way -- the first return value is then such a deferred input."""
         w = st.P[wname]
+        pro = None
+        if isinstance(x, dict):
+            B, D, H, W, Cin = x["y"].shape
+            g = ConvGeom(B, D, H, W, Cin, w.shape[0], k, stride, pad, dil)
+            if k == 3 and ops.conv_prologue_ok(g, x["y"].dtype):
+                pro, x = x["ss"], x["y"]
+            else:
+                x = ops.bn_apply(x["y"], x["ss"][0], x["ss"][1], None, 1, True)
         B, D, H, W, Cin = x.shape
         g = ConvGeom(B, D, H, W, Cin, w.shape[0], k, stride, pad, dil)
         st.convs.append((wname, g))
@@ -144,15 +161,18 @@ class Engine:
         else:                                           # inference: packed / transformed once per weight version
             wf, wb = ops.packed_forward_weight(w, g, st.storage), None
         y, sp, v = ops.conv3d_fwd_keep(x, wf, st.P[bname] if bname else None, g, st.training,
-                                       st.need_grad and not st.recompute)
-        z, mean, invstd, count, ss = self._bn_fwd(st, y, sp, bnp, residual, rs)
+                                       st.need_grad and not st.recompute, prologue=pro)
+        defer_z = defer_z and residual is None
+        z, mean, invstd, count, ss = self._bn_fwd(st, y, sp, bnp, residual, rs, apply=not defer_z)
         c = None
         if st.need_grad:
-            drop_x = st.recompute and xr is not None
+            if pro is not None and xr is None:
+                raise RuntimeError("a fused BatchNorm prologue needs the producing unit's context (xr)")
+            drop_x = (st.recompute and xr is not None) or pro is not None     # (pro: x is the producer's y, not the input)
             c = dict(x=None if drop_x else x, xr=xr if drop_x else None, y=y,
                      z=None if (st.recompute and residual is None) else z, mean=mean, invstd=invstd, g=g, wb=wb,
                      count=count, w=wname, b=bname, bn=bnp, v=v, ss=ss)
-        return z, c
+        return (dict(y=y, ss=ss) if defer_z else z), c
 
     def _conv_bn_bwd(self, st: _State, c: dict, dz: Tensor, need_dx=True, add=None, gate=None):
         dy = self._bn_bwd(st, c, dz)
@@ -201,7 +221,11 @@ class Engine:
             st.grads[c["w"]] = ops.upmix_merge_wgrad(dwlo, dws, out=out)
             c["h"] = None
         else:
-            st.grads[c["w"]] = ops.conv3d_bwd_weight(self._input_of(c), dy, c["g"], out=out, v_cache=c.get("v"))
+            v = c.get("v")
+            # (a unit that applied its producer's BatchNorm on the way in holds no input tensor: the pipeline's weight
+            # gradient takes the forward's transformed input instead; anything else re-derives the input)
+            xin = c["x"] if (c["x"] is not None or (v is not None and ops.conv_plan(c["g"]).walgo == 1)) else self._input_of(c)
+            st.grads[c["w"]] = ops.conv3d_bwd_weight(xin, dy, c["g"], out=out, v_cache=v)
             c["v"] = None                               # release the cached Winograd-domain input
         if st.dist is not None:
             names = [c["w"], c["bn"] + ".weight", c["bn"] + ".bias"] + ([c["b"]] if c["b"] else [])
@@ -236,11 +260,12 @@ class Engine:
     def _block_fwd(self, st, x, p, planes, stride, dil, has_ds):
         e = self.e
         if self.kind == "basic":
-            z1, c1 = self._conv_bn_fwd(st, x, p + ".conv1.weight", None, p + ".bn1", 3, stride, dil, dil)
+            # (z1 has ONE consumer, conv2: its BatchNorm-apply + ReLU is deferred to that convolution's way in)
+            z1, c1 = self._conv_bn_fwd(st, x, p + ".conv1.weight", None, p + ".bn1", 3, stride, dil, dil, defer_z=True)
             z2, c2 = self._conv_bn_fwd(st, z1, p + ".conv2.weight", None, p + ".bn2", 3, 1, dil, dil,
                                        residual=x, rs=stride if has_ds else 1, xr=("bn", c1))
             return z2, (c1, c2, has_ds)
-        z1, c1 = self._conv_bn_fwd(st, x, p + ".conv1.weight", None, p + ".bn1", 1, 1, 0, 1)
+        z1, c1 = self._conv_bn_fwd(st, x, p + ".conv1.weight", None, p + ".bn1", 1, 1, 0, 1, defer_z=True)
         z2, c2 = self._conv_bn_fwd(st, z1, p + ".conv2.weight", None, p + ".bn2", 3, stride, dil, dil, xr=("bn", c1))
         z3, c3 = self._conv_bn_fwd(st, z2, p + ".conv3.weight", None, p + ".bn3", 1, 1, 0, 1,
                                    residual=x, rs=stride if has_ds else 1, xr=("bn", c2))
@@ -293,12 +318,12 @@ class Engine:
         ysk, _ = ops.conv3d_fwd(skip, wf_s, st.P[bname], g_s, False)
         y, sp = ops.upmix_gather_fwd(b, ysk, Co, st.training)
         del b
-        z, mean, invstd, count, ss = self._bn_fwd(st, y, sp, bnp, None, 1)
+        z, mean, invstd, count, ss = self._bn_fwd(st, y, sp, bnp, None, 1, apply=False)     # left to conv_blocks[1]
         c = None
         if st.need_grad:
-            c = dict(kind="upmix", src=src, skip=skip, y=y, z=None if st.recompute else z, mean=mean, invstd=invstd,
+            c = dict(kind="upmix", src=src, skip=skip, y=y, z=None, mean=mean, invstd=invstd,
                      g_lo=g_lo, g_s=g_s, wb_lo=wb_lo, wb_s=wb_s, count=count, w=wname, b=bname, bn=bnp, ss=ss, h=None)
-        return z, c
+        return dict(y=y, ss=ss), c
 
     def _upmix_bwd(self, st, c, dz):
         """-> (gradient w.r.t. the low-resolution source, gradient w.r.t. the skip tensor)"""
@@ -327,7 +352,7 @@ class Engine:
             return zb, (ca, cb, tuple(src.shape), tuple(skip.shape))
         cat = ops.upcat_fwd(src, skip)
         za, ca = self._conv_bn_fwd(st, cat, f"{p}.conv_blocks.0.0.weight", f"{p}.conv_blocks.0.0.bias",
-                                   f"{p}.conv_blocks.0.1", 3, 1, 1, 1, xr=("upcat", src, skip))
+                                   f"{p}.conv_blocks.0.1", 3, 1, 1, 1, xr=("upcat", src, skip), defer_z=True)
         zb, cb = self._conv_bn_fwd(st, za, f"{p}.conv_blocks.1.0.weight", f"{p}.conv_blocks.1.0.bias",
                                    f"{p}.conv_blocks.1.1", 3, 1, 1, 1, xr=("bn", ca))
         if st.recompute and cb is not None:

@@ -337,7 +337,7 @@ def _workspace(nbytes: int, device) -> Tensor:
 
 # environment switches the library's plan functions read (tests flip them between cases): part of the plan-cache key
 _PLAN_ENV = ("DRAM_CONV_ALGO", "DRAM_WINO_TILING", "DRAM_MATH", "DRAM_W2D_V", "DRAM_IGEMM_V", "DRAM_IGEMM_V3_FORCE",
-             "DRAM_WGRAD_V", "DRAM_BF16_NW", "DRAM_BF16_WGRAD", "DRAM_W2D_MARGIN", "DRAM_W2D_MARGIN_BIG")
+             "DRAM_WGRAD_V", "DRAM_BF16_NW", "DRAM_BF16_WGRAD", "DRAM_W2D_MARGIN", "DRAM_W2D_MARGIN_BIG", "DRAM_NN_STREAM")
 
 
 class ConvPlan:
@@ -346,7 +346,7 @@ class ConvPlan:
     dimensions, statistic rows, workspace sizes, cached-transform size -- ~12 host calls into the library
     (each of which re-derives tilings and reads the environment) instead of that many per launch."""
     __slots__ = ("desc", "dref", "algo", "walgo", "taps_f", "taps_b", "stat_rows", "ws_fwd", "ws_bwd", "ws_wgrad",
-                 "v_elems", "ws_direct_wgrad", "bf16", "bf16_stat_rows", "bf16_ws_wgrad")
+                 "v_elems", "ws_direct_wgrad", "bf16", "bf16_stat_rows", "bf16_ws_wgrad", "prologue")
 
     def __init__(self, g: "ConvGeom"):
         L = _L()
@@ -370,6 +370,7 @@ class ConvPlan:
         # bf16-storage path: the direct bf16-MFMA kernels take the 3x3x3 stride-1 and the 1x1x1 convolutions; the one
         # stride-2 convolution per network runs on them through its space-to-depth form (s2_geom), whatever is left
         # (odd extents) on the fp32 kernels above around cast passes
+        self.prologue = bool(self.algo == 1 and L.dram_wino_prologue_supported(d))
         self.bf16 = bool(L.dram_conv_bf16_supported(d))
         self.bf16_stat_rows = int(L.dram_conv_bf16_num_stat_rows(d)) if self.bf16 else 0
         self.bf16_ws_wgrad = int(L.dram_conv3d_bwd_weight_bf16_workspace(d)) if self.bf16 else 0
@@ -499,10 +500,21 @@ def conv3d_fwd(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, want_
     return y, stats
 
 
-def conv3d_fwd_keep(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, want_stats: bool, keep: bool):
+def conv_prologue_ok(g: ConvGeom, dtype=torch.float32) -> bool:
+    """Can the convolution apply the producing unit's BatchNorm + ReLU on the way in (conv3d_fwd_keep(prologue=...))?
+    The fp32 Winograd pipeline with F(4,3)^3 tiles; DRAM_BN_PROLOGUE=0 under DRAM_TUNING=1 switches it off (A/B)."""
+    return dtype == torch.float32 and tuning_env("DRAM_BN_PROLOGUE", "1") != "0" and conv_plan(g).prologue
+
+
+def conv3d_fwd_keep(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, want_stats: bool, keep: bool,
+                    prologue: Optional[Tuple[Tensor, Tensor]] = None):
     """Forward conv; with keep=True on the Winograd path also returns the transformed input V
-    (reused by conv3d_bwd_weight instead of transforming x again), else None."""
+    (reused by conv3d_bwd_weight instead of transforming x again), else None.
+    prologue=(scale, shift): x is the PRE-BatchNorm output of the producing unit and max(x*scale + shift, 0) is applied
+    inside the input transform (only where conv_prologue_ok(g))."""
     plan = conv_plan(g)
+    if prologue is not None and not (x.dtype == torch.float32 and plan.prologue):
+        raise RuntimeError(f"conv3d_fwd_keep: no BatchNorm prologue for {g}")
     if _act(x, "x", g.in_shape):                       # bf16 storage
         if bias is not None:
             _req(bias, "bias", shape=(g.Cout,))
@@ -536,8 +548,14 @@ def conv3d_fwd_keep(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, 
         if keep:
             v = torch.empty((plan.v_elems,), device=x.device, dtype=torch.float32)
         with _span("conv_wino_kernels", g.flops, f"fwd {g}"):
-            _chk(_L().dram_wino_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), _p(v), d, _p(ws),
-                                           nbytes, _stream()), f"dram_wino_conv3d_fwd{g}")
+            if prologue is not None:
+                _req(prologue[0], "scale", shape=(g.Cin,))
+                _req(prologue[1], "shift", shape=(g.Cin,))
+                _chk(_L().dram_wino_conv3d_fwd_bn(_p(x), _p(prologue[0]), _p(prologue[1]), _p(wf), _p(bias), _p(y), _p(stats),
+                                                  _p(v), d, _p(ws), nbytes, _stream()), f"dram_wino_conv3d_fwd_bn{g}")
+            else:
+                _chk(_L().dram_wino_conv3d_fwd(_p(x), _p(wf), _p(bias), _p(y), _p(stats), _p(v), d, _p(ws),
+                                               nbytes, _stream()), f"dram_wino_conv3d_fwd{g}")
         return y, stats, v
     if algo == 3:                                    # 1x1x1: plain GEMM, wf [1, Cout, Cin] is the weight itself
         with _span("conv1x1_gemm", g.flops, f"fwd {g}"):
@@ -614,9 +632,9 @@ def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] 
     plan = conv_plan(g)
     d, walgo = plan.dref, plan.walgo
     shape = (g.Cout, g.Cin, g.k, g.k, g.k)
-    dw = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty(shape, device=dy.device, dtype=torch.float32)
     _req(dw, "dw", shape=shape)
-    if _act(x, "x", g.in_shape):                       # bf16 storage: the gradient itself is fp32
+    if x is not None and _act(x, "x", g.in_shape):     # bf16 storage: the gradient itself is fp32
         _act(dy, "dy", g.out_shape, like=x)
         if plan.bf16:
             nbytes = plan.bf16_ws_wgrad
@@ -631,7 +649,11 @@ def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] 
             _chk(_L().dram_s2_extract_wgrad(_p(dw3), _p(dw), g.Cout, g.Cin, _stream()), "dram_s2_extract_wgrad")
             return dw
         return conv3d_bwd_weight(cast(x, torch.float32), cast(dy, torch.float32), g, out=dw)
-    _req(x, "x", shape=g.in_shape)
+    if x is None:                                     # the forward's transformed input stands in for x (pipeline only)
+        if not (walgo == 1 and v_cache is not None and plan.ws_wgrad):
+            raise RuntimeError(f"conv3d_bwd_weight: x missing and no cached Winograd-domain input for {g}")
+    else:
+        _req(x, "x", shape=g.in_shape)
     _req(dy, "dy", shape=g.out_shape)
     if walgo == 3:
         nbytes = plan.ws_wgrad
@@ -650,7 +672,7 @@ def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] 
     if walgo == 1:
         nbytes = plan.ws_wgrad
         if nbytes:                                   # 0: this geometry's weight gradient stays on the direct path
-            ws = _workspace(nbytes, x.device)
+            ws = _workspace(nbytes, dy.device)
             if v_cache is not None:
                 _req(v_cache, "v_cache", shape=(plan.v_elems,))
             with _span("conv_wino_kernels", g.flops, f"wgrad {g}"):

@@ -180,6 +180,14 @@ size_t dram_wino_v_elems(const DramConvDesc* desc);
 int dram_wino_conv3d_fwd(const float* x, const float* uf, const float* bias, float* y,
                          float* stats_partial, float* v_keep, const DramConvDesc* desc, void* workspace,
                          size_t workspace_bytes, dram_stream_t stream);
+/* The same convolution reading the PRE-BatchNorm output x_pre of the producing unit: BatchNorm-apply + ReLU
+ * (max(x*pscale + pshift, 0), zero padding outside the volume) run inside the input transform (med3d.py:121-124: bn,
+ * relu, next conv) -- the activation tensor in between is never written.  F(4,3)^3 tilings, fp32 math only
+ * (dram_wino_prologue_supported). */
+int dram_wino_prologue_supported(const DramConvDesc* d);
+int dram_wino_conv3d_fwd_bn(const float* x_pre, const float* pscale, const float* pshift, const float* uf, const float* bias,
+                            float* y, float* stats_partial, float* v_keep, const DramConvDesc* d, void* workspace,
+                            size_t workspace_bytes, dram_stream_t stream);
 int dram_wino_conv3d_bwd_data(const float* dy, const float* ub, float* dx, const float* add,
                               const float* gate, const DramConvDesc* desc, void* workspace,
                               size_t workspace_bytes, dram_stream_t stream);

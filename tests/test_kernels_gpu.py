@@ -274,6 +274,33 @@ def test_winograd_streaming_gemm_equals_tiled_gemm(ops, monkeypatch, case):
     assert rel_l2(to_ncdhw(res["2"][0]).double(), ref) < 3e-5
 
 
+@pytest.mark.parametrize("case", [WINO_CASES[0], WINO_CASES[2], WINO_CASES[5], WINO_CASES[7]], ids=str)
+def test_winograd_batchnorm_prologue_is_bit_identical(ops, monkeypatch, case):
+    """K7(b) (med3d.py:121-124: bn, relu, conv): the F(4,3)^3 input transform applies the producing unit's
+    BatchNorm-apply + ReLU on its way in (zero padding outside the volume, ragged / dilated / empty-sub-lattice
+    tiles included) -- output, statistics and the cached transformed input are bit-identical to bn_apply followed
+    by the plain convolution, and the weight gradient runs from that cached input without the activation tensor."""
+    monkeypatch.setenv("DRAM_CONV_ALGO", "2")
+    monkeypatch.setenv("DRAM_WINO_TILING", "4,4,4")
+    B, D, H, W, Cin, Cout, dil = case
+    g = ops.ConvGeom(B, D, H, W, Cin, Cout, 3, 1, dil, dil)
+    assert ops.conv_prologue_ok(g)
+    y_pre = to_ndhwc(rnd(B, Cin, D, H, W, seed=1))
+    scale = (rnd(Cin, seed=2).abs() + 0.5).to(DEV)
+    shift = (rnd(Cin, seed=3) * 0.3).to(DEV)
+    w = (rnd(Cout, Cin, 3, 3, 3, seed=4) * 0.1).to(DEV)
+    bias = rnd(Cout, seed=5).to(DEV)
+    wf, _ = ops.pack_conv_weight(w, True, False, g)
+    z = ops.bn_apply(y_pre, scale, shift, None, 1, True)
+    y0, s0, v0 = ops.conv3d_fwd_keep(z, wf, bias, g, True, True)
+    y1, s1, v1 = ops.conv3d_fwd_keep(y_pre, wf, bias, g, True, True, prologue=(scale, shift))
+    assert torch.equal(y0, y1) and torch.equal(s0, s1) and torch.equal(v0, v1)
+    gy = to_ndhwc(rnd(B, Cout, D, H, W, seed=6))
+    assert torch.equal(ops.conv3d_bwd_weight(None, gy, g, v_cache=v1), ops.conv3d_bwd_weight(z, gy, g, v_cache=v0))
+    monkeypatch.setenv("DRAM_WINO_TILING", "4,4,2")            # other tilings: no prologue (the engine materialises z)
+    assert not ops.conv_prologue_ok(g)
+
+
 MATH_TOL = {  # measured rel-L2 vs fp64 (tools/math_check.py): fp32 6.5e-7 / 1.1e-5, bf16x3 9.8e-6 / 1.7e-4, bf16 5.2e-3 / 9e-2
     ("bf16x3", "2,2,2"): 3e-5, ("bf16x3", "4,4,4"): 5e-4, ("bf16", "2,2,2"): 1.5e-2, ("bf16", "4,4,4"): 0.25}
 
