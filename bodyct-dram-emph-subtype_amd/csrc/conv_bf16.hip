@@ -1156,6 +1156,101 @@ __global__ __launch_bounds__(256) void wgrad1_bf16_kernel(const bf16_t* __restri
   }
 }
 
+// The same weight gradient on 128 x 128 (co, ci) blocks: a wave owns 64 x 64 (four accumulators), so an A or B
+// fragment read from LDS feeds two MFMAs instead of one -- 1 KB of transposed LDS reads per MFMA where the 64 x 64
+// form needs 2 KB (four waves: 256 B per clock against the 128 B the LDS delivers; that form sat at ~240 TFLOP/s).
+// Tiles of 128 voxels, double-buffered (2 x 64 KB); slabs in the 64 x 64-pair layout of the small kernel, so the reduce
+// is shared.  Channel counts that are multiples of 64 but not of 128 run ragged blocks (zero-filled loads, skipped
+// slab pairs).
+struct W1bGeom {
+  long M;
+  int Cin, Cout;
+  int ntile, nsplit, ci_blocks, co_blocks, ci2, co2, npairs, nblk;     // ci_blocks / co_blocks: 64-wide; ci2 / co2: 128-wide
+};
+
+__global__ __launch_bounds__(256) void wgrad1b_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                           float* __restrict__ slab, const W1bGeom g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char d0[32768];   // dy tile: [4 cb][128 voxels][64 B]
+  __shared__ __attribute__((aligned(1024))) unsigned char d1[32768];
+  __shared__ __attribute__((aligned(1024))) unsigned char x0[32768];   // x tile:  [4 ib][128 voxels][64 B]
+  __shared__ __attribute__((aligned(1024))) unsigned char x1[32768];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = xcd_remap(blockIdx.x, g.nblk);
+  const int blk = L % (g.ci2 * g.co2), split = L / (g.ci2 * g.co2);
+  const int cib = blk % g.ci2, cob = blk / g.ci2;                     // 128-wide block indices
+  const int ch = wave & 1, ih = wave >> 1;                            // the wave's 64-channel halves (co, ci)
+  const long xbytes = g.M * g.Cin * 2, dbytes = g.M * g.Cout * 2;
+  auto issue = [&](int t, unsigned char* db, unsigned char* xb) __attribute__((always_inline)) {
+    const long m0 = (long)t * 128;
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(dy, m0 * g.Cout * 2, dbytes), rx = make_rsrc(x, m0 * g.Cin * 2, xbytes);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                     // granule p -> (32-channel block, voxel, slot): byte p * 16 of the image
+      const int p = i * 256 + tid, hf = p >> 9, r = (p >> 2) & 127, sl = p & 3;
+      const int cd = cob * 128 + hf * 32 + sl * 8, cx = cib * 128 + hf * 32 + sl * 8;
+      const bool inr = m0 + r < g.M;
+      BUFLDS16(rd, (inr && cd < g.Cout) ? (unsigned)(((long)r * g.Cout + cd) * 2) : 0xffffffffu, db + i * 4096 + wave * 1024);
+      BUFLDS16(rx, (inr && cx < g.Cin) ? (unsigned)(((long)r * g.Cin + cx) * 2) : 0xffffffffu, xb + i * 4096 + wave * 1024);
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  const int g4 = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3, h = g4 >> 1;
+  const int cpiece = ((g4 & 1) * 2 + (p4 >> 1)) * 16 + (p4 & 1) * 8;
+  const int lo0 = (h * 8 + q) * 64 + cpiece, lo1 = (h * 8 + 4 + q) * 64 + cpiece;
+  auto tr8 = [&](const unsigned char* base) __attribute__((always_inline)) {
+    const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + lo0));
+    const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + lo1));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+  auto compute = [&](const unsigned char* db, const unsigned char* xb) __attribute__((always_inline)) {
+#pragma unroll 2
+    for (int ks = 0; ks < 8; ++ks) {                  // 16 voxels per step; a 32-channel block image is 128 x 64 B = 8 KB
+      const bf16x8 a0 = tr8(db + (2 * ch) * 8192 + ks * 1024), a1 = tr8(db + (2 * ch + 1) * 8192 + ks * 1024);
+      const bf16x8 b0 = tr8(xb + (2 * ih) * 8192 + ks * 1024), b1 = tr8(xb + (2 * ih + 1) * 8192 + ks * 1024);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  };
+  // (two phases with named buffer pairs, as in wgrad1_bf16_kernel)
+  if (split < g.ntile) issue(split, d0, x0);
+  for (int t = split; t < g.ntile; t += 2 * g.nsplit) {
+    WAIT_VM0();
+    __builtin_amdgcn_s_barrier();
+    const bool more = t + g.nsplit < g.ntile;
+    if (more) issue(t + g.nsplit, d1, x1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(d0, x0);
+    WAIT_VM0();
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 * g.nsplit < g.ntile) issue(t + 2 * g.nsplit, d0, x0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) compute(d1, x1);
+  }
+  // slabs: the 64 x 64 pair (co64, ci64) of this wave, laid out as the small kernel does
+  const int li = lane & 31, lh = lane >> 5;
+  const int co64 = cob * 2 + ch, ci64 = cib * 2 + ih;
+  if (co64 < g.co_blocks && ci64 < g.ci_blocks) {
+    float* sb = slab + ((long)split * g.npairs + (long)co64 * g.ci_blocks + ci64) * 4096;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * lh;
+          sb[(a * 32 + row) * 64 + b * 32 + li] = acc[a][b][e];
+        }
+  }
+}
+
 // dw[co][ci][tap] = sum_split slab[split][pair(co / 64, ci / 32)][tap][co % 64][ci % 32], fixed order
 // dw[co][ci][tap] = sum_split slab[split][pair][tap][co % 64][ci % cw], fixed order (deterministic).
 // PER_PAIR: one thread per (co, ci) -- its `taps` results are contiguous in dw and, for a fixed tap, neighbouring
@@ -1497,6 +1592,27 @@ int launch_gemm1(const bf16_t* x, const bf16_t* w, const bf16_t* add, const bf16
   return DRAM_OK;
 }
 
+bool wgrad1_big(const DramConvDesc* d) {      // 128 x 128 blocks: from 128 channels on both sides (A/B: DRAM_BF16_WGRAD1=small)
+  static const bool small = tune_env("DRAM_BF16_WGRAD1") && !strcmp(tune_env("DRAM_BF16_WGRAD1"), "small");
+  return !small && d->Cin >= 128 && d->Cout >= 128;
+}
+void plan_wgrad1b(const DramConvDesc* d, W1bGeom& g) {
+  g.M = (long)d->B * d->D * d->H * d->W;
+  g.Cin = d->Cin; g.Cout = d->Cout;
+  g.ntile = (int)((g.M + 127) / 128);
+  g.ci_blocks = d->Cin / 64;
+  g.co_blocks = d->Cout / 64;
+  g.ci2 = (d->Cin + 127) / 128;
+  g.co2 = (d->Cout + 127) / 128;
+  g.npairs = g.ci_blocks * g.co_blocks;
+  const int nb = g.ci2 * g.co2;
+  int ns = (512 + nb - 1) / nb;                  // ~512 workgroups (one per CU and a half: 128 KB of LDS each)
+  if (ns > g.ntile / 2) ns = g.ntile / 2;
+  if (ns > 256) ns = 256;
+  if (ns < 1) ns = 1;
+  g.nsplit = ns;
+  g.nblk = nb * ns;
+}
 void plan_wgrad1(const DramConvDesc* d, W1Geom& g) {
   g.M = (long)d->B * d->D * d->H * d->W;
   g.Cin = d->Cin; g.Cout = d->Cout;
@@ -1619,6 +1735,11 @@ extern "C" int dram_conv3d_bwd_data_bf16(const void* dy, const void* wb, void* d
 
 extern "C" size_t dram_conv3d_bwd_weight_bf16_workspace(const DramConvDesc* d) {
   if (geom1_ok(d)) {
+    if (wgrad1_big(d)) {
+      W1bGeom wb{};
+      plan_wgrad1b(d, wb);
+      return (size_t)wb.nsplit * wb.npairs * 4096 * sizeof(float);
+    }
     W1Geom w1{};
     plan_wgrad1(d, w1);
     return (size_t)w1.nsplit * w1.npairs * 4096 * sizeof(float);
@@ -1637,6 +1758,25 @@ extern "C" size_t dram_conv3d_bwd_weight_bf16_workspace(const DramConvDesc* d) {
 extern "C" int dram_conv3d_bwd_weight_bf16(const void* x, const void* dy, float* dw, const DramConvDesc* d,
                                            void* workspace, size_t workspace_bytes, dram_stream_t stream) {
   if (!x || !dy || !dw) return DRAM_ERR_BAD_ARG;
+  if (geom1_ok(d) && wgrad1_big(d)) {
+    W1bGeom wb{};
+    plan_wgrad1b(d, wb);
+    const size_t needb = (size_t)wb.nsplit * wb.npairs * 4096 * sizeof(float);
+    if (!workspace || workspace_bytes < needb) return DRAM_ERR_WORKSPACE;
+    hipStream_t s1 = (hipStream_t)stream;
+    {
+      DramProf prof(DRAM_FAM_WGRAD_BF16, 6, 2.0 * (double)wb.ntile * 128.0 * d->Cin * d->Cout,
+                    2.0 * (double)wb.M * (d->Cin + d->Cout) + 4.0 * d->Cin * d->Cout, s1, 2.0 * (double)wb.M * d->Cin * d->Cout);
+      hipLaunchKernelGGL(wgrad1b_bf16_kernel, dim3(wb.nblk), dim3(256), 0, s1, (const bf16_t*)x, (const bf16_t*)dy,
+                         (float*)workspace, wb);
+      DRAM_LAUNCH_CHECK();
+    }
+    const long n1 = (long)d->Cout * d->Cin;
+    DramProf prof(DRAM_FAM_WGRAD_BF16, 5, 0.0, 4.0 * (double)n1 * (wb.nsplit + 1), s1);
+    launch_reduce((const float*)workspace, dw, d->Cout, d->Cin, wb.ci_blocks, wb.npairs, wb.nsplit, 64, 1, s1);
+    DRAM_LAUNCH_CHECK();
+    return DRAM_OK;
+  }
   if (geom1_ok(d)) {
     W1Geom w1{};
     plan_wgrad1(d, w1);

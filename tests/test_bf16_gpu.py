@@ -116,7 +116,9 @@ def test_conv3_bf16_fwd_dgrad_wgrad(ops, monkeypatch, case, nw, wg):
     assert torch.equal(dw, ops.conv3d_bwd_weight(nd(x.detach()), nd(gy), g))
 
 
-@pytest.mark.parametrize("case", [(2, 4, 6, 5, 128, 64), (1, 8, 8, 8, 64, 256), (1, 5, 6, 7, 256, 128), (1, 16, 16, 16, 512, 64)], ids=str)
+@pytest.mark.parametrize("case", [(2, 4, 6, 5, 128, 64), (1, 8, 8, 8, 64, 256), (1, 5, 6, 7, 256, 128), (1, 16, 16, 16, 512, 64),
+                                  (1, 8, 8, 9, 192, 320),      # 128 x 128 weight-gradient blocks, ragged in both channel counts
+                                  (2, 8, 16, 16, 256, 384)], ids=str)
 def test_conv1x1_bf16_gemm(ops, case):
     """the 1x1x1 convolutions of the Bottleneck blocks as bf16 GEMMs over the flat voxel index (gemm1_bf16_kernel,
     wgrad1_bf16_kernel): ragged row tiles, 64- and 128-column tiles, statistics, the shortcut-gradient epilogue."""
