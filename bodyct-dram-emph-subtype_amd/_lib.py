@@ -41,6 +41,11 @@ class DramChunkRef(ctypes.Structure):
     _fields_ = [("tensor", ctypes.c_int32), ("pad", ctypes.c_int32), ("offset", ctypes.c_int64)]
 
 
+class DramPackRef(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("off_f", ctypes.c_int64), ("off_b", ctypes.c_int64), ("Cout", ctypes.c_int32),
+                ("Cin", ctypes.c_int32), ("taps", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+
 DP = ctypes.POINTER(DramConvDesc)
 
 # name -> (restype, argtypes); mirrors include/dram_hip.h one to one
@@ -121,6 +126,7 @@ SIGNATURES = {
     "dram_head_bwd_nparts": (I, [LL]),
     "dram_head_bwd": (I, [P, P, P, P, P, P, I, I, I, P, P, I, I, I, I, I, I, P]),
     # bf16 storage path (same argument lists as the fp32 namesakes; activation tensors are bf16)
+    "dram_pack_conv_weight_bf16_multi": (I, [P, P, I, P, D, P]),
     "dram_cast_f32_to_bf16": (I, [P, P, LL, P]),
     "dram_cast_bf16_to_f32": (I, [P, P, LL, P]),
     "dram_s2d_bf16": (I, [P, P, I, I, I, I, I, P]),

@@ -1321,6 +1321,29 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, bf16_t* __r
   }
 }
 
+// All bf16 weight packings of a step in ONE launch (a ResNet-50 step issued 54 launches of ~10 us): a device work list
+// as in adam_multi_kernel -- DramPackRef per weight (its packed copies at fixed offsets of one flat bf16 buffer),
+// DramChunkRef per block of DRAM_OPT_CHUNK output elements.
+__global__ __launch_bounds__(256) void pack_weight_bf16_multi_kernel(const DramPackRef* __restrict__ table,
+                                                                     const DramChunkRef* __restrict__ chunks,
+                                                                     bf16_t* __restrict__ flat) {
+  const DramChunkRef c = chunks[blockIdx.x];
+  const DramPackRef t = table[c.tensor];
+  const long n = (long)t.Cout * t.Cin * t.taps;
+  const long i1 = c.offset + DRAM_OPT_CHUNK < n ? c.offset + DRAM_OPT_CHUNK : n;
+  bf16_t* wf = t.off_f >= 0 ? flat + t.off_f : nullptr;
+  bf16_t* wb = t.off_b >= 0 ? flat + t.off_b : nullptr;
+  for (long i = c.offset + threadIdx.x; i < i1; i += 256) {
+    const int ci = (int)(i % t.Cin);
+    long r = i / t.Cin;
+    const int co = (int)(r % t.Cout);
+    const int tap = (int)(r / t.Cout);
+    const bf16_t v = f32_to_bf16(t.w[((long)co * t.Cin + ci) * t.taps + tap]);
+    if (wf) wf[i] = v;
+    if (wb) wb[((long)(t.taps - 1 - tap) * t.Cin + ci) * t.Cout + co] = v;
+  }
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n4, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
     st4<bf16_t>(dst, 4 * i, ld4<float>(src, 4 * i));
@@ -1648,6 +1671,16 @@ extern "C" int dram_pack_conv_weight_bf16(const float* w, void* wf, void* wb, in
   DramProf prof(DRAM_FAM_WEIGHT_PACK, 8, 0.0, (double)n * (4.0 + 2.0 * ((wf ? 1 : 0) + (wb ? 1 : 0))), (hipStream_t)stream);
   hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wf,
                      (bf16_t*)wb, Cout, Cin, taps);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_pack_conv_weight_bf16_multi(const DramPackRef* table, const DramChunkRef* chunks, int nchunks,
+                                                void* flat, double total_elems, dram_stream_t stream) {
+  if (!table || !chunks || !flat || nchunks < 1) return DRAM_ERR_BAD_ARG;
+  DramProf prof(DRAM_FAM_WEIGHT_PACK, 9, 0.0, total_elems * 8.0, (hipStream_t)stream);
+  hipLaunchKernelGGL(pack_weight_bf16_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, chunks,
+                     (bf16_t*)flat);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

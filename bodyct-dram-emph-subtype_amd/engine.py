@@ -406,13 +406,33 @@ class Engine:
         of the activations).  From the second step of an input shape on they all run on the engine's second
         stream at the start of forward, under the stem convolution, instead of in front of each layer."""
         plan = self._conv_lists.get(key)
-        if plan is None or not self._two_streams():
+        if plan is None:
+            return
+        # bf16 storage: every plain bf16 packing (3x3x3 stride 1, 1x1x1) in ONE launch -- also on a single stream and
+        # inside a hipGraph capture (54 launches of ~10 us per ResNet-50 step otherwise)
+        multi = [(wname, g) for wname, g in plan if st.storage == torch.bfloat16 and ops.conv_plan(g).bf16]
+        if not self._two_streams():
+            if multi:
+                packed = ops.pack_conv_weights_bf16_multi([st.P[wname] for wname, _ in multi])
+                if packed is not None:
+                    for (wname, g), (wf, wb) in zip(multi, packed):
+                        st.packed[wname] = (wf, wb, g)
             return
         side = ops.side_stream(key[-1])
         main = torch.cuda.current_stream()
         side.wait_stream(main)                         # the optimizer's update of the weights precedes the packing
         with ops.on_stream(side):
+            done = set()
+            if multi:
+                packed = ops.pack_conv_weights_bf16_multi([st.P[wname] for wname, _ in multi])
+                if packed is not None:
+                    packed[0][0].record_stream(main)   # (views of ONE flat buffer)
+                    for (wname, g), (wf, wb) in zip(multi, packed):
+                        st.packed[wname] = (wf, wb, g)
+                        done.add(wname)
             for wname, g in plan:
+                if wname in done:
+                    continue
                 wf, wb = ops.pack_conv_weight(st.P[wname], True, True, g, st.storage)
                 wf.record_stream(main)
                 wb.record_stream(main)
@@ -569,7 +589,11 @@ def forward_decisions(saved: dict) -> Dict[str, Tensor]:
     for c in units:
         if c["z"] is not None:
             out[c["bn"]] = mask(c["z"])
-        else:                               # activation recompute: z was not kept; same fma as bn_apply_kernel
+        else:
+            # z was not kept (activation recompute) or never written (its BatchNorm-apply ran as the consumer's
+            # prologue): re-derived with the kernel the engine itself uses -- the SAME fma, bit for bit (a torch
+            # expression may round the product before the add and flip a tie)
             sc, sh = c["ss"]
-            out[c["bn"]] = (torch.addcmul(sh, c["y"].float(), sc) > 0).permute(0, 4, 1, 2, 3).contiguous()
+            with ops.launch_scope(c["y"].device):
+                out[c["bn"]] = mask(ops.bn_apply(c["y"], sc, sh, None, 1, True))
     return out

@@ -14,7 +14,7 @@ import ctypes
 import os
 import threading
 from dataclasses import dataclass
-from typing import Dict, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -459,6 +459,52 @@ def pack_conv_weight(w: Tensor, want_fwd=True, want_bwd=True, g: Optional["ConvG
     else:
         _chk(_L().dram_pack_conv_weight(_p(w), _p(wf), _p(wb), Cout, Cin, taps, _stream()), "dram_pack_conv_weight")
     return wf, wb
+
+
+# All bf16 weight packings of a training step in ONE launch (dram_pack_conv_weight_bf16_multi): the device work list is
+# built once per set of weights (their addresses and shapes: parameters are updated in place) by an EAGER step and
+# reused, also inside hipGraph captures, where a host->device copy is not allowed.
+_PACK_TABLES: Dict[tuple, tuple] = {}
+
+
+def pack_conv_weights_bf16_multi(weights: List[Tensor]):
+    """[Cout,Cin,k,k,k] fp32 weights -> [(wf [taps,Cout,Cin], wb [taps,Cin,Cout])] bf16, views of one flat buffer
+    written by one kernel; None when no work list exists yet and the stream is capturing (the caller packs one by one)."""
+    import numpy as np
+    if not weights:
+        return []
+    key = tuple((w.data_ptr(), tuple(w.shape)) for w in weights)
+    ent = _PACK_TABLES.get(key)
+    if ent is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        tab = np.zeros(len(weights), dtype=np.dtype([("w", "<u8"), ("off_f", "<i8"), ("off_b", "<i8"), ("Cout", "<i4"),
+                                                     ("Cin", "<i4"), ("taps", "<i4"), ("pad", "<i4")]))
+        assert tab.dtype.itemsize == ctypes.sizeof(_lib.DramPackRef)
+        chunks, layout, off = [], [], 0
+        for i, w in enumerate(weights):
+            _req(w, "w")
+            Cout, Cin = w.shape[0], w.shape[1]
+            taps = w.shape[2] * w.shape[3] * w.shape[4]
+            n = Cout * Cin * taps
+            npad = (n + 63) // 64 * 64
+            tab[i] = (w.data_ptr(), off, off + npad, Cout, Cin, taps, 0)
+            layout.append((off, off + npad, n, taps, Cout, Cin))
+            off += 2 * npad
+            chunks.extend((i, 0, o) for o in range(0, n, _lib.OPT_CHUNK))
+        ch = np.array(chunks, dtype=np.dtype([("tensor", "<i4"), ("pad", "<i4"), ("offset", "<i8")]))
+        dev = weights[0].device
+        ent = (torch.from_numpy(tab.view(np.uint8).copy()).to(dev), torch.from_numpy(ch.view(np.uint8).copy()).to(dev),
+               len(chunks), off, layout)
+        while len(_PACK_TABLES) >= 8:
+            _PACK_TABLES.pop(next(iter(_PACK_TABLES)))
+        _PACK_TABLES[key] = ent
+    table, chunks, nchunks, total, layout = ent
+    flat = torch.empty((total,), device=weights[0].device, dtype=BF16)
+    _chk(_L().dram_pack_conv_weight_bf16_multi(_p(table), _p(chunks), nchunks, _p(flat), float(total // 2), _stream()),
+         "dram_pack_conv_weight_bf16_multi")
+    return [(flat[of:of + n].view(taps, Cout, Cin), flat[ob:ob + n].view(taps, Cin, Cout))
+            for of, ob, n, taps, Cout, Cin in layout]
 
 
 # Packed forward weights of inference calls (no_grad): repacking / re-transforming every weight on every

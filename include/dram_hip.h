@@ -434,6 +434,15 @@ typedef struct DramChunkRef {
   int64_t offset;
 } DramChunkRef;
 #define DRAM_OPT_CHUNK 16384
+/* Work list of dram_pack_conv_weight_bf16_multi: weight [Cout][Cin][taps] (fp32) -> its bf16 packed copies wf
+ * [taps][Cout][Cin] / wb [taps reversed][Cin][Cout] at ELEMENT offsets off_f / off_b of one flat bf16 buffer (-1: not
+ * wanted); chunks enumerate blocks of DRAM_OPT_CHUNK elements of wf's index space. */
+typedef struct DramPackRef {
+  const float* w;
+  int64_t off_f;
+  int64_t off_b;
+  int32_t Cout, Cin, taps, pad;
+} DramPackRef;
 int dram_adam_multi(const DramTensorRef* table, const DramChunkRef* chunks, int nchunks, float lr,
                     float beta1, float beta2, float eps, float weight_decay, float bias_corr1,
                     float bias_corr2, float grad_scale, dram_stream_t stream);
@@ -503,6 +512,8 @@ int dram_add(const float* a, const float* b, float* out, long long n, dram_strea
  * GRADIENT are fp32, statistic folds are double.  Arithmetic: products of bf16 operands accumulated in fp32
  * (v_mfma_f32_32x32x16_bf16), element-wise math in fp32, one rounding (to nearest even) on store.
  * The *_bf16 element-wise entry points take exactly the arguments of their fp32 namesakes. */
+int dram_pack_conv_weight_bf16_multi(const DramPackRef* table, const DramChunkRef* chunks, int nchunks, void* flat,
+                                     double total_elems, dram_stream_t stream);
 int dram_cast_f32_to_bf16(const float* src, void* dst, long long n, dram_stream_t stream);
 int dram_cast_bf16_to_f32(const void* src, float* dst, long long n, dram_stream_t stream);
 /* The stride-2 3x3x3 convolution (k 3, stride 2, pad 1, even extents, Cin % 8 == 0) as a stride-1 convolution of the
