@@ -157,6 +157,7 @@ SIGNATURES = {
     "dram_segloss_nblk": (I, [LL]),
     "dram_segloss_fwd": (I, [P, P, P, P, P, I, I, I, P, I, I, I, I, F, P]),
     "dram_segloss_bwd": (I, [P, P, P, P, P, I, I, I, P, P, P, I, I, I, I, F, P]),
+    "dram_regloss_tail": (I, [P, I, P, P, P, P, P, P, P, I, P, I, I, D, D, D, D, P, P, P, P]),
     "dram_upproject_nblk": (I, [LL]),
     "dram_upproject": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "dram_adam_multi": (I, [P, P, I, F, F, F, F, F, F, F, F, P]),

@@ -96,8 +96,20 @@ __global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __rest
   const bool live = ff.gamma ? (blockIdx.x * 32 + (t64 & 31) < C) : (col < RC);
   const int S = gridDim.y, sidx = blockIdx.y;
   double s = 0.0;
-  if (live)
-    for (int p = sidx + S * lane4; p < nparts; p += 16 * S) s += (double)partial[(long)p * RC + col];
+  if (live) {
+    // eight independent loads in flight per thread, added in the same fixed order as a plain loop (a loop with
+    // the add in it waits out one memory latency per row: up to 64 of them in a row at 1 024 parts)
+    const int step = 16 * S;
+    int p = sidx + S * lane4;
+    for (; p + 7 * step < nparts; p += 8 * step) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = partial[(long)(p + j * step) * RC + col];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (double)v[j];
+    }
+    for (; p < nparts; p += step) s += (double)partial[(long)p * RC + col];
+  }
   sm[threadIdx.x] = s;
   __syncthreads();
   double total = 0.0;
@@ -116,7 +128,16 @@ __global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __rest
     if (threadIdx.x == 0) g_fold_ticket[slot * FOLD_XMAX + blockIdx.x] = 0;    // free for the next launch / graph replay
     if (lane4 == 0 && live) {
       total = 0.0;
-      for (int k = 0; k < S; ++k)                    // written by other CUs: agent-scope loads, all in flight together
+      int k = 0;
+      for (; k + 8 <= S; k += 8) {                   // written by other CUs: agent-scope loads, eight in flight
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] = __hip_atomic_load(scratch + (long)(k + j) * RC + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) total += v[j];
+      }
+      for (; k < S; ++k)
         total += __hip_atomic_load(scratch + (long)k * RC + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

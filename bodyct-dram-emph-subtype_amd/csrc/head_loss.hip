@@ -262,6 +262,83 @@ __global__ void segloss_bwd_kernel(const float* __restrict__ cle, const float* _
   }
 }
 
+// ----------------------------------------------------------------------------- reg-loss tail
+// One block closes the whole train loss of models.py:549-574 from the seg-loss block sums: the fixed-order fp64
+// fold of partial[nblk][6], dice + class-balanced BCE (metrics.py:10-37), both interval losses (models.py:512-521,
+// band lookup of models.py:492-510 from the label), the total, and everything the backward needs (the four
+// seg-loss coefficients for d loss, the d loss / d reg_outs rows).  Replaces ~90 O(B) torch launches.
+struct RegTail {
+  const float* partial; int nblk;
+  const float* reg[2]; const long long* label[2]; const float* weight[2]; const float* bands[2]; int nband[2];
+  int B; double N, smooth, beta, gamma;
+  float* out;     // [5]  loss, loss_cle, loss_pse, mul, seg
+  float* coef;    // [8]  seg-loss backward coefficients of d loss (g_mul = 2, g_seg = 1)
+  float* greg;    // [2][B]
+};
+
+__global__ __launch_bounds__(256) void regloss_tail_kernel(RegTail a) {
+  __shared__ double red[256];
+  __shared__ double tot[8];
+  const int tid = threadIdx.x;
+  for (int k = 0; k < 6; ++k) {
+    double s = 0.0;
+    for (int r = tid; r < a.nblk; r += 256) s += (double)a.partial[(long)r * 6 + k];
+    red[tid] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (tid < w) red[tid] += red[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) tot[k] = red[0];
+    __syncthreads();
+  }
+  for (int h = 0; h < 2; ++h) {
+    double s = 0.0;
+    for (int i = tid; i < a.B; i += 256) {
+      const long long lab = a.label[h][i];
+      double l = nan(""), g = nan("");            // a label outside the band table poisons the loss
+      if (lab >= 0 && lab < a.nband[h]) {
+        const double o = (double)a.reg[h][i], w = (double)a.weight[h][i];
+        const double no = a.beta * pow(o, a.gamma);
+        const double nl = a.beta * pow((double)a.bands[h][2 * lab], a.gamma);
+        const double nh = a.beta * pow((double)a.bands[h][2 * lab + 1], a.gamma);
+        const double hw = 0.5 * (nh - nl), d = no - 0.5 * (nh + nl);
+        const double unh = d * d - hw * hw;
+        l = unh > 0.0 ? 10.0 * unh * w : 0.0;
+        g = unh > 0.0 ? 20.0 * w * d * a.beta * a.gamma * pow(o, a.gamma - 1.0) : 0.0;
+      }
+      a.greg[(long)h * a.B + i] = (float)g;
+      s += l;
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (tid < w) red[tid] += red[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) tot[6 + h] = red[0];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double st = tot[0], A1 = tot[1], A0 = tot[2], I = tot[3], S1 = tot[4], S2 = tot[5];
+    double alpha = 1.0 - st / (double)a.B;                      // metrics.py:18
+    alpha = alpha < 0.3 ? 0.3 : (alpha > 0.7 ? 0.7 : alpha);
+    const double sw = alpha * st + (1.0 - alpha) * (a.N - st);
+    const double seg = (alpha * A1 + (1.0 - alpha) * A0) / sw;
+    const double den = S1 + S2 + a.smooth;
+    const double mul = (2.0 * I + a.smooth) / den;
+    // float-rounded terms summed in float, as the reference's fp32 scalars are (models.py:572)
+    const float lc = (float)tot[6], lp = (float)tot[7], fm = (float)mul, fs = (float)seg;
+    a.out[0] = lc + lp + 2.0f * fm + fs;
+    a.out[1] = lc; a.out[2] = lp; a.out[3] = fm; a.out[4] = fs;
+    a.coef[0] = (float)(2.0 * 2.0 / den);
+    a.coef[1] = (float)(2.0 * (2.0 * I + a.smooth) / (den * den));
+    a.coef[2] = (float)(alpha / sw);
+    a.coef[3] = (float)((1.0 - alpha) / sw);
+    a.coef[4] = a.coef[5] = a.coef[6] = a.coef[7] = 0.f;
+  }
+}
+
 inline NearGeom make_near(int Dl, int Hl, int Wl, int D, int H, int W) {
   NearGeom n;
   n.Dl = Dl; n.Hl = Hl; n.Wl = Wl;
@@ -378,6 +455,28 @@ extern "C" int dram_segloss_bwd(const float* cle, const float* pse, const float*
   DramProf prof(DRAM_FAM_HEAD_LOSS, 3, 0.0, 4.0 * (double)total * 4.25, (hipStream_t)stream);
   hipLaunchKernelGGL(segloss_bwd_kernel, dim3(dram_segloss_nblk(total)), dim3(256), 0, (hipStream_t)stream, cle, pse,
                      lungs, ems, binary, make_near(Dl, Hl, Wl, D, H, W), coef, gcle, gpse, B, D, H, W, smoothness);
+  DRAM_LAUNCH_CHECK();
+  return DRAM_OK;
+}
+
+extern "C" int dram_regloss_tail(const float* partial, int nblk, const float* reg_cle, const float* reg_pse,
+                                 const long long* cle_labels, const long long* pse_labels, const float* cle_w,
+                                 const float* pse_w, const float* cle_bands, int n_cle, const float* pse_bands,
+                                 int n_pse, int B, double voxels_total, double smooth, double beta, double gamma,
+                                 float* out, float* coef, float* greg, dram_stream_t stream) {
+  if (!partial || nblk < 1 || !reg_cle || !reg_pse || !cle_labels || !pse_labels || !cle_w || !pse_w || !cle_bands ||
+      !pse_bands || n_cle < 1 || n_pse < 1 || B < 1 || !out || !coef || !greg)
+    return DRAM_ERR_BAD_ARG;
+  RegTail a;
+  a.partial = partial; a.nblk = nblk;
+  a.reg[0] = reg_cle; a.reg[1] = reg_pse;
+  a.label[0] = cle_labels; a.label[1] = pse_labels;
+  a.weight[0] = cle_w; a.weight[1] = pse_w;
+  a.bands[0] = cle_bands; a.bands[1] = pse_bands;
+  a.nband[0] = n_cle; a.nband[1] = n_pse;
+  a.B = B; a.N = voxels_total; a.smooth = smooth; a.beta = beta; a.gamma = gamma;
+  a.out = out; a.coef = coef; a.greg = greg;
+  hipLaunchKernelGGL(regloss_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

@@ -71,12 +71,16 @@ _CLE_BANDS, _PSE_BANDS = _band_table(CLE_RATIO_MAP), _band_table(PSE_RATIO_MAP)
 _BANDS_DEV: Dict[tuple, torch.Tensor] = {}
 
 
-def generate_regression_labels(cls_targets: torch.Tensor, which: str) -> torch.Tensor:
-    key = (which, cls_targets.device)
+def _bands(which: str, device) -> torch.Tensor:
+    key = (which, device)
     tab = _BANDS_DEV.get(key)
     if tab is None:      # one host->device copy per device (none per step: the step stays graph-capturable)
-        tab = _BANDS_DEV[key] = (_CLE_BANDS if which == "cle" else _PSE_BANDS).to(cls_targets.device)
-    return tab[cls_targets.long()]
+        tab = _BANDS_DEV[key] = (_CLE_BANDS if which == "cle" else _PSE_BANDS).to(device).contiguous()
+    return tab
+
+
+def generate_regression_labels(cls_targets: torch.Tensor, which: str) -> torch.Tensor:
+    return _bands(which, cls_targets.device)[cls_targets.long()]
 
 
 def interval_regression_loss(outs, reg_targets, weight_factors):
@@ -142,16 +146,47 @@ def segmentation_loss(dense_cle, dense_pse, ems, lungs, binary):
     return _SegLossFn.apply(c4, p4, l4, e4, binary.float().contiguous())
 
 
+class _RegLossFn(torch.autograd.Function):
+    """The whole train loss of ScanRegLightningModule.shared_step (models.py:549-574) as three launches: the seg-loss
+    pass over the dense maps, one O(B) tail kernel (fold, dice/BCE, both interval losses, the total, the backward's
+    coefficients), and -- in backward -- the seg-loss gradient pass.  The four components come back detached."""
+
+    @staticmethod
+    def forward(ctx, cle, pse, lungs, ems, reg_cle, reg_pse, cle_labels, pse_labels, cle_w, pse_w):
+        B, D, H, W = cle.shape
+        binary = torch.logical_or(cle_labels > 0, pse_labels > 0).float()            # models.py:566
+        part = ops.segloss_fwd(cle, pse, lungs, ems, binary, 0.85)                    # 0.85: models.py:529
+        out, coef, greg = ops.regloss_tail(part, reg_cle, reg_pse, cle_labels, pse_labels, cle_w, pse_w,
+                                           _bands("cle", cle.device), _bands("pse", cle.device), B * D * H * W,
+                                           1e-7, BETA, GAMMA)                         # 1e-7: BinaryDice, models.py:412
+        ctx.save_for_backward(cle, pse, lungs, ems, binary, coef, greg)
+        loss, lc, lp, mul, seg = out.unbind(0)
+        ctx.mark_non_differentiable(lc, lp, mul, seg)
+        return loss, lc, lp, mul, seg
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        cle, pse, lungs, ems, binary, coef, greg = ctx.saved_tensors
+        gcle, gpse = ops.segloss_bwd(cle, pse, lungs, ems, binary, coef * g, 0.85)
+        gr = greg * g
+        return gcle, gpse, None, None, gr[0], gr[1], None, None, None, None
+
+
 def reg_train_loss(dense_outs, reg_outs, lungs, ems, cle_labels, pse_labels, cle_w, pse_w):
-    """Train branch of ScanRegLightningModule.shared_step (models.py:549-574)."""
-    t0 = generate_regression_labels(cle_labels, "cle")
-    t1 = generate_regression_labels(pse_labels, "pse")
-    loss_cle = interval_regression_loss(reg_outs[0], t0, cle_w)
-    loss_pse = interval_regression_loss(reg_outs[1], t1, pse_w)
-    binary = torch.logical_or(cle_labels > 0, pse_labels > 0).float()
-    mul, seg = segmentation_loss(dense_outs[0], dense_outs[1], ems, lungs, binary)
-    loss = loss_cle + loss_pse + 2.0 * mul + seg
-    return loss, dict(loss_cle=loss_cle, loss_pse=loss_pse, mul_loss=mul, seg_loss=seg)
+    """Train branch of ScanRegLightningModule.shared_step (models.py:549-574): loss = interval(cle) + interval(pse)
+    + 2 dice + BCE.  Same terms as interval_regression_loss / segmentation_loss above, closed in one tail kernel."""
+    B = dense_outs[0].shape[0]
+
+    def vol(t):
+        return t.reshape(B, *t.shape[-3:]).float().contiguous()
+
+    def row(t, dtype=torch.float32):
+        return t.reshape(B).to(dtype).contiguous()
+
+    loss, lc, lp, mul, seg = _RegLossFn.apply(vol(dense_outs[0]), vol(dense_outs[1]), vol(lungs), vol(ems),
+                                              row(reg_outs[0]), row(reg_outs[1]), row(cle_labels, torch.int64),
+                                              row(pse_labels, torch.int64), row(cle_w), row(pse_w))
+    return loss, dict(loss_cle=lc, loss_pse=lp, mul_loss=mul, seg_loss=seg)
 
 
 def cls_train_loss(cls_outs, cle_labels, pse_labels, cle_cw, pse_cw):

@@ -1192,6 +1192,30 @@ def segloss_bwd(cle: Tensor, pse: Tensor, lungs: Tensor, ems: Tensor, binary: Te
     return gcle, gpse
 
 
+def regloss_tail(partial: Tensor, reg_cle: Tensor, reg_pse: Tensor, cle_labels: Tensor, pse_labels: Tensor,
+                 cle_w: Tensor, pse_w: Tensor, cle_bands: Tensor, pse_bands: Tensor, voxels_total: int,
+                 smooth: float, beta: float, gamma: float):
+    """The O(B) tail of models.py:549-574 in one launch (csrc/head_loss.hip regloss_tail_kernel) ->
+    out [5] (loss, loss_cle, loss_pse, mul, seg), coef [8] for segloss_bwd, greg [2,B] = d loss / d reg_outs."""
+    _req(partial, "partial")
+    B = reg_cle.shape[0]
+    for t, n in ((reg_cle, "reg_cle"), (reg_pse, "reg_pse"), (cle_w, "cle_w"), (pse_w, "pse_w")):
+        _req(t, n, shape=(B,))
+    for t, n in ((cle_labels, "cle_labels"), (pse_labels, "pse_labels")):
+        _req(t, n, dtype=torch.int64, shape=(B,))
+    _req(cle_bands, "cle_bands")
+    _req(pse_bands, "pse_bands")
+    dev = partial.device
+    out = torch.empty(5, device=dev, dtype=torch.float32)
+    coef = torch.empty(8, device=dev, dtype=torch.float32)
+    greg = torch.empty((2, B), device=dev, dtype=torch.float32)
+    _chk(_L().dram_regloss_tail(_p(partial), partial.shape[0], _p(reg_cle), _p(reg_pse), _p(cle_labels),
+                                _p(pse_labels), _p(cle_w), _p(pse_w), _p(cle_bands), cle_bands.shape[0],
+                                _p(pse_bands), pse_bands.shape[0], B, float(voxels_total), float(smooth), float(beta),
+                                float(gamma), _p(out), _p(coef), _p(greg), _stream()), "dram_regloss_tail")
+    return out, coef, greg
+
+
 # --------------------------------------------------------------------------- optimizer
 def adam_multi(table: Tensor, chunks: Tensor, nchunks: int, lr, b1, b2, eps, wd, bc1, bc2, grad_scale):
     _chk(_L().dram_adam_multi(_p(table), _p(chunks), nchunks, lr, b1, b2, eps, wd, bc1, bc2, grad_scale, _stream()),

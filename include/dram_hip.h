@@ -411,6 +411,17 @@ int dram_segloss_bwd(const float* cle, const float* pse, const float* lungs, con
                      const float* binary, int Dl, int Hl, int Wl, const float* coef, float* gcle,
                      float* gpse, int B, int D, int H, int W, float smoothness, dram_stream_t stream);
 
+/* The O(B) tail of the regression train loss (models.py:549-574) in ONE launch: the fp64 fold of the seg-loss
+ * block sums, dice + balanced BCE (metrics.py:10-37), the two interval losses (models.py:512-521) with the band
+ * of each label looked up in *_bands [n][2] (models.py:492-510), loss = cle + pse + 2 mul + seg.
+ *   out [5]: loss, loss_cle, loss_pse, mul_loss, seg_loss;  coef [8]: dram_segloss_bwd's input for d loss;
+ *   greg [2][B]: d loss / d reg_outs.  A label outside its band table makes the loss NaN. */
+int dram_regloss_tail(const float* partial, int nblk, const float* reg_cle, const float* reg_pse,
+                      const long long* cle_labels, const long long* pse_labels, const float* cle_w,
+                      const float* pse_w, const float* cle_bands, int n_cle, const float* pse_bands, int n_pse,
+                      int B, double voxels_total, double smooth, double beta, double gamma, float* out,
+                      float* coef, float* greg, dram_stream_t stream);
+
 /* Predict-time up-projection (models.py:438-441): out = trilinear(dense -> Do,Ho,Wo,
  * align_corners) * ess; partial [B][nblk] per-block sums of out. */
 int dram_upproject_nblk(long long voxels_per_sample);

@@ -715,6 +715,42 @@ def test_segloss(ops, B, binary):
     assert rel_l2(gp.cpu().reshape(pse.shape), pse.grad) < 1e-5
 
 
+def test_regression_train_loss_tail_in_one_launch(ops):
+    """models.reg_train_loss (seg-loss pass + ONE tail kernel) against the oracle's restatement of models.py:549-574:
+    every component, the total, d loss / d dense maps and d loss / d scores (fp64 autograd of the oracle), with
+    labels that cover the empty band of class 0; a label outside the band table must poison the loss."""
+    from bodyct_dram_emph_subtype_amd import models
+    B, D, H, W = 5, 4, 8, 6
+    gen = torch.Generator().manual_seed(11)
+    cle = torch.rand(B, 1, D, H, W, generator=gen) * 0.6
+    pse = torch.rand(B, 1, D, H, W, generator=gen) * 0.6
+    reg = [torch.rand(B, generator=gen) * 0.8 + 0.05 for _ in range(2)]
+    lungs = (torch.rand(B, 1, 2 * D, 2 * H, 2 * W, generator=gen) > 0.4).float()
+    ems = (torch.rand(B, 1, 2 * D, 2 * H, 2 * W, generator=gen) > 0.7).float() * lungs
+    cl, pl = torch.tensor([0, 5, 2, 0, 3]), torch.tensor([0, 2, 1, 1, 0])
+    cw, pw = torch.rand(B, generator=gen) + 0.1, torch.rand(B, generator=gen) + 0.1
+    leaf = [t.double().requires_grad_(True) for t in (cle, pse, reg[0], reg[1])]
+    l_ref, parts_ref = orc.reg_train_loss(leaf[:2], leaf[2:], lungs.double(), ems.double(), cl, pl, cw.double(), pw.double())
+    l_ref.backward()
+
+    dev = [t.to(DEV).requires_grad_(True) for t in (cle, pse, reg[0], reg[1])]
+    loss, parts = models.reg_train_loss(dev[:2], dev[2:], lungs.to(DEV), ems.to(DEV), cl.to(DEV), pl.to(DEV),
+                                        cw.to(DEV), pw.to(DEV))
+    assert abs(float(loss) - float(l_ref)) < 1e-5 * max(1.0, abs(float(l_ref)))
+    for k, v in parts_ref.items():
+        assert abs(float(parts[k]) - float(v)) < 1e-5 * max(1.0, abs(float(v))), k
+        assert not parts[k].requires_grad
+    (3.0 * loss).backward()                                   # an upstream factor reaches every gradient
+    ok = ((cle + pse).double() - 1.0).abs() > 1e-3            # off the clamp kink of models.py:527
+    for i in (0, 1):
+        assert rel_l2(dev[i].grad.cpu()[ok], 3.0 * leaf[i].grad[ok]) < 1e-5, i
+    for i in (2, 3):
+        assert rel_l2(dev[i].grad.cpu(), 3.0 * leaf[i].grad) < 1e-5, i
+    bad, _ = models.reg_train_loss(dev[:2], dev[2:], lungs.to(DEV), ems.to(DEV), torch.full((B,), 6).to(DEV),
+                                   pl.to(DEV), cw.to(DEV), pw.to(DEV))
+    assert torch.isnan(bad).item()
+
+
 def test_upproject(ops):
     B, D, H, W = 2, 4, 6, 5
     dense = torch.rand(B, 1, D, H, W, generator=torch.Generator().manual_seed(1))
