@@ -679,9 +679,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// Weight transform  U = G w G^T (3-D), one z point per workgroup (blockIdx.z; 9 + 36 live values).  The 64 x 64
-// layers have 4 096 (co, ci) pairs = 16 workgroups per direction: with all NI z points in one thread (216 stores each)
-// the launch took 42 us on 32 CUs, 13 times a step.
+// Weight transform  U = G w G^T (3-D), streamed over the z point (9 + 36 live values).
 //   blockIdx.y == 0: uf[xi][co][ci]               (forward B operand, K = ci contiguous)
 //   blockIdx.y == 1: ub[xi][ci][co], taps flipped  (data-gradient B operand, K = co contiguous)
 template <int NZ, int NY, int NX>
@@ -706,7 +704,6 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
   for (int a = 0; a < 27; ++a) (&gw[0][0][0])[a] = src[bwd ? 26 - a : a];
 #pragma unroll
   for (int a = 0; a < NI; ++a) {
-    if (a != (int)blockIdx.z) continue;      // one z point per workgroup (wave-uniform; `a` stays a compile-time constant)
     float r[3][3], p[3][NK], u[NJ][NK];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
@@ -2186,8 +2183,8 @@ extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, const
   if (!w || (!uf && !ub)) return DRAM_ERR_BAD_ARG;
   if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
   const long n = (long)d->Cout * d->Cin;
+  const dim3 grid((unsigned)((n + 255) / 256), 2);
   const WinoGeom gf = make_geom(d, 0), gb = make_geom(d, 1);      // uf: forward tiling, ub: data-gradient tiling
-  dim3 grid((unsigned)((n + 255) / 256), 2, (unsigned)(gf.nz + 2));
   const bool same = gf.nz == gb.nz && gf.ny == gb.ny && gf.nx == gb.nx;
   float *pf = uf, *pb = same ? ub : nullptr;
   DramProf prof(DRAM_FAM_WEIGHT_PACK, 1, 0.0,
@@ -2199,7 +2196,6 @@ extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, const
   if (!same && ub) {
     pf = nullptr;
     pb = ub;
-    grid.z = (unsigned)(gb.nz + 2);
     WINO_TILING_DISPATCH(gb, W_WT);
   }
 #undef W_WT
