@@ -127,6 +127,7 @@ SIGNATURES = {
     "dram_head_bwd": (I, [P, P, P, P, P, P, I, I, I, P, P, I, I, I, I, I, I, P]),
     # bf16 storage path (same argument lists as the fp32 namesakes; activation tensors are bf16)
     "dram_pack_conv_weight_bf16_multi": (I, [P, P, I, P, D, P]),
+    "dram_pack_conv_weight_bf16_tiles": (LL, [I, I, I]),
     "dram_cast_f32_to_bf16": (I, [P, P, LL, P]),
     "dram_cast_bf16_to_f32": (I, [P, P, LL, P]),
     "dram_s2d_bf16": (I, [P, P, I, I, I, I, I, P]),

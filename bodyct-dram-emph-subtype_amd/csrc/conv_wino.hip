@@ -679,7 +679,10 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// Weight transform  U = G w G^T (3-D), streamed over the z point (9 + 36 live values).
+// Weight transform  U = G w G^T (3-D), streamed over the z point (9 + 36 live values).  The launches that cost are
+// the 256- and 512-channel layers, bound by writing 216 / 27 x the weight tensor twice (226 MB per direction at
+// 512 x 512); one z point per workgroup (6x the workgroups for the 64 x 64 layers) re-reads w six times with 108-byte
+// lane strides and measured 42 -> 62 us per launch on average.
 //   blockIdx.y == 0: uf[xi][co][ci]               (forward B operand, K = ci contiguous)
 //   blockIdx.y == 1: ub[xi][ci][co], taps flipped  (data-gradient B operand, K = co contiguous)
 template <int NZ, int NY, int NX>

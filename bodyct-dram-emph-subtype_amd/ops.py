@@ -491,7 +491,9 @@ def pack_conv_weights_bf16_multi(weights: List[Tensor]):
             tab[i] = (w.data_ptr(), off, off + npad, Cout, Cin, taps, 0)
             layout.append((off, off + npad, n, taps, Cout, Cin))
             off += 2 * npad
-            chunks.extend((i, 0, o) for o in range(0, n, _lib.OPT_CHUNK))
+            ntiles = _L().dram_pack_conv_weight_bf16_tiles(Cout, Cin, taps)
+            _chk(min(ntiles, 0), "dram_pack_conv_weight_bf16_tiles")
+            chunks.extend((i, 0, t) for t in range(ntiles))
         ch = np.array(chunks, dtype=np.dtype([("tensor", "<i4"), ("pad", "<i4"), ("offset", "<i8")]))
         dev = weights[0].device
         ent = (torch.from_numpy(tab.view(np.uint8).copy()).to(dev), torch.from_numpy(ch.view(np.uint8).copy()).to(dev),

@@ -447,7 +447,7 @@ typedef struct DramChunkRef {
 #define DRAM_OPT_CHUNK 16384
 /* Work list of dram_pack_conv_weight_bf16_multi: weight [Cout][Cin][taps] (fp32) -> its bf16 packed copies wf
  * [taps][Cout][Cin] / wb [taps reversed][Cin][Cout] at ELEMENT offsets off_f / off_b of one flat bf16 buffer (-1: not
- * wanted); chunks enumerate blocks of DRAM_OPT_CHUNK elements of wf's index space. */
+ * wanted); chunks enumerate the tiles of each weight: offset = 0 .. dram_pack_conv_weight_bf16_tiles(...) - 1. */
 typedef struct DramPackRef {
   const float* w;
   int64_t off_f;
@@ -523,6 +523,7 @@ int dram_add(const float* a, const float* b, float* out, long long n, dram_strea
  * GRADIENT are fp32, statistic folds are double.  Arithmetic: products of bf16 operands accumulated in fp32
  * (v_mfma_f32_32x32x16_bf16), element-wise math in fp32, one rounding (to nearest even) on store.
  * The *_bf16 element-wise entry points take exactly the arguments of their fp32 namesakes. */
+long long dram_pack_conv_weight_bf16_tiles(int Cout, int Cin, int taps);
 int dram_pack_conv_weight_bf16_multi(const DramPackRef* table, const DramChunkRef* chunks, int nchunks, void* flat,
                                      double total_elems, dram_stream_t stream);
 int dram_cast_f32_to_bf16(const float* src, void* dst, long long n, dram_stream_t stream);

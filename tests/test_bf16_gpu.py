@@ -76,6 +76,32 @@ CASES = [
 VARIANTS = [("", ""), ("4", "tile"), ("8", "zwalk")]
 
 
+def test_bf16_weight_packing_tiles_and_work_list(ops):
+    """The LDS-turned packing (csrc/conv_bf16.hip pack_tile_bf16): full and ragged 32 x 32 tiles at 27 taps, the 864-wide
+    tiles of the 1x1x1 weights, an odd tap count; wf / wb are the round-to-nearest-even bf16 images of the permuted /
+    tap-flipped fp32 weight, and the one-launch work list writes exactly what the per-weight launches write."""
+    from bodyct_dram_emph_subtype_amd import _lib
+    shapes = [(64, 64, 3), (32, 96, 3), (40, 36, 3), (128, 1728, 1), (70, 33, 1), (8, 8, 2)]
+    ws = [(rnd(co, ci, k, k, k, seed=10 + i) * 0.3).to(DEV) for i, (co, ci, k) in enumerate(shapes)]
+    L = _lib.load()
+    singles = []
+    for w, (co, ci, k) in zip(ws, shapes):
+        taps = k ** 3
+        wf = torch.empty((taps, co, ci), device=DEV, dtype=BF)
+        wb = torch.empty((taps, ci, co), device=DEV, dtype=BF)
+        rc = L.dram_pack_conv_weight_bf16(w.data_ptr(), wf.data_ptr(), wb.data_ptr(), co, ci, taps,
+                                          torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        ref = w.reshape(co, ci, taps).to(BF)                      # RNE
+        assert torch.equal(wf, ref.permute(2, 0, 1)), (co, ci, k)
+        assert torch.equal(wb, ref.flip(2).permute(2, 1, 0)), (co, ci, k)
+        singles.append((wf, wb))
+    multi = ops.pack_conv_weights_bf16_multi(ws)
+    for (wf, wb), (mf, mb) in zip(singles, multi):
+        assert torch.equal(wf, mf) and torch.equal(wb, mb)
+    assert L.dram_pack_conv_weight_bf16_tiles(4, 4, 1000) < 0      # more taps than a tile holds: refused
+
+
 @pytest.mark.parametrize("nw,wg", VARIANTS, ids=["plan", "nw4-tile", "nw8-zwalk"])
 @pytest.mark.parametrize("case", CASES, ids=str)
 def test_conv3_bf16_fwd_dgrad_wgrad(ops, monkeypatch, case, nw, wg):
