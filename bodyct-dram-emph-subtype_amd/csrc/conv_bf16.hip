@@ -1343,9 +1343,19 @@ __device__ __forceinline__ void pack_tile_bf16(const float* __restrict__ w, bf16
   const int nco = Cout - co0 < PK_CO ? Cout - co0 : PK_CO;
   const int nci = Cin - ci0 < CI ? Cin - ci0 : CI;
   const int run = nci * taps;                                    // <= PK_RUN
-  for (int r = 0; r < nco; ++r) {
-    const float* src = w + ((long)(co0 + r) * Cin + ci0) * taps;
-    for (int e = threadIdx.x; e < run; e += 256) lds[r * PK_PITCH + e] = f32_to_bf16(src[e]);
+  if (nco == PK_CO && run == PK_RUN) {                            // full tile: one flat loop, eight loads in flight
+    const float* src = w + ((long)co0 * Cin + ci0) * taps;
+    const long row = (long)Cin * taps;
+#pragma unroll 8
+    for (int i = threadIdx.x; i < PK_CO * PK_RUN; i += 256) {
+      const int r = i / PK_RUN, e = i - r * PK_RUN;
+      lds[r * PK_PITCH + e] = f32_to_bf16(src[r * row + e]);
+    }
+  } else {
+    for (int r = 0; r < nco; ++r) {
+      const float* src = w + ((long)(co0 + r) * Cin + ci0) * taps;
+      for (int e = threadIdx.x; e < run; e += 256) lds[r * PK_PITCH + e] = f32_to_bf16(src[e]);
+    }
   }
   __syncthreads();
   if (nco == PK_CO && nci == CI && (taps == 27 || taps == 1)) {     // full tile of the two network tap counts:

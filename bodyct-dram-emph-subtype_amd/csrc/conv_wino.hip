@@ -2161,11 +2161,13 @@ extern "C" int dram_conv_wgrad_algo(const DramConvDesc* d) {
   }
   if (w2 && d->D >= 8 && vox >= 65536.0) {
     const double w2d = vox * 54.0 * K * N / W2D_WGRAD_RATE;     // direct-equivalent rate, measured
-    // same preference as the forward plan: the z-walking kernel keeps a layer unless the pipeline (which
-    // here would also have to transform x again: the fused forward kernel leaves no V) is estimated > 15 %
-    // faster (64->64 @ 2x64x128x128: measured 1.89 vs 2.51 ms)
-    const char* me = tune_env(d->D >= 64 ? "DRAM_W2D_MARGIN_BIG" : "DRAM_W2D_MARGIN");
-    const double margin = me ? atof(me) : (d->D >= 64 ? 1.0 : 1.15);      // as in dram_conv_algo
+    // No preference margin here (the forward plan keeps the z-walking kernel at D < 64 for its smaller rounding
+    // error, which a weight gradient does not hand on to any other layer): the cheaper estimate wins, the pipeline's
+    // including the transform of x that the fused forward kernel did not leave behind.  64->64 @ 2x32x64x64: kernel
+    // times are level (0.24 vs 0.26 ms), but on the second stream the pipeline's HBM-bound transforms overlap the
+    // matrix-bound data-gradient chain where the z-walking kernel competes with it: config 1 40.95 -> 40.14 ms.
+    const char* mw = tune_env("DRAM_WGRAD_MARGIN");                        // A/B
+    const double margin = mw ? atof(mw) : 1.0;
     if (w2d < 0.92 * direct && w2d < margin * best) { best = w2d; pick = 2; }
   }
   return pick;

@@ -337,7 +337,8 @@ def _workspace(nbytes: int, device) -> Tensor:
 
 # environment switches the library's plan functions read (tests flip them between cases): part of the plan-cache key
 _PLAN_ENV = ("DRAM_CONV_ALGO", "DRAM_WINO_TILING", "DRAM_MATH", "DRAM_W2D_V", "DRAM_IGEMM_V", "DRAM_IGEMM_V3_FORCE",
-             "DRAM_WGRAD_V", "DRAM_BF16_NW", "DRAM_BF16_WGRAD", "DRAM_W2D_MARGIN", "DRAM_W2D_MARGIN_BIG", "DRAM_NN_STREAM")
+             "DRAM_WGRAD_V", "DRAM_BF16_NW", "DRAM_BF16_WGRAD", "DRAM_W2D_MARGIN", "DRAM_W2D_MARGIN_BIG", "DRAM_NN_STREAM",
+             "DRAM_WGRAD_MARGIN")
 
 
 class ConvPlan:

@@ -55,7 +55,8 @@ def test_conv_plan_is_host_side_and_consistent(monkeypatch):
              (desc(1, 16, 32, 32, 128, 128), 1, 1, 144),           # ... batch 1: 256 of them -> the 4x4x2 tiling
              (desc(2, 64, 128, 128, 128, 64), 1, None, 216),       # decoder, wide input
              (desc(2, 64, 128, 128, 64, 64), 1, 1, 216),           # last decoder stage, narrow: the pipeline since round 4
-             (desc(2, 32, 64, 64, 64, 64), 2, 2, None),            # layer1: fused in-plane kernels (F(2x2): 10x less rounding)
+             (desc(2, 32, 64, 64, 64, 64), 2, 1, None),            # layer1: fused in-plane kernel forward (F(2x2): 10x less
+                                                                   # rounding); its weight gradient hands no error on: pipeline
              (desc(2, 64, 128, 128, 64, 32), 2, 2, None),          # us3: 32 output channels -> fused in-plane kernels
              (desc(2, 32, 64, 64, 64, 128, s=2), 0, 0, None),      # strided: direct
              (desc(2, 16, 32, 32, 512, 2048, k=1), 3, 3, None),    # 1x1x1 on a 256-multiple of voxels: plain GEMM
