@@ -14,6 +14,8 @@ os.makedirs(dst, exist_ok=True)
 # kernel name fragment -> family, the library's own taxonomy (include/dram_hip.h DRAM_FAM_*, the names in
 # bench.py's roofline.families); first match wins
 FAMILIES = [("conv3_bf16", "conv_bf16"), ("gemm1_bf16", "conv_bf16"), ("wgrad3", "wgrad_bf16"), ("wgrad1_bf16", "wgrad_bf16"),
+            ("wgrad1b_bf16", "wgrad_bf16"), ("s2d_bf16", "pool_up"), ("d2s_bf16", "pool_up"), ("s2_embed", "weight_pack"),
+            ("s2_extract", "weight_pack"), ("regloss", "head_loss"),
             ("cast_", "bn_elementwise"), ("conv_wino2d", "conv_wino2d"), ("wino_in", "wino_in"), ("wino_out_kernel", "wino_out"),
             ("wino_gemm_nn", "wino_gemm_nn"), ("wino_gemm_tn", "wino_gemm_tn"), ("wino_wgrad_out", "wino_wgrad_out"),
             ("slab_sum", "wino_wgrad_out"), ("wino_weight", "weight_pack"), ("wino2d_weight", "weight_pack"),
