@@ -312,6 +312,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ONE JSON line on stdout, nothing else: RCCL prints a five-line version banner on rank 0's stdout when its
+    # first communicator comes up, and nothing stops another native library from doing the like.  From here on file
+    # descriptor 1 is stderr for everything in this process; the result goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
                          f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`")
@@ -438,6 +444,7 @@ def main():
     for i in range(args.steps):
         loss = step()
         marks[i + 1].record()
+    host_issue_s = time.perf_counter() - t0        # the host has ISSUED the K steps (the GPU is still running them)
     barrier()
     dt = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
@@ -510,6 +517,8 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(args.graph),
                        "streams": 1 if (args.detail or args.graph or ops.tuning_env("DRAM_WGRAD_STREAM", "1") == "0") else 2,
                        "train_gflop_per_volume": gflop_per_vol},
+            # host time to issue a step; close to ms_per_step = the step is launch-bound (the GPU waits for the host)
+            "host_issue_ms_per_step": host_issue_s / args.steps * 1e3,
             "loss": float(loss.detach()),
             "peak_hbm_gb": torch.cuda.max_memory_allocated(device) / 1e9,
         }
@@ -571,7 +580,8 @@ def main():
             }
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 

@@ -23,16 +23,22 @@ assert _TABLE_DT.itemsize == ctypes.sizeof(_lib.DramTensorRef)
 assert _CHUNK_DT.itemsize == ctypes.sizeof(_lib.DramChunkRef)
 
 
+def build_chunks(sizes, chunk: int = _lib.OPT_CHUNK):
+    """One DramChunkRef per `chunk` elements of every tensor (depends on the tensor SIZES only)."""
+    parts = []
+    for i, n in enumerate(sizes):
+        c = np.zeros((n + chunk - 1) // chunk, dtype=_CHUNK_DT)
+        c["tensor"] = i
+        c["offset"] = np.arange(0, n, chunk, dtype=np.int64)
+        parts.append(c)
+    return np.concatenate(parts) if parts else np.zeros(0, dtype=_CHUNK_DT)
+
+
 def build_tables(ptrs: List[tuple], chunk: int = _lib.OPT_CHUNK):
     """Host-side layout of the kernel's work list: one DramTensorRef per tensor and one
     DramChunkRef per `chunk` elements.  ptrs: [(p, g, m, v, n), ...] as integers."""
-    table = np.zeros(len(ptrs), dtype=_TABLE_DT)
-    chunks = []
-    for i, (p, g, m, v, n) in enumerate(ptrs):
-        table[i] = (p, g, m, v, n)
-        for off in range(0, n, chunk):
-            chunks.append((i, 0, off))
-    return table, np.array(chunks, dtype=_CHUNK_DT)
+    table = np.array(ptrs, dtype=_TABLE_DT) if ptrs else np.zeros(0, dtype=_TABLE_DT)
+    return table, build_chunks([t[4] for t in ptrs], chunk)
 
 
 class _FusedBase(torch.optim.Optimizer):
@@ -40,6 +46,9 @@ class _FusedBase(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._cache_key = None
         self._cache = None
+        self._chunk_cache = None      # (sizes, device) -> (device chunk list, count): independent of the pointers
+        self._ring = [None, None]     # pinned staging buffers of the pointer table (+ the event after their last copy)
+        self._ring_i = 0
         self._pinned_spare = None     # pinned staging pair for the next graph capture (capturable mode)
         self._pinned_owned = []       # pairs captured graphs read on every replay: never written again
         self.grad_scale = 1.0   # DDP folds the 1/world_size of the gradient mean in here
@@ -66,7 +75,25 @@ class _FusedBase(torch.optim.Optimizer):
                 c.copy_(sp[1], non_blocking=True)
                 self._pinned_owned.append(sp)
             else:
-                t, c = ht.to(device), hc.to(device)        # synchronous w.r.t. the host buffers
+                # Gradients are fresh tensors every step (zero_grad(set_to_none=True)), so the POINTER table changes
+                # every step.  A pageable host->device copy blocks the host until the stream has drained -- the host then
+                # starts issuing the next step on an idle GPU, every step -- so the table goes through a pinned ring,
+                # asynchronously; the chunk list depends on the sizes only and is uploaded once.
+                ck = (tuple(int(n) for n in table["n"]), str(device))
+                if self._chunk_cache is None or self._chunk_cache[0] != ck:
+                    self._chunk_cache = (ck, hc.to(device), len(chunks))
+                c = self._chunk_cache[1]
+                slot = self._ring_i = (self._ring_i + 1) % len(self._ring)
+                ent = self._ring[slot]
+                if ent is None or ent[0].numel() != ht.numel():
+                    ent = self._ring[slot] = [torch.empty_like(ht).pin_memory(), None]
+                if ent[1] is not None:
+                    ent[1].synchronize()                   # its previous copy (two steps ago) has long finished
+                ent[0].copy_(ht)
+                t = torch.empty(ht.shape, dtype=ht.dtype, device=device)
+                t.copy_(ent[0], non_blocking=True)
+                ent[1] = torch.cuda.Event()
+                ent[1].record()
                 if getattr(self, "capturable", False) and self._pinned_spare is None:
                     self._pinned_spare = (torch.empty_like(ht).pin_memory(), torch.empty_like(hc).pin_memory())
             self._cache_key, self._cache = key, (t, c, len(chunks))

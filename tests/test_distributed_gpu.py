@@ -247,8 +247,8 @@ def test_bench_gpus2_self_launches_its_ranks():
             proc.kill()
             proc.communicate()
     assert proc.returncode == 0, err[-3000:]
-    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out
+    lines = out.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out      # ONE JSON line and nothing else on stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["value"] > 0
     assert rec["collectives_per_step"]["bn_allreduce"] == 2 * 38          # ResNet-34: 38 BN layers, both directions
