@@ -64,6 +64,7 @@ class Engine:
         self.kind, self.layers = ARCHS[net]
         self.e = EXPANSION[self.kind]
         self._conv_lists: Dict[tuple, list] = {}     # input shape -> [(weight name, geometry)] of a forward
+        self._inflight: List[torch.cuda.Event] = []  # end-of-backward events of the steps the host has issued
 
     # ------------------------------------------------------------------ BN helpers
     def _bn_fwd(self, st: _State, y: Tensor, sp: Optional[Tensor], bnp: str, residual, rs, relu=True, pool=False,
@@ -383,11 +384,32 @@ class Engine:
         if storage not in (torch.float32, torch.bfloat16):
             raise NotImplementedError(f"activation storage type {storage}")
         with ops.launch_scope(x.device):
+            if need_grad:
+                self._throttle()
             return self._forward(P, x, lungs, training, need_grad, dist, recompute, storage)
 
     def backward(self, saved: dict, g_dense: List[Optional[Tensor]], g_outs: List[Optional[Tensor]]):
         with ops.launch_scope(saved["dense"].device):
-            return self._backward(saved, g_dense, g_outs)
+            out = self._backward(saved, g_dense, g_outs)
+            if not torch.cuda.is_current_stream_capturing():
+                ev = torch.cuda.Event()
+                ev.record()
+                self._inflight.append(ev)
+            return out
+
+    def _throttle(self):
+        """The host issues an eager step in a quarter of the time the GPU needs for it.  Left alone (no .item() in the
+        training loop) it runs many steps ahead, and every tensor that crossed to the second stream (record_stream)
+        stays unavailable to the caching allocator until the GPU has caught up: the pool grows step after step and the
+        hipMalloc / hipFree traffic made config 1 swing between 39 and 69 ms per step.  So: at most ONE step issued
+        ahead of the one the GPU is executing -- the forward of step k + 1 waits (on the host) for the backward of step
+        k - 1.  The GPU never idles for it; DRAM_INFLIGHT (DRAM_TUNING=1) changes the depth, 0 = as if the loop read
+        the loss every step."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        depth = int(ops.tuning_env("DRAM_INFLIGHT", "1"))
+        while len(self._inflight) > depth:
+            self._inflight.pop(0).synchronize()
 
     @staticmethod
     def _two_streams() -> bool:

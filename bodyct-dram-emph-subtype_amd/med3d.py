@@ -107,7 +107,7 @@ class _Med3DFunction(torch.autograd.Function):
 
         grads = module._engine.backward(saved, [c(gd0), c(gd1)], [c(go0), c(go1)])
         out = [None, None, None]
-        for name, p in module.named_parameters():
+        for name, p in module._named_tensors()[0]:
             out.append(grads.get(name) if p.requires_grad else None)
         return tuple(out)
 
@@ -176,9 +176,28 @@ class _ResNetSeg(nn.Module):
             return torch.bfloat16
         return self.storage_dtype
 
+    def _named_tensors(self):
+        """(named_parameters(), named_buffers()) as lists, in nn.Module's own order, without nn.Module's recursive
+        generators: three such traversals per step were 1.5 ms of a ResNet-50 step's 15 ms of host time.  The list of
+        submodules is taken once (the constructor builds all of them); parameters and buffers are read from the
+        submodules' own dicts every time, so `.to()` / `load_state_dict` / a replaced tensor are always seen."""
+        mods = self.__dict__.get("_submodules")
+        if mods is None:
+            mods = self.__dict__["_submodules"] = [((pre + ".") if pre else "", m) for pre, m in self.named_modules()]
+        params, bufs = [], []
+        for pre, m in mods:
+            for k, p in m._parameters.items():
+                if p is not None:
+                    params.append((pre + k, p))
+            for k, b in m._buffers.items():
+                if b is not None:
+                    bufs.append((pre + k, b))
+        return params, bufs
+
     def _tensor_dict(self):
-        d = dict(self.named_parameters())
-        d.update(dict(self.named_buffers()))
+        params, bufs = self._named_tensors()
+        d = dict(params)
+        d.update(bufs)
         return d
 
     def forward(self, x: torch.Tensor, lungs: Optional[torch.Tensor] = None):
@@ -193,7 +212,7 @@ class _ResNetSeg(nn.Module):
         x = x.contiguous().float()
         if lungs is not None:
             lungs = lungs.contiguous().float()
-        params = [p for _, p in self.named_parameters()]
+        params = [p for _, p in self._named_tensors()[0]]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         if need_grad:
             d0, d1, o0, o1 = _Med3DFunction.apply(self, x, lungs, *params)

@@ -382,7 +382,9 @@ _PLANS: Dict[tuple, ConvPlan] = {}
 
 def conv_plan(g: "ConvGeom") -> ConvPlan:
     env = os.environ
-    key = (g,) + tuple(env.get(k) for k in _PLAN_ENV)
+    # the library reads the A/B switches under DRAM_TUNING=1 only (csrc/common.h tune_env): without it the plan depends
+    # on the geometry alone (13 environment look-ups per call were 1.2 ms of a ResNet-50 step's host time)
+    key = (g,) + tuple(env.get(k) for k in _PLAN_ENV) if env.get("DRAM_TUNING") == "1" else g
     p = _PLANS.get(key)
     if p is None:
         p = _PLANS[key] = ConvPlan(g)

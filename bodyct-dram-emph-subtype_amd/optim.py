@@ -47,8 +47,6 @@ class _FusedBase(torch.optim.Optimizer):
         self._cache_key = None
         self._cache = None
         self._chunk_cache = None      # (sizes, device) -> (device chunk list, count): independent of the pointers
-        self._ring = [None, None]     # pinned staging buffers of the pointer table (+ the event after their last copy)
-        self._ring_i = 0
         self._pinned_spare = None     # pinned staging pair for the next graph capture (capturable mode)
         self._pinned_owned = []       # pairs captured graphs read on every replay: never written again
         self.grad_scale = 1.0   # DDP folds the 1/world_size of the gradient mean in here
@@ -77,23 +75,17 @@ class _FusedBase(torch.optim.Optimizer):
             else:
                 # Gradients are fresh tensors every step (zero_grad(set_to_none=True)), so the POINTER table changes
                 # every step.  A pageable host->device copy blocks the host until the stream has drained -- the host then
-                # starts issuing the next step on an idle GPU, every step -- so the table goes through a pinned ring,
+                # starts issuing the next step on an idle GPU, every step -- so the table goes through pinned memory,
                 # asynchronously; the chunk list depends on the sizes only and is uploaded once.
                 ck = (tuple(int(n) for n in table["n"]), str(device))
                 if self._chunk_cache is None or self._chunk_cache[0] != ck:
                     self._chunk_cache = (ck, hc.to(device), len(chunks))
                 c = self._chunk_cache[1]
-                slot = self._ring_i = (self._ring_i + 1) % len(self._ring)
-                ent = self._ring[slot]
-                if ent is None or ent[0].numel() != ht.numel():
-                    ent = self._ring[slot] = [torch.empty_like(ht).pin_memory(), None]
-                if ent[1] is not None:
-                    ent[1].synchronize()                   # its previous copy (two steps ago) has long finished
-                ent[0].copy_(ht)
+                # (a fresh pinned block per step from torch's caching host allocator, which hands a block out again
+                # only after the copy that read it has executed: the host runs several steps ahead of the GPU, a ring
+                # of two staging buffers with an event wait measured 13 ms of host stall per step)
                 t = torch.empty(ht.shape, dtype=ht.dtype, device=device)
-                t.copy_(ent[0], non_blocking=True)
-                ent[1] = torch.cuda.Event()
-                ent[1].record()
+                t.copy_(ht.pin_memory(), non_blocking=True)
                 if getattr(self, "capturable", False) and self._pinned_spare is None:
                     self._pinned_spare = (torch.empty_like(ht).pin_memory(), torch.empty_like(hc).pin_memory())
             self._cache_key, self._cache = key, (t, c, len(chunks))

@@ -132,6 +132,14 @@ def test_factories_conf_and_state_dict_contract():
     r50 = utils.get_model_by_name("med3d50")
     assert tuple(r50.state_dict()["us1.conv_blocks.0.0.weight"].shape) == (64, 2304, 3, 3, 3)
     assert tuple(r50.fcs[0].weight.shape) == (6, 32, 1, 1, 1)
+    # the engine's own (cheap) traversal hands out exactly nn.Module's named_parameters() / named_buffers(), also
+    # after a conversion replaced the buffers and in a deep copy
+    import copy
+    for mod in (r50, r50.double(), copy.deepcopy(r50)):
+        params, bufs = mod._named_tensors()
+        ref_p, ref_b = list(mod.named_parameters()), list(mod.named_buffers())
+        assert [k for k, _ in params] == [k for k, _ in ref_p] and all(a is b for (_, a), (_, b) in zip(params, ref_p))
+        assert [k for k, _ in bufs] == [k for k, _ in ref_b] and all(a is b for (_, a), (_, b) in zip(bufs, ref_b))
     with pytest.raises(NotImplementedError):
         med3d.ResNetSegReg(med3d.BasicBlock, [2, 2, 2, 2], shortcut_type="B")
     with pytest.raises(FileNotFoundError):
