@@ -439,12 +439,15 @@ def main():
     # per-step hipEvent marks on the stream the step is launched on (median of the per-step
     # intervals); `value` stays the wall clock over exactly K steps between two barriers (driver contract)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    wait0 = module._engine.throttle_wait_s
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
         loss = step()
         marks[i + 1].record()
-    host_issue_s = time.perf_counter() - t0        # the host has ISSUED the K steps (the GPU is still running them)
+    # the host has ISSUED the K steps (the GPU is still running them); minus the time the engine made it wait so as
+    # not to run more than one step ahead (engine._throttle) = the time the host was busy issuing
+    host_issue_s = time.perf_counter() - t0 - (module._engine.throttle_wait_s - wait0)
     barrier()
     dt = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
@@ -517,7 +520,7 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(args.graph),
                        "streams": 1 if (args.detail or args.graph or ops.tuning_env("DRAM_WGRAD_STREAM", "1") == "0") else 2,
                        "train_gflop_per_volume": gflop_per_vol},
-            # host time to issue a step; close to ms_per_step = the step is launch-bound (the GPU waits for the host)
+            # host time to issue a step (waits for the GPU excluded); close to ms_per_step = the step is launch-bound
             "host_issue_ms_per_step": host_issue_s / args.steps * 1e3,
             "loss": float(loss.detach()),
             "peak_hbm_gb": torch.cuda.max_memory_allocated(device) / 1e9,

@@ -14,6 +14,7 @@ Fusion boundaries
 from __future__ import annotations
 
 import os
+import time
 from typing import Dict, List, Optional
 
 import torch
@@ -65,6 +66,7 @@ class Engine:
         self.e = EXPANSION[self.kind]
         self._conv_lists: Dict[tuple, list] = {}     # input shape -> [(weight name, geometry)] of a forward
         self._inflight: List[torch.cuda.Event] = []  # end-of-backward events of the steps the host has issued
+        self.throttle_wait_s = 0.0                   # host time spent waiting in _throttle (bench.py reports it)
 
     # ------------------------------------------------------------------ BN helpers
     def _bn_fwd(self, st: _State, y: Tensor, sp: Optional[Tensor], bnp: str, residual, rs, relu=True, pool=False,
@@ -408,8 +410,11 @@ class Engine:
         if torch.cuda.is_current_stream_capturing():
             return
         depth = int(ops.tuning_env("DRAM_INFLIGHT", "1"))
-        while len(self._inflight) > depth:
-            self._inflight.pop(0).synchronize()
+        if len(self._inflight) > depth:
+            t0 = time.perf_counter()
+            while len(self._inflight) > depth:
+                self._inflight.pop(0).synchronize()
+            self.throttle_wait_s += time.perf_counter() - t0
 
     @staticmethod
     def _two_streams() -> bool:
