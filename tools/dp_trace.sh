@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel trace of the data-parallel step with its collectives in place at world size 1
-R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r4; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/dp; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/trace_fd
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_fd -- python3 $R/bench.py --config 1 --force-dist --steps 4 --warmup 2 --no-cpu-baseline --timeline off > $O/prof_fd.json 2>/dev/null
