@@ -421,9 +421,11 @@ class Engine:
         """Weight-gradient kernels and the per-step weight packing on the engine's second stream?  Eager steps: yes.
         While the step is being captured into a hipGraph: no -- the two-branch schedule CAN be captured (the side stream
         forks from the capturing stream by wait_stream / event and rejoins it before the step ends;
-        DRAM_GRAPH_STREAMS=2 under DRAM_TUNING=1), but measured it buys nothing once the launch gaps are gone: config 1
+        DRAM_GRAPH_STREAMS=2 under DRAM_TUNING=1), but measured it buys little once the launch gaps are gone: config 1
         42.91 / 42.92 ms, config 3 fp32 41.45 / 41.83, config 2 bf16 17.47 / 18.07, config 3 bf16 17.94 / 18.83 (one /
-        two branches) -- what the second stream wins in the eager step is launch latency, not kernel overlap."""
+        two branches) mid-round 4; 40.28 / 39.82 ms (config 1), 39.65 / 39.40 (config 3 fp32) once layer1's weight
+        gradients ran the HBM-bound pipeline, which does overlap the matrix-bound data-gradient chain -- against 5.6 GB
+        more for the graph's pool and an eager two-stream step that is as fast (39.2 ms)."""
         if ops.tuning_env("DRAM_WGRAD_STREAM", "1") == "0":
             return False
         return not (torch.cuda.is_current_stream_capturing() and ops.tuning_env("DRAM_GRAPH_STREAMS", "1") != "2")
