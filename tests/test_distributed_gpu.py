@@ -254,6 +254,25 @@ def test_bench_gpus2_self_launches_its_ranks():
     assert rec["collectives_per_step"]["bn_allreduce"] == 2 * 38          # ResNet-34: 38 BN layers, both directions
 
 
+def test_bench_line_is_alone_on_stdout_with_rccl_up():
+    """`python bench.py --force-dist` (RCCL communicators at world size 1): RCCL prints a version banner on rank 0's
+    stdout when its first communicator comes up; the bench line must still be the ONE line of stdout (the driver parses
+    it), and it carries the data-parallel fields and the host issue time."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MASTER_PORT"] = "29577"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "0", "--steps", "2", "--warmup", "1", "--force-dist",
+           "--no-cpu-baseline", "--timeline", "off"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["host_issue_ms_per_step"] > 0
+    assert rec["collectives_per_step"]["bn_allreduce"] == 2 * 38 and rec["exposed_collective_ms"] >= 0
+
+
 def test_two_rank_bf16_storage_matches_ddp_syncbn_emulation():
     """The data-parallel path on bf16 activations (BASELINE configs[3] / [4] ask for bf16 + DDP): two ranks (1 + 2 volumes,
     gloo on device tensors) against the fp64 DDP + SyncBN emulation on the ranks' own decisions.  SyncBN statistics and
