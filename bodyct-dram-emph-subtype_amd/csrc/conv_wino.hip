@@ -1772,7 +1772,10 @@ bool plan_tn(const DramConvDesc* d, const WinoGeom& g, TnPlan& p) {
   const int base = g.npts * p.m_tiles * p.n_tiles;
   const int k32 = g.Tpad / 32;
   int ns = 1;
-  while (base * ns < 512 && ns * 2 <= k32 / 4 && ns < (g.npts == 1 ? 64 : 16)) ns *= 2;
+  // (1x1x1, one point: a 64 x 256 weight gradient over 131 072 voxels is ONE output tile -- 64 splits left three
+  // quarters of the chip idle, 168 MB in 147 us; up to 256 splits of >= 256 rows, one round of workgroups: a second
+  // round's worth of splits only added slab traffic to the matrix-bound 256 <-> 1024 shapes)
+  while (base * ns < (g.npts == 1 ? 256 : 512) && ns * 2 <= k32 / 4 && ns < (g.npts == 1 ? 256 : 16)) ns *= 2;
   p.nsplit = ns;
   p.kper = ((k32 + ns - 1) / ns) * 32;
   return true;
@@ -1955,18 +1958,32 @@ WinoGeom c1_geom(const DramConvDesc* d) {
   g.T = g.Tpad = d->B * d->D * d->H * d->W;
   return g;
 }
-__global__ void slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, const long n, const int nsplit) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float p[4];                         // four interleaved partial sums (loads in flight), fixed combination order
+// dw = sum of the split-K slabs.  64 results x 4 slab groups per workgroup: a thread sums its group's slabs (k = kg,
+// kg + 4, ...) in eight interleaved partial sums (eight loads in flight), the four groups meet through LDS in a fixed
+// order -- with up to 256 slabs (the 1x1x1 weight gradients of ResNet-50's 32x64x64 stages) one thread per result and
+// four loads in flight was a chain of 64 memory latencies.
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, const long n,
+                                                       const int nsplit) {
+  __shared__ float part[4][64];
+  const int r = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  for (long i0 = blockIdx.x * 64L; i0 < n; i0 += (long)gridDim.x * 64L) {      // (uniform: every thread reaches the barriers)
+    const long i = i0 + r;
+    const bool live = i < n;
+    float p[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p[j] = 0.f;
-    int k = 0;
-    for (; k + 4 <= nsplit; k += 4) {
+    for (int j = 0; j < 8; ++j) p[j] = 0.f;
+    if (live) {
+      int k = kg;
+      for (; k + 28 < nsplit; k += 32) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) p[j] += slab[(long)(k + j) * n + i];
+        for (int j = 0; j < 8; ++j) p[j] += slab[(long)(k + 4 * j) * n + i];
+      }
+      for (int j = 0; k < nsplit; k += 4, ++j) p[j] += slab[(long)k * n + i];
     }
-    for (int j = 0; k < nsplit; ++k, ++j) p[j] += slab[(long)k * n + i];
-    out[i] = (p[0] + p[1]) + (p[2] + p[3]);
+    part[kg][r] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    __syncthreads();
+    if (kg == 0 && live) out[i] = (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
+    __syncthreads();
   }
 }
 }  // namespace
@@ -2033,7 +2050,7 @@ extern "C" int dram_conv1x1_bwd_weight(const float* x, const float* dy, float* d
   }
   if (p.nsplit > 1) {
     const long n = (long)d->Cout * d->Cin;
-    const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    const int grid = (int)((n + 63) / 64 > 4096 ? 4096 : (n + 63) / 64);
     DramProf prof(DRAM_FAM_WINO_WGRAD_OUT, 0, 0.0, 4.0 * (double)n * (p.nsplit + 1), s);
     hipLaunchKernelGGL(slab_sum_kernel, dim3(grid), dim3(256), 0, s, slab, dw, n, p.nsplit);
     DRAM_LAUNCH_CHECK();
