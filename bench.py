@@ -179,9 +179,10 @@ def host_cpu_share():
     return n, n
 
 
-def cpu_baseline(factory, dims):
-    """Oracle train steps (fwd + loss + bwd + Adam) on the host cores: 1 warm-up + 2 timed steps of ONE
-    volume of the benchmarked shape (BASELINE.md §3 plan).  Bounded: dims are capped at 128x256x256."""
+def cpu_baseline(factory, dims, B=1):
+    """Oracle train steps (fwd + loss + bwd + Adam) on the host cores, at the batch the GPU line runs (so BatchNorm
+    sees the same batch): 1 warm-up + 2 timed steps at batch 1, 1 warm-up + 1 timed step at batch >= 2 (BASELINE.md
+    §3 plan; ~25 s of CPU work for the headline).  Bounded: dims are capped at 128x256x256, the batch at 2."""
     from oracle import med3d_oracle as orc
     from bodyct_dram_emph_subtype_amd import med3d
     dims = tuple(min(a, b) for a, b in zip(dims, (128, 256, 256)))
@@ -190,7 +191,8 @@ def cpu_baseline(factory, dims):
     m = getattr(med3d, factory)(**kw)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     names = [n for n, _ in m.named_parameters()]
-    image, lung, em, cle, pse = synth_batch(1, dims, 0, "cpu")
+    B = max(1, min(int(B), 2))
+    image, lung, em, cle, pse = synth_batch(B, dims, 0, "cpu")
     mom = {n: (torch.zeros_like(sd[n]), torch.zeros_like(sd[n])) for n in names}
     # `cores` = CPUs this job OWNS (cgroup cpu.max quota; the GPU box shows all 128 hardware threads of the host but
     # grants 16 CPUs), `threads` = intra-op threads the oracle ran on (2 x the share: measured fastest,
@@ -198,7 +200,8 @@ def cpu_baseline(factory, dims):
     cores, threads = host_cpu_share()
     torch.set_num_threads(threads)
     times = []
-    for it in range(3):
+    nsteps = 3 if B == 1 else 2
+    for it in range(nsteps):
         t0 = time.perf_counter()
         leaves = {k: (v.detach().requires_grad_(True) if k in names else v) for k, v in sd.items()}
         dense, outs = orc.forward(leaves, image, lung, factory, train=True)
@@ -213,11 +216,12 @@ def cpu_baseline(factory, dims):
                 orc.adam_step(p, leaves[n].grad, mom[n][0], mom[n][1], it + 1, 1e-4)
                 sd[n] = p
         times.append(time.perf_counter() - t0)
-    dt = (times[1] + times[2]) / 2
-    return {"value": 1.0 / dt, "unit": "volumes/sec", "cores": cores, "threads": threads, "kind": "port",
-            "sample": f"{factory} train step (oracle, torch CPU ops, fwd+loss+bwd+Adam), batch 1 of "
-                      f"1x{dims[0]}x{dims[1]}x{dims[2]}: 1 warm-up ({times[0]:.1f} s) + 2 timed steps "
-                      f"({times[1]:.1f} s, {times[2]:.1f} s), {threads} threads on the {cores} CPUs the job owns "
+    dt = sum(times[1:]) / (nsteps - 1)
+    return {"value": B / dt, "unit": "volumes/sec", "cores": cores, "threads": threads, "kind": "port",
+            "sample": f"{factory} train step (oracle, torch CPU ops, fwd+loss+bwd+Adam), batch {B} of "
+                      f"1x{dims[0]}x{dims[1]}x{dims[2]} (the GPU line's per-GPU batch, capped at 2): 1 warm-up "
+                      f"({times[0]:.1f} s) + {nsteps - 1} timed step(s) ({', '.join(f'{t:.1f} s' for t in times[1:])}), "
+                      f"{threads} threads on the {cores} CPUs the job owns "
                       f"(cgroup cpu.max; {os.cpu_count()} hardware threads visible)"}
 
 
@@ -329,7 +333,7 @@ def main():
 
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(factory, dims)          # first: the GPU burst below is then the tail of the run
+        cpu = cpu_baseline(factory, dims, B)          # first: the GPU burst below is then the tail of the run
 
     if args.share_gpu:
         local_rank = 0

@@ -53,6 +53,7 @@ SIGNATURES = {
     "dram_version": (I, []),
     "dram_build_info": (c_char_p, []),
     "dram_abi_hash": (c_char_p, []),
+    "dram_stream_capture_id": (ctypes.c_ulonglong, [P]),
     "dram_profile_family_name": (c_char_p, [I]),
     "dram_profile_family_is_mfma": (I, [I]),
     "dram_profile_start": (I, [I]),

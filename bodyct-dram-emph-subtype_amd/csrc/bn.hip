@@ -75,8 +75,10 @@ struct FoldFinalize {               // gamma == NULL: no finalize
   float momentum, eps; int update;
   float* mean; float* invstd; float* scale; float* shift;
 };
-constexpr int FOLD_SLOTS = 256, FOLD_XMAX = 512;
-__device__ unsigned g_fold_ticket[FOLD_SLOTS * FOLD_XMAX];
+// S > 1: the tickets are PER-CALL memory (FOLD_XMAX words behind the S stage rows of `scratch`, zeroed by a memset
+// in front of the launch): launches in flight together -- two streams, a graph replay beside an eager step, two host
+// threads -- cannot share a counter, whatever their order.
+constexpr int FOLD_XMAX = 512;
 
 // grid (column groups, S stage rows), 1 024 threads = 16 part lanes x 64 columns.  A block owns 64 columns: plain mode 64 consecutive ones; finalize mode the
 // sum AND the sum of squares of 32 channels (columns c and C + c), so that the block which completes a column group
@@ -86,7 +88,8 @@ __global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __rest
                                                              double* __restrict__ sums, float* __restrict__ sums_f32,
                                                              float* __restrict__ f32_row1, const int nparts, const int RC,
                                                              const double tail,
-                                                             const int has_tail, const int slot, const FoldFinalize ff) {
+                                                             const int has_tail, unsigned* __restrict__ ticket,
+                                                             const FoldFinalize ff) {
   __shared__ double sm[1024];
   __shared__ double tot[64];
   __shared__ unsigned s_ticket;
@@ -121,11 +124,10 @@ __global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __rest
     if (lane4 == 0 && live) scratch[(long)sidx * RC + col] = total;
     __threadfence();                                 // this block's stage row is visible device-wide ...
     __syncthreads();
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&g_fold_ticket[slot * FOLD_XMAX + blockIdx.x], 1u);   // ... before its ticket
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&ticket[blockIdx.x], 1u);   // ... before its ticket
     __syncthreads();
     if (s_ticket != (unsigned)S - 1) return;
     __threadfence();
-    if (threadIdx.x == 0) g_fold_ticket[slot * FOLD_XMAX + blockIdx.x] = 0;    // free for the next launch / graph replay
     if (lane4 == 0 && live) {
       total = 0.0;
       int k = 0;
@@ -577,14 +579,18 @@ extern "C" int dram_fold_partials_stages(int nparts) {
 
 static int fold_launch(const float* partial, double* sums, double* scratch, float* sums_f32, float* f32_row1, int nparts,
                        int RC, double tail, int has_tail, const FoldFinalize& ff, hipStream_t st) {
-  static std::atomic<unsigned> next_slot{0};         // host-side round robin: launches in flight together (two
-  const int slot = (int)(next_slot.fetch_add(1) % FOLD_SLOTS);   // streams, two host threads) use different tickets
   const int S = dram_fold_partials_stages(nparts);
   const int gx = ff.gamma ? (RC / 2 + 31) / 32 : (RC + 63) / 64;
   if (S > 1 && gx > FOLD_XMAX) return DRAM_ERR_UNSUPPORTED;        // (no such layer: S > 1 goes with few channels)
+  unsigned* ticket = nullptr;
+  if (S > 1) {                                       // (a memset NODE under capture: every replay starts from zero)
+    ticket = reinterpret_cast<unsigned*>(scratch + (long)S * RC);
+    const hipError_t e = hipMemsetAsync(ticket, 0, sizeof(unsigned) * gx, st);
+    if (e != hipSuccess) return (int)e;
+  }
   DramProf prof(DRAM_FAM_BN, 0, 0.0, 4.0 * (double)nparts * RC + 8.0 * RC, st);
   hipLaunchKernelGGL(fold_partials_kernel, dim3(gx, S), dim3(1024), 0, st, partial, scratch, sums, sums_f32, f32_row1,
-                     nparts, RC, tail, has_tail, slot, ff);
+                     nparts, RC, tail, has_tail, ticket, ff);
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

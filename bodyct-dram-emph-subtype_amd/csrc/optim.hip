@@ -150,3 +150,11 @@ extern "C" const char* dram_build_info(void) { return "libdram_hip gfx950 fp32-m
 #error "build through _build.py (it passes -DDRAM_ABI_HASH=<sha1 of include/dram_hip.h>)"
 #endif
 extern "C" const char* dram_abi_hash(void) { return DRAM_ABI_HASH; }
+
+extern "C" unsigned long long dram_stream_capture_id(dram_stream_t stream) {
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo((hipStream_t)stream, &status, &id) != hipSuccess) return 0;
+  if (status != hipStreamCaptureStatusActive) return 0;
+  return id ? id : ~0ull;                            // (never 0 while capturing)
+}

@@ -227,7 +227,11 @@ class Engine:
             v = c.get("v")
             # (a unit that applied its producer's BatchNorm on the way in holds no input tensor: the pipeline's weight
             # gradient takes the forward's transformed input instead; anything else re-derives the input)
-            xin = c["x"] if (c["x"] is not None or (v is not None and ops.conv_plan(c["g"]).walgo == 1)) else self._input_of(c)
+            # (ops.conv3d_bwd_weight's own predicate: a cached image, the pipeline's plan AND its workspace -- a geometry
+            # whose TN plan fails reports no workspace and runs the direct weight gradient, which needs the input)
+            plan = ops.conv_plan(c["g"])
+            from_v = v is not None and plan.walgo == 1 and plan.ws_wgrad > 0
+            xin = c["x"] if (c["x"] is not None or from_v) else self._input_of(c)
             st.grads[c["w"]] = ops.conv3d_bwd_weight(xin, dy, c["g"], out=out, v_cache=v)
             c["v"] = None                               # release the cached Winograd-domain input
         if st.dist is not None:

@@ -21,6 +21,7 @@ from typing import Callable, Sequence
 
 import torch
 
+from . import ops
 from .optim import FusedAdam
 
 
@@ -41,7 +42,8 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        self._keep: list = []                         # scratch buffers / device work lists the captured launches point at
+        with ops.capture_keepalive(self._keep), torch.cuda.graph(self.graph):
             self.static_loss = self._eager()
         self.steps_captured_eagerly = max(1, warmup)          # the capture pass itself does not execute
 

@@ -13,6 +13,7 @@ import contextlib
 import ctypes
 import os
 import threading
+import weakref
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -314,7 +315,36 @@ class ConvGeom:
 
 
 # --------------------------------------------------------------------------- conv
+# Memory a CAPTURED launch bakes a pointer of (scratch buffers, device work lists) must outlive the graph, and must not
+# be handed to anybody else meanwhile.  Whoever owns a capture passes a list to capture_keepalive() and keeps it as long
+# as the graph (graph.GraphedTrainStep does); captures made without one pin such memory for the life of the process.
+_CAPTURE_KEEP: List[object] = []
+_CAPTURE_OWNER: Optional[List[object]] = None       # process-wide: backward runs on autograd's thread, not the caller's
+
+
+@contextlib.contextmanager
+def capture_keepalive(owner: List[object]):
+    global _CAPTURE_OWNER
+    prev, _CAPTURE_OWNER = _CAPTURE_OWNER, owner
+    try:
+        yield owner
+    finally:
+        _CAPTURE_OWNER = prev
+
+
+def capture_id() -> int:
+    """0 when the launch stream is not being captured into a hipGraph, else a number unique to that capture."""
+    return int(_L().dram_stream_capture_id(_stream()))
+
+
+def _keep_for_capture(obj):
+    keep = _CAPTURE_OWNER if _CAPTURE_OWNER is not None else _CAPTURE_KEEP
+    if not any(o is obj for o in keep[-16:]):
+        keep.append(obj)
+
+
 _WORKSPACE: Dict[tuple, Tensor] = {}
+_CAPTURE_WS: Dict[tuple, "weakref.ref"] = {}        # (device, stream, capture id) -> the capture's own scratch (weak)
 
 
 def _workspace(nbytes: int, device) -> Tensor:
@@ -322,15 +352,28 @@ def _workspace(nbytes: int, device) -> Tensor:
     (device, launch stream): the weight-gradient stream has its own)."""
     device = torch.device(device)
     n = (nbytes + 3) // 4
-    # (capturing: a buffer of its own, from the graph's private pool -- an eager call on the same stream that outgrows
-    # the cached buffer later must not free memory a captured graph still writes to on every replay)
-    key = (device, _stream().value, torch.cuda.is_current_stream_capturing())
+    cid = capture_id()
+    if cid:
+        # capturing: a buffer of THIS capture's own (from the graph's private pool), owned by the capture's keep-alive
+        # list -- never shared with an eager call or another capture on the same stream, never evicted: the graph
+        # writes to it on every replay.  A buffer it outgrows stays alive too (earlier captured launches use it).
+        key = (device, _stream().value, cid)
+        ref = _CAPTURE_WS.get(key)
+        ws = ref() if ref is not None else None
+        if ws is None or ws.numel() < n:
+            ws = torch.empty((n,), device=device, dtype=torch.float32)
+            _keep_for_capture(ws)
+            for k in [k for k, r in _CAPTURE_WS.items() if r() is None]:
+                del _CAPTURE_WS[k]
+            _CAPTURE_WS[key] = weakref.ref(ws)
+        return ws
+    key = (device, _stream().value)
     ws = _WORKSPACE.pop(key, None)                  # re-inserted below: the dict stays in least-recently-used order
     if ws is None or ws.numel() < n:
         ws = None
         ws = torch.empty((n,), device=device, dtype=torch.float32)
-        while len(_WORKSPACE) >= 6:                 # caller stream + side stream + a graph-capture stream or two; streams
-            _WORKSPACE.pop(next(iter(_WORKSPACE)))  # that went away (old captures) must not pin up to 0.7 GB each
+        while len(_WORKSPACE) >= 6:                 # caller stream + side stream + a few more; streams that went away
+            _WORKSPACE.pop(next(iter(_WORKSPACE)))  # must not pin up to 0.7 GB each
     _WORKSPACE[key] = ws
     return ws
 
@@ -477,7 +520,9 @@ def pack_conv_weights_bf16_multi(weights: List[Tensor]):
     if not weights:
         return []
     key = tuple((w.data_ptr(), tuple(w.shape)) for w in weights)
-    ent = _PACK_TABLES.get(key)
+    ent = _PACK_TABLES.pop(key, None)               # (re-inserted below: least recently USED is evicted first)
+    if ent is not None:
+        _PACK_TABLES[key] = ent
     if ent is None:
         if torch.cuda.is_current_stream_capturing():
             return None
@@ -504,6 +549,8 @@ def pack_conv_weights_bf16_multi(weights: List[Tensor]):
         while len(_PACK_TABLES) >= 8:
             _PACK_TABLES.pop(next(iter(_PACK_TABLES)))
         _PACK_TABLES[key] = ent
+    if torch.cuda.is_current_stream_capturing():
+        _keep_for_capture(ent)                      # the captured launch reads this work list on every replay
     table, chunks, nchunks, total, layout = ent
     flat = torch.empty((total,), device=weights[0].device, dtype=BF16)
     _chk(_L().dram_pack_conv_weight_bf16_multi(_p(table), _p(chunks), nchunks, _p(flat), float(total // 2), _stream()),
@@ -518,7 +565,6 @@ def pack_conv_weights_bf16_multi(weights: List[Tensor]):
 # recycled for another tensor while the entry lives; an entry is valid while the tensor still uses that storage,
 # its torch version counter is unchanged and no raw-pointer writer (FusedAdam / FusedSGD bump WEIGHT_EPOCH)
 # has run.
-import weakref  # noqa: E402
 
 WEIGHT_EPOCH = 0
 _PACKED: Dict[int, tuple] = {}      # id(weight) -> (weakref to the weight, {plan key: entry}); removed when it dies
@@ -783,6 +829,9 @@ def stem_bwd_weight(x: Tensor, dy: Tensor, out: Optional[Tensor] = None) -> Tens
 
 
 # --------------------------------------------------------------------------- batch norm
+FOLD_TICKET_DOUBLES = 256       # include/dram_hip.h DRAM_FOLD_TICKET_DOUBLES: per-call ticket words behind the stage rows
+
+
 def reduce_partials(partial: Tensor, tail: Optional[float] = None, want_f32: bool = False):
     """[P,R,C] float32 -> [R,C] float64, ONE launch (dram_fold_partials).  With `tail` (SyncBN: the rank's element
     count) returns (flat [R*C+1] float64 whose last element is tail -- the buffer to all-reduce --, its [R,C] view);
@@ -792,7 +841,8 @@ def reduce_partials(partial: Tensor, tail: Optional[float] = None, want_f32: boo
     Pn, R, C = partial.shape
     stages = _L().dram_fold_partials_stages(Pn)
     n = R * C + (1 if tail is not None else 0)
-    buf = torch.empty((n + stages * R * C,), device=partial.device, dtype=torch.float64)
+    buf = torch.empty((n + stages * R * C + (FOLD_TICKET_DOUBLES if stages > 1 else 0),), device=partial.device,
+                      dtype=torch.float64)
     flat = buf[:n]
     # float copy: one tensor PER ROW (whole tensors, which autograd takes over as .grad without a copy; row views of
     # one [R, C] tensor are cloned by AccumulateGrad -- 108 copies per ResNet-50 step)
@@ -820,7 +870,8 @@ def bn_fold_finalize(partial: Tensor, count: float, gamma: Tensor, beta: Tensor,
     for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
         _req(t, nm, shape=(C,))
     stages = _L().dram_fold_partials_stages(Pn)
-    buf = torch.empty(((1 + stages) * 2 * C,), device=partial.device, dtype=torch.float64)
+    buf = torch.empty(((1 + stages) * 2 * C + (FOLD_TICKET_DOUBLES if stages > 1 else 0),), device=partial.device,
+                      dtype=torch.float64)
     out = torch.empty((4, C), device=partial.device, dtype=torch.float32)
     _chk(_L().dram_bn_fold_finalize(_p(partial), _p(buf), _p(buf[2 * C:]), Pn, C, float(count), _p(gamma), _p(beta),
                                     _p(running_mean), _p(running_var), float(momentum), float(eps), 1, _p(out[0]),

@@ -72,6 +72,7 @@ class _FusedBase(torch.optim.Optimizer):
                 t.copy_(sp[0], non_blocking=True)
                 c.copy_(sp[1], non_blocking=True)
                 self._pinned_owned.append(sp)
+                ops._keep_for_capture((t, c))         # the captured update reads them on every replay
             else:
                 # Gradients are fresh tensors every step (zero_grad(set_to_none=True)), so the POINTER table changes
                 # every step.  A pageable host->device copy blocks the host until the stream has drained -- the host then

@@ -42,6 +42,11 @@ const char* dram_build_info(void);
 /* sha1 (first 16 hex digits) of the dram_hip.h this library was compiled against; the host binding
  * compares it with the header it reads its signatures from and refuses a mismatching library. */
 const char* dram_abi_hash(void);
+/* Identity of the hipGraph capture `stream` is recording into (hipStreamGetCaptureInfo): 0 when the stream is not
+ * capturing, otherwise a number unique to that capture.  The host side keys everything a captured launch bakes a
+ * pointer of (scratch buffers, device work lists) by it, so that no other capture and no eager call can take over or
+ * free such memory while the graph lives.  Does not enqueue anything. */
+unsigned long long dram_stream_capture_id(dram_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* Kernel timeline (measurement only; off by default, no cost when off).
@@ -266,10 +271,13 @@ int dram_stem_bwd_weight(const float* x, const float* dy, float* dw, int B, int 
  *   global count (ranks may hold different batch sizes -- torch SyncBatchNorm semantics). */
 int dram_reduce_partials_stages(int nparts);
 /* The same fold in ONE launch (S = dram_fold_partials_stages(nparts) stage rows; for S > 1 the last block of a column
- * group to finish folds them, fixed order): scratch = S*R*C doubles, sums_f32: optional float copy of the sums
+ * group to finish folds them, fixed order): scratch = S*R*C doubles, followed for S > 1 by DRAM_FOLD_TICKET_DOUBLES
+ * doubles of per-call ticket words which the call zeroes itself (a memset on `stream`: launches in flight together on
+ * other streams, or a graph replay beside an eager step, never share a counter); sums_f32: optional float copy of the sums
  * ([R][C]; with f32_row1 != NULL and R == 2, row 1 goes there instead: two separately allocated [C] tensors).
  * dram_bn_fold_finalize: fold of the [nparts][2][C] convolution-epilogue partials + dram_bn_finalize on the result
  * (host-side count) in that launch -- the single-process training forward. */
+#define DRAM_FOLD_TICKET_DOUBLES 256
 int dram_fold_partials_stages(int nparts);
 int dram_fold_partials(const float* partial, double* sums, double* scratch, float* sums_f32, float* f32_row1, int nparts,
                        int R, int C, double tail, int has_tail, dram_stream_t stream);

@@ -558,6 +558,20 @@ def test_graphed_bf16_train_step_equals_eager():
              torch.randint(0, 6, (2,), generator=g).to(DEV), torch.randint(0, 3, (2,), generator=g).to(DEV))
     cw, pw = torch.full((6,), 1 / 6, device=DEV), torch.full((3,), 1 / 3, device=DEV)
 
+    def churn():
+        """More than eight OTHER sets of weights through the one-launch packing (its cache of device work lists holds
+        eight) and scratch requests from another capture-free stream, then allocations that recycle whatever was
+        freed, filled with ones: a captured graph whose work list or scratch had been given up would now pack garbage."""
+        from bodyct_dram_emph_subtype_amd import ops
+        with ops.launch_scope(DEV):
+            for i in range(10):
+                ws = [torch.randn(32 + 32 * (i % 3), 32, 3, 3, 3, device=DEV) for _ in range(2 + i % 2)]
+                assert ops.pack_conv_weights_bf16_multi(ws) is not None
+        torch.cuda.synchronize()
+        junk = [torch.full((n,), 0xFF, device=DEV, dtype=torch.uint8) for n in (512, 4096, 32768, 1 << 18, 1 << 21) for _ in range(8)]
+        torch.cuda.synchronize()
+        del junk
+
     def run(graphed):
         torch.manual_seed(11)
         m = med3d.resnet18segcls(n_classes=[6, 3]).to(DEV).train()
@@ -566,6 +580,8 @@ def test_graphed_bf16_train_step_equals_eager():
         loss_fn = lambda i, l, c, p: cls_train_loss(m(i, l)[1], c, p, cw, pw)[0]      # noqa: E731
         if graphed:
             step = GraphedTrainStep(m, opt, loss_fn, batch, warmup=2)
+            assert step._keep, "the capture kept no scratch buffer / work list alive"
+            churn()
         else:
             def step(*b):
                 opt.zero_grad(set_to_none=True)

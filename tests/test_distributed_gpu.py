@@ -261,7 +261,10 @@ def test_bench_line_is_alone_on_stdout_with_rccl_up():
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env["MASTER_PORT"] = "29577"
+    import socket
+    with socket.socket() as sk:                       # a free port (a leftover run on the box must not fail the rendezvous)
+        sk.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(sk.getsockname()[1])
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "0", "--steps", "2", "--warmup", "1", "--force-dist",
            "--no-cpu-baseline", "--timeline", "off"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd="/tmp")

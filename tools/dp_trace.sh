@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/dp; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/trace_fd
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_fd -- python3 $R/bench.py --config 1 --force-dist --steps 4 --warmup 2 --no-cpu-baseline --timeline off > $O/prof_fd.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_fd -- python3 $R/bench.py --config 1 --force-dist --steps 4 --warmup 2 --no-cpu-baseline --timeline off > $O/prof_fd.json 2>$O/prof_fd.err
 find $O/trace_fd -name "*agent_info.csv" -delete
 python3 - <<PY
 import csv,glob
