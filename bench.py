@@ -346,7 +346,10 @@ def main():
         # in bf16: 41.5 -> 44.6) and the small config 0 (67-93 -> 99); the fp32 steps of configs 1 / 3 / 5 stay eager:
         # the captured step is single-stream, and the weight-gradient side stream is worth as much as the gaps there
         # (config 1: 44.0 ms eager, 44.7 as a graph, 11 GB more for the graph's private pool)
-        args.graph = (not (use_dist or args.predict or args.detail)) and (args.dtype == "bf16" or args.config == 0)
+        # data parallel: the same rule -- under RCCL the collectives are plain stream work and are captured with the step
+        # (distributed.DistContext.capturable); a gloo rehearsal runs eager
+        args.graph = (not (args.predict or args.detail or (use_dist and args.backend != "nccl"))) and \
+            (args.dtype == "bf16" or args.config == 0)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -392,9 +395,10 @@ def main():
             res = processor.build_outputs([out], want_u8=True)
             return res[0]["full_cle"].float().mean()
         args.timeline = "off"
+    if args.graph and dctx is not None and not dctx.capturable:
+        print("[bench] this process group's collectives run on the host (gloo): timing eager steps", file=sys.stderr)
+        args.graph = False
     if args.graph:
-        if use_dist:
-            raise SystemExit("--graph is single-GPU")
         from bodyct_dram_emph_subtype_amd.graph import GraphedTrainStep
         from bodyct_dram_emph_subtype_amd.models import cls_train_loss, reg_train_loss
         if factory.endswith("cls"):
@@ -413,7 +417,10 @@ def main():
         eager_step = step
         try:
             graphed = GraphedTrainStep(module, opt, loss_fn, batch, warmup=2)
-            step = lambda: graphed(*batch)      # noqa: E731
+            if graphed.graph is None:           # (data parallel: the runtime refused to record the collectives)
+                args.graph = False
+            else:
+                step = lambda: graphed(*batch)      # noqa: E731
         except Exception as e:                  # capture refused (driver / allocator state): time eager steps, say so
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); timing eager steps", file=sys.stderr)
             args.graph = False
@@ -460,6 +467,28 @@ def main():
     if args.detail:
         single_stream(False)
     tl_step_s = dt / args.steps
+    # Data parallel: what do the collectives COST a step?  The same K steps once more WITHOUT them (context detached,
+    # every rank on its own; same eager / graph form) right after the timed region: exposed_collective_ms = the
+    # difference of the two step times, which by construction reconciles with the wall clock (the event-bracketed
+    # sum of round 4 saw neither the cross-stream hand-offs nor RCCL's own launch overhead).
+    plain_step_ms = None
+    if dctx is not None and not args.predict:
+        module._dist = None
+        try:
+            pstep = eager_step if args.graph else step
+            if args.graph:
+                g2 = GraphedTrainStep(module, opt, loss_fn, batch, warmup=2)
+                pstep = lambda: g2(*batch)      # noqa: E731
+            for _ in range(max(2, args.warmup)):
+                pstep()
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for _ in range(args.steps):
+                pstep()
+            torch.cuda.synchronize()
+            plain_step_ms = (time.perf_counter() - tp) / args.steps * 1e3
+        finally:
+            module._dist = dctx
     if args.graph:
         step = eager_step                   # the timeline pass brackets individual launches: eager
     # every rank runs the second pass (its steps contain collectives); rank 0 records the timeline
@@ -471,6 +500,7 @@ def main():
         # data-gradient chain on a second stream a kernel's event interval would also contain the time it
         # shared its CUs with the other stream's kernel, and per-family fractions would mean nothing.
         single_stream(True)
+        stats0 = dict(dctx.stats) if dctx is not None else None
         step()
         barrier()
         if dctx is not None:
@@ -530,12 +560,20 @@ def main():
             "peak_hbm_gb": torch.cuda.max_memory_allocated(device) / 1e9,
         }
         if dctx is not None:
-            ran = args.warmup + args.steps + (args.steps + 1 if args.timeline in ("after", "off") else 0)   # + second pass
-            out["collectives_per_step"] = {k: v / ran for k, v in dctx.stats.items()}
+            if args.timeline in ("after", "off"):    # counted over the eager second pass (a replayed graph issues none from the host)
+                out["collectives_per_step"] = {k: (v - stats0[k]) / (args.steps + 1) for k, v in dctx.stats.items()}
+            else:
+                out["collectives_per_step"] = {k: v / (args.warmup + args.steps) for k, v in dctx.stats.items()}
+            out["collective_transport"] = "rccl-c-api" if dctx._stat is not None else f"torch.distributed/{args.backend}"
+            if plain_step_ms is not None:
+                # step time with the collectives minus step time without them (same process, same form, measured
+                # right after the timed region; on rank 0 -- dt is the max over ranks)
+                out["plain_ms_per_step"] = plain_step_ms
+                out["exposed_collective_ms"] = 1e3 * step_s - plain_step_ms
             if args.timeline in ("after", "off"):
-                # time the data path's stream sat between issuing a SyncBN statistic exchange and continuing, per step
-                # (single-stream pass; the gradient buckets are asynchronous and not part of it)
-                out["exposed_collective_ms"] = exposed_ms
+                # event pairs around every SyncBN statistic exchange on the data path's stream, per step (single-stream
+                # pass; the gradient buckets are asynchronous and not part of it): a LOWER bound of the above
+                out["stat_exchange_ms_bracketed"] = exposed_ms
         if timeline:
             fams = timeline.families()
             bf16_fams = ("conv_bf16", "wgrad_bf16") + (("stem",) if (args.dtype == "bf16" and ops.tuning_env("DRAM_STEM_BF16", "1") != "0") else ())

@@ -7,6 +7,20 @@
 
 namespace {
 
+// ONE element's update, the same instruction sequence on the vector and the scalar path (contraction pinned: left to
+// the compiler the two paths fused differently, and a parameter whose gradient arrived 4-byte aligned -- a view of the
+// data-parallel step's small-gradient bucket -- moved one ulp away from the same update of an aligned gradient).
+__device__ __forceinline__ void adam1(float& p, const float g, float& m, float& v, const float b1, const float b2,
+                                      const float eps, const float wd, const float step, const float rs2,
+                                      const float gscale) {
+#pragma clang fp contract(off)
+  float gg = g * gscale;
+  if (wd != 0.f) gg = __builtin_fmaf(wd, p, gg);
+  m = __builtin_fmaf(b1, m, (1.f - b1) * gg);
+  v = __builtin_fmaf(b2, v, ((1.f - b2) * gg) * gg);
+  p -= (step * m) / __builtin_fmaf(sqrtf(v), rs2, eps);
+}
+
 __device__ __forceinline__ void adam_chunk(const DramTensorRef* __restrict__ table,
                                            const DramChunkRef* __restrict__ chunks, float lr, float b1, float b2,
                                            float eps, float wd, float bc1, float bc2, float gscale) {
@@ -25,40 +39,21 @@ __device__ __forceinline__ void adam_chunk(const DramTensorRef* __restrict__ tab
     const long n4 = n >> 2;
     for (long i = threadIdx.x; i < n4; i += 256) {
       float4 pv = reinterpret_cast<float4*>(p)[i];
-      float4 gv = reinterpret_cast<const float4*>(g)[i];
+      const float4 gv = reinterpret_cast<const float4*>(g)[i];
       float4 mv = reinterpret_cast<float4*>(m)[i];
       float4 vv = reinterpret_cast<float4*>(v)[i];
-#define ADAM1(f)                                   \
-  {                                                \
-    float gg = gv.f * gscale;                      \
-    if (wd != 0.f) gg += wd * pv.f;                \
-    mv.f = b1 * mv.f + (1.f - b1) * gg;            \
-    vv.f = b2 * vv.f + (1.f - b2) * gg * gg;       \
-    pv.f -= step * mv.f / (sqrtf(vv.f) * rs2 + eps); \
-  }
-      ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
-#undef ADAM1
+      adam1(pv.x, gv.x, mv.x, vv.x, b1, b2, eps, wd, step, rs2, gscale);
+      adam1(pv.y, gv.y, mv.y, vv.y, b1, b2, eps, wd, step, rs2, gscale);
+      adam1(pv.z, gv.z, mv.z, vv.z, b1, b2, eps, wd, step, rs2, gscale);
+      adam1(pv.w, gv.w, mv.w, vv.w, b1, b2, eps, wd, step, rs2, gscale);
       reinterpret_cast<float4*>(p)[i] = pv;
       reinterpret_cast<float4*>(m)[i] = mv;
       reinterpret_cast<float4*>(v)[i] = vv;
     }
-    for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
-      float gg = g[i] * gscale;
-      if (wd != 0.f) gg += wd * p[i];
-      const float mm = b1 * m[i] + (1.f - b1) * gg;
-      const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
-      m[i] = mm; v[i] = vv;
-      p[i] -= step * mm / (sqrtf(vv) * rs2 + eps);
-    }
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) adam1(p[i], g[i], m[i], v[i], b1, b2, eps, wd, step, rs2, gscale);
   } else {
-    for (long i = threadIdx.x; i < n; i += 256) {
-      float gg = g[i] * gscale;
-      if (wd != 0.f) gg += wd * p[i];
-      const float mm = b1 * m[i] + (1.f - b1) * gg;
-      const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
-      m[i] = mm; v[i] = vv;
-      p[i] -= step * mm / (sqrtf(vv) * rs2 + eps);
-    }
+    // (16-byte alignment is not guaranteed: a data-parallel step hands over small gradients as views of one bucket)
+    for (long i = threadIdx.x; i < n; i += 256) adam1(p[i], g[i], m[i], v[i], b1, b2, eps, wd, step, rs2, gscale);
   }
 }
 

@@ -21,8 +21,15 @@ Collectives per train step: 2 x (number of BN layers) statistic all-reduces (22/
 ResNet-18/34/50: 44/76/108, each <= 32 KB, latency-bound; the backward half is hidden behind a
 weight-gradient kernel) + ceil(parameter bytes / bucket_bytes) + 1 gradient all-reduces (R18: 5 + 1).
 
-``torch.distributed`` with backend ``nccl`` IS RCCL on ROCm; the same code runs on ``gloo`` (CPU or
-device tensors) for tests.  ``force=True`` (or DRAM_DIST_FORCE=1) keeps every collective in place at
+Transport.  Under the ``nccl`` backend (= RCCL on ROCm) the collectives do NOT go through ``torch.distributed``: the
+context owns two RCCL communicators reached through librccl's C API (rccl.py).  The statistic exchanges are enqueued on
+the DATA stream itself -- the stream the producing fold kernel was launched on -- so an exchange is one more kernel in
+the data path's queue: no second stream, no event hand-off (ProcessGroupNCCL's two hand-offs per call were +10 / +15 /
++38 % on the config 1 / config 2 bf16 / ResNet-50 bf16 step at world size 1, round 4).  The gradient buckets go to a
+communication stream forked from the producing stream and joined at the end of backward with plain events.  All of it is
+ordinary stream work, so the data-parallel step can be captured into a hipGraph (``capturable``).  ``gloo`` groups (CPU
+or device tensors: the tests) keep ``torch.distributed``'s collectives; DRAM_DIST_TRANSPORT=torch under DRAM_TUNING=1
+forces that path under ``nccl`` too (A/B).  ``force=True`` (or DRAM_DIST_FORCE=1) keeps every collective in place at
 world_size 1, which is how the RCCL code path is exercised on a one-GPU box.  The engine's fused
 conv-BN units are invisible to ``SyncBatchNorm.convert_sync_batchnorm``, hence
 this module.
@@ -74,11 +81,18 @@ class DistContext:
         self.average = average
         self._backend = dist.get_backend(process_group)
         # SyncBN statistics travel on their OWN communicator: a latency-critical 2C-double exchange the data path
-        # waits for must not queue, on one RCCL stream, behind a >= 32 MB gradient bucket that itself waits for the
-        # side stream's weight-gradient kernels.  Under RCCL the group gets a high-priority HIP stream (torch hands
-        # the results over with events: work.wait() / the blocking call order the caller's stream after it).
+        # waits for must not queue behind a >= 32 MB gradient bucket that itself waits for the side stream's
+        # weight-gradient kernels.
         self.stat_pg = process_group
-        if self.active and (self.world > 1 or self._backend == "nccl"):
+        self._stat = self._grad = self._comm_stream = None       # own RCCL communicators (rccl.py) + the bucket stream
+        if self.active and self._backend == "nccl" and self._transport() == "rccl":
+            from . import rccl
+            self._stat = rccl.Communicator(process_group)        # used on the data stream itself
+            self._grad = rccl.Communicator(process_group)        # used on _comm_stream
+            self._comm_stream = torch.cuda.Stream()
+        elif self.active and (self.world > 1 or self._backend == "nccl"):
+            # torch.distributed transport (gloo; nccl under DRAM_DIST_TRANSPORT=torch): under RCCL the group gets a
+            # high-priority HIP stream, torch hands the results over with events
             self.stat_pg = self._new_stat_group(process_group)
         self.timing = False                                              # bench.py --force-dist: time the exchanges
         self._timed: List[tuple] = []
@@ -88,6 +102,18 @@ class DistContext:
         self.stats = dict(bn_allreduce=0, grad_allreduce=0)              # collectives issued since construction
         self.last_arena = None                                           # (ptr, bytes) of the last finished step's arena
         self._reset()
+
+    @staticmethod
+    def _transport() -> str:
+        from . import ops, rccl
+        want = ops.tuning_env("DRAM_DIST_TRANSPORT", "rccl")
+        return "rccl" if (want != "torch" and rccl.available()) else "torch"
+
+    @property
+    def capturable(self) -> bool:
+        """Can a step with these collectives be captured into a hipGraph?  Yes when they are plain stream work (own
+        RCCL communicators) or absent (inactive context)."""
+        return (not self.active) or self._stat is not None
 
     def _new_stat_group(self, process_group):
         ranks = dist.get_process_group_ranks(process_group) if process_group is not None else None
@@ -108,8 +134,9 @@ class DistContext:
 
     def exposed_ms(self, reset: bool = True) -> float:
         """Sum of the intervals the CALLER'S stream spent between issuing a statistic exchange and being allowed
-        to continue (forward: the blocking call; backward: work.wait()), over everything timed since the last
-        reset.  Synchronises the device."""
+        to continue (forward: the blocking call; backward: work.wait(); own communicators: the RCCL kernel's span on
+        the data stream), over everything timed since the last reset.  Synchronises the device.  A lower bound of
+        what the collectives cost a step -- bench.py reports the step-time difference to the plain step next to it."""
         torch.cuda.synchronize()
         total = sum(a.elapsed_time(b) for a, b in self._timed)
         if reset:
@@ -169,7 +196,10 @@ class DistContext:
             return
         self.stats["bn_allreduce"] += 1
         a = self._mark()
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.stat_pg)
+        if self._stat is not None:
+            self._stat.all_reduce(flat)                 # on the data stream: the consumer is simply the next kernel
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.stat_pg)
         if a is not None:
             self._timed.append((a, self._mark()))
 
@@ -179,6 +209,14 @@ class DistContext:
         if not (self.sync_bn and self.active):
             return _Done()
         self.stats["bn_allreduce"] += 1
+        if self._stat is not None:
+            # own communicator: enqueued on the data stream, in order -- nothing to wait for on the host; the GPU stays
+            # busy with the weight-gradient kernels of the engine's second stream meanwhile
+            a = self._mark()
+            self._stat.all_reduce(flat)
+            if a is not None:
+                self._timed.append((a, self._mark()))
+            return _Done()
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.stat_pg, async_op=True)
         return _TimedWork(work, self) if self.timing else work
 
@@ -213,10 +251,24 @@ class DistContext:
         a = self._order[lo][1]
         b = self._order[self._hi - 1][1] + self._order[self._hi - 1][2]
         seg = self._arena[a:b]
-        work, scaled = self._all_reduce(seg, self.average, True)
+        work, scaled = self._bucket_all_reduce(seg)
         self.stats["grad_allreduce"] += 1
         self._inflight.append((work, seg, scaled))
         self._hi = lo
+
+    def _bucket_all_reduce(self, seg: Tensor):
+        """Mean (or sum) of a finished gradient range over ranks, asynchronous to the launching stream."""
+        if self._grad is None:
+            return self._all_reduce(seg, self.average, True)
+        from . import rccl
+        # fork: the communication stream continues from the point the producing stream (the weight-gradient stream, or
+        # the caller's) has reached; joined in finish().  Plain events: capturable.
+        ready = torch.cuda.Event()
+        ready.record()
+        self._comm_stream.wait_event(ready)
+        seg.record_stream(self._comm_stream)
+        self._grad.all_reduce(seg, rccl.AVG if self.average else rccl.SUM, stream=self._comm_stream.cuda_stream)
+        return None, True
 
     def finish(self, grads: Dict[str, Tensor]):
         """Flush what is left, wait for every bucket; the small parameters go in one extra bucket."""
@@ -229,11 +281,14 @@ class DistContext:
         flat = None
         if small:
             flat = torch.cat([grads[n].reshape(-1) for n in small])
-            work, scaled = self._all_reduce(flat, self.average, True)
+            work, scaled = self._bucket_all_reduce(flat)
             self.stats["grad_allreduce"] += 1
             self._inflight.append((work, flat, scaled))
+        if self._grad is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)        # join: every bucket is final from here on
         for work, seg, scaled in self._inflight:
-            work.wait()
+            if work is not None:
+                work.wait()
             if self.average and not scaled:
                 seg.div_(self.world)
         if small:

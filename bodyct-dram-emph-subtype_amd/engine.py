@@ -50,6 +50,7 @@ class _State:
         self.nbt: List[Tensor] = []
         self.deferred = None          # (ctx, dy) of the unit whose weight gradient is still to be launched
         self.side = None              # second HIP stream for the weight-gradient kernels (set by backward)
+
         self.convs: List[tuple] = []  # (weight name, geometry) in call order, recorded for the pre-pack of later steps
         self.packed: Dict[str, tuple] = {}   # weight name -> (wf, wb) packed ahead on the side stream
         self.packed_ready = None      # event: every entry of `packed` is complete
@@ -246,12 +247,13 @@ class Engine:
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)
+        side = st.side
         arena = st.dist.grad_out(c["w"]) if st.dist is not None else None     # written by the side stream's kernel
         for t in (c.get("x"), dy, c.get("v"), arena, c.get("src"), c.get("skip"), c.get("h")) + self._recipe_inputs(c):
             if t is not None:
-                t.record_stream(st.side)      # the allocator must not recycle them under the side stream's kernels
-        with ops.on_stream(st.side):
-            st.side.wait_event(ready)
+                t.record_stream(side)         # the allocator must not recycle them under the side stream's kernels
+        with ops.on_stream(side):
+            side.wait_event(ready)
             # data parallel: grads_ready() inside _wgrad launches the arena all-reduce from THIS stream context,
             # so the collective is ordered after the weight-gradient kernels that fill the range
             self._wgrad(st, c, dy)
@@ -537,6 +539,7 @@ class Engine:
             st.dist.begin_backward(saved["dense"].device)
         if self._two_streams():
             st.side = ops.side_stream(saved["dense"].device.index)
+
         n0, n1 = saved["n0"], saved["n1"]
         NO = n0 + n1
         dense = saved["dense"]

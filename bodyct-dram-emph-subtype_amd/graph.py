@@ -12,8 +12,14 @@ corrections in device memory, so the step can be captured once and replayed:
         loss = step(*batch)              # copies the batch into the static buffers, replays the graph
     scheduler.step()                     # lr changes reach the captured update through the device-side copy
 
-Single GPU only (the data-parallel collectives are not captured); BN running statistics, num_batches_tracked
-and the Adam state are updated by the replay exactly as by the eager step (tests/test_models_gpu.py).
+BN running statistics, num_batches_tracked and the Adam state are updated by the replay exactly as by the eager step
+(tests/test_models_gpu.py).
+
+Data parallel (``distributed.attach``): under RCCL the context's collectives are plain stream work -- ``ncclAllReduce``
+on the capturing stream for the SyncBN statistics, on a forked and re-joined communication stream for the gradient
+buckets (rccl.py) -- so the step is captured WITH them; an eager data-parallel ResNet-50 bf16 step is host-bound
+(~19 ms of launch issue for 16 ms of kernels), the replay is not.  If the runtime refuses the capture, a note goes to
+stderr and the step runs eagerly; a ``gloo`` group (host-side collectives) is never captured.
 """
 from __future__ import annotations
 
@@ -30,8 +36,10 @@ class GraphedTrainStep:
                  example_inputs: Sequence[torch.Tensor], warmup: int = 2):
         if not isinstance(optimizer, FusedAdam) or not optimizer.capturable:
             raise TypeError("GraphedTrainStep needs FusedAdam(..., capturable=True)")
-        if getattr(getattr(module, "model", module), "_dist", None) is not None:
-            raise NotImplementedError("graph capture of the data-parallel step is not supported")
+        ctx = getattr(getattr(module, "model", module), "_dist", None)
+        if ctx is not None and not ctx.capturable:
+            raise NotImplementedError("graph capture of a data-parallel step needs the RCCL transport (a gloo process "
+                                      "group runs its collectives on the host)")
         self.module, self.optimizer, self.loss_fn = module, optimizer, loss_fn
         self.static = [t.clone() for t in example_inputs]
         side = torch.cuda.Stream()
@@ -43,8 +51,19 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         self._keep: list = []                         # scratch buffers / device work lists the captured launches point at
-        with ops.capture_keepalive(self._keep), torch.cuda.graph(self.graph):
-            self.static_loss = self._eager()
+        try:
+            with ops.capture_keepalive(self._keep), torch.cuda.graph(self.graph):
+                self.static_loss = self._eager()
+        except RuntimeError as exc:
+            if ctx is None:
+                raise
+            # collectives the runtime would not record: the data-parallel step stays correct, eagerly
+            import sys
+            print(f"GraphedTrainStep: capture of the data-parallel step was refused ({str(exc).splitlines()[0]}); "
+                  "running eager steps", file=sys.stderr)
+            self.graph = None
+            self._keep.clear()
+            torch.cuda.synchronize()
         self.steps_captured_eagerly = max(1, warmup)          # the capture pass itself does not execute
 
     def _eager(self):
@@ -62,6 +81,8 @@ class GraphedTrainStep:
                 raise ValueError("GraphedTrainStep: input shapes / dtypes are fixed at capture time")
             if s.data_ptr() != t.data_ptr():
                 s.copy_(t)
+        if self.graph is None:
+            return self._eager()
         self.optimizer.sync_hyper()                   # lr moved by the scheduler since the last replay?
         self.graph.replay()
         self.optimizer.note_replayed_step()

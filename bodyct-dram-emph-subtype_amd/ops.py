@@ -59,16 +59,17 @@ def tuning_env(name: str, default: str) -> str:
     return os.environ.get(name, default) if os.environ.get("DRAM_TUNING", "0") == "1" else default
 
 
-_SIDE: Dict[int, "torch.cuda.Stream"] = {}
+_SIDE: Dict[tuple, "torch.cuda.Stream"] = {}
 
 
-def side_stream(device_index: int) -> "torch.cuda.Stream":
-    """The per-device second HIP stream of the engine (weight-gradient kernels run there, concurrently with the
-    data-gradient chain on the caller's stream)."""
-    s = _SIDE.get(device_index)
+def side_stream(device_index: int, which: int = 0) -> "torch.cuda.Stream":
+    """The per-device side HIP streams of the engine (weight-gradient kernels run there, concurrently with the
+    data-gradient chain on the caller's stream; `which` = 0, 1: consecutive layers alternate, so one layer's HBM-bound
+    transforms run under the previous layer's matrix-bound GEMM)."""
+    s = _SIDE.get((device_index, which))
     if s is None:
         prio = int(tuning_env("DRAM_SIDE_PRIORITY", "0"))     # A/B switch (tools): HIP stream priority of the side stream
-        s = _SIDE[device_index] = torch.cuda.Stream(device=device_index, priority=prio)
+        s = _SIDE[(device_index, which)] = torch.cuda.Stream(device=device_index, priority=prio)
     return s
 
 

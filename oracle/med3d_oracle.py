@@ -106,6 +106,34 @@ def upsample2_trilinear(x: Tensor) -> Tensor:
 
 
 # ---------------------------------------------------------------------------
+# storage rounding (test device: the reference under Lightning's `--precision bf16`, train.py:46, with the rounding
+# points of the build's bf16 STORAGE path -- DESIGN.md section 4b -- instead of torch autocast's)
+# ---------------------------------------------------------------------------
+_STORAGE = None          # None, or the dtype activations / convolution weights are rounded to where the build stores them
+
+
+class _RoundST(torch.autograd.Function):
+    """Round to the storage type and back; the gradient passes straight through (the build's backward treats a stored
+    activation as exact)."""
+
+    @staticmethod
+    def forward(ctx, t, dtype):
+        return t.to(dtype).to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def q(t: Tensor) -> Tensor:
+    """Identity, or -- inside forward(..., storage=torch.bfloat16) -- one rounding to the storage type: applied to the
+    network input, to every convolution weight (the packed bf16 operand), to every convolution output after its bias
+    (the stored pre-BatchNorm tensor; batch statistics are taken from the ROUNDED values), to every BatchNorm + residual
+    + ReLU output and to the up-sampled tensor.  Everything else (statistics, affine parameters, heads) stays exact."""
+    return t if _STORAGE is None else _RoundST.apply(t, _STORAGE)
+
+
+# ---------------------------------------------------------------------------
 # pinned decisions (test device: removes ReLU / max-pool tie-flips from gradient comparisons)
 # ---------------------------------------------------------------------------
 def relu(x: Tensor, pins: Optional[Dict[str, Tensor]] = None, key: str = "") -> Tensor:
@@ -155,34 +183,34 @@ def max_pool3(x: Tensor, pins: Optional[Dict[str, Tensor]] = None) -> Tensor:
 # ---------------------------------------------------------------------------
 def basic_block(x, sd, p, planes, stride, dil, has_ds, train, ns, pins=None):
     """BasicBlock.forward (med3d.py:129-144)."""
-    out = F.conv3d(x, sd[p + ".conv1.weight"], None, stride, dil, dil)
-    out = relu(batch_norm(out, sd, p + ".bn1", train, ns), pins, p + ".bn1")
-    out = F.conv3d(out, sd[p + ".conv2.weight"], None, 1, dil, dil)
+    out = q(F.conv3d(x, q(sd[p + ".conv1.weight"]), None, stride, dil, dil))
+    out = q(relu(batch_norm(out, sd, p + ".bn1", train, ns), pins, p + ".bn1"))
+    out = q(F.conv3d(out, q(sd[p + ".conv2.weight"]), None, 1, dil, dil))
     out = batch_norm(out, sd, p + ".bn2", train, ns)
     res = shortcut_a(x, planes, stride) if has_ds else x
-    return relu(out + res, pins, p + ".bn2")
+    return q(relu(out + res, pins, p + ".bn2"))
 
 
 def bottleneck(x, sd, p, planes, stride, dil, has_ds, train, ns, pins=None):
     """Bottleneck.forward (med3d.py:164-184)."""
-    out = F.conv3d(x, sd[p + ".conv1.weight"])
-    out = relu(batch_norm(out, sd, p + ".bn1", train, ns), pins, p + ".bn1")
-    out = F.conv3d(out, sd[p + ".conv2.weight"], None, stride, dil, dil)
-    out = relu(batch_norm(out, sd, p + ".bn2", train, ns), pins, p + ".bn2")
-    out = F.conv3d(out, sd[p + ".conv3.weight"])
+    out = q(F.conv3d(x, q(sd[p + ".conv1.weight"])))
+    out = q(relu(batch_norm(out, sd, p + ".bn1", train, ns), pins, p + ".bn1"))
+    out = q(F.conv3d(out, q(sd[p + ".conv2.weight"]), None, stride, dil, dil))
+    out = q(relu(batch_norm(out, sd, p + ".bn2", train, ns), pins, p + ".bn2"))
+    out = q(F.conv3d(out, q(sd[p + ".conv3.weight"])))
     out = batch_norm(out, sd, p + ".bn3", train, ns)
     res = shortcut_a(x, planes * 4, stride) if has_ds else x
-    return relu(out + res, pins, p + ".bn3")
+    return q(relu(out + res, pins, p + ".bn3"))
 
 
 def up_block(inputs, cats, sd, p, nconv, train, ns, pins=None):
     """UpsampleConvBlock5d.forward (med3d.py:85-89): up2 -> crop_concat (upsampled
     channels FIRST) -> nconv x (conv3+bias -> BN -> ReLU)."""
-    x = crop_concat(upsample2_trilinear(inputs), cats)
+    x = crop_concat(q(upsample2_trilinear(inputs)), cats)
     for i in range(nconv):
-        q = f"{p}.conv_blocks.{i}"
-        x = F.conv3d(x, sd[q + ".0.weight"], sd[q + ".0.bias"], 1, 1)
-        x = relu(batch_norm(x, sd, q + ".1", train, ns), pins, q + ".1")
+        cb = f"{p}.conv_blocks.{i}"
+        x = q(F.conv3d(x, q(sd[cb + ".0.weight"]), sd[cb + ".0.bias"], 1, 1))
+        x = q(relu(batch_norm(x, sd, cb + ".1", train, ns), pins, cb + ".1"))
     return x
 
 
@@ -191,14 +219,28 @@ def up_block(inputs, cats, sd, p, nconv, train, ns, pins=None):
 # ---------------------------------------------------------------------------
 def forward(sd: Dict[str, Tensor], x: Tensor, lungs: Optional[Tensor], arch: str,
             train: bool = True, new_stats: Optional[Dict[str, Tensor]] = None,
-            taps: Optional[Dict[str, Tensor]] = None, pins: Optional[Dict[str, Tensor]] = None):
+            taps: Optional[Dict[str, Tensor]] = None, pins: Optional[Dict[str, Tensor]] = None,
+            storage: Optional[torch.dtype] = None):
     """ResNetSegCls.forward (med3d.py:270-285) / ResNetSegReg.forward (:369-388).
+
+    ``storage`` (optional, e.g. torch.bfloat16): evaluate the SAME graph with activations and convolution weights
+    rounded once to that type wherever the build's bf16 storage path stores them (see ``q``), in whatever precision
+    ``sd`` / ``x`` carry -- the yardstick of the bf16 path that does not inherit bf16's own conditioning.
 
     ``sd``: state_dict-keyed tensors (reference key names).  Returns
     (dense_outs, outs) exactly like the reference.  ``taps`` (optional dict)
     receives named intermediate activations for layer-level tests.  ``pins`` (optional) forces
     every ReLU / max-pool decision (see ``relu`` / ``max_pool3``).
     """
+    global _STORAGE
+    prev, _STORAGE = _STORAGE, storage
+    try:
+        return _forward(sd, x, lungs, arch, train, new_stats, taps, pins)
+    finally:
+        _STORAGE = prev
+
+
+def _forward(sd, x, lungs, arch, train, new_stats, taps, pins):
     net, head = split_arch(arch)
     kind, layers = ARCHS[net]
     e = EXPANSION[kind]
@@ -206,8 +248,8 @@ def forward(sd: Dict[str, Tensor], x: Tensor, lungs: Optional[Tensor], arch: str
     B = x.shape[0]
     ns = new_stats
 
-    x = F.conv3d(x, sd["conv1.weight"], None, 2, 3)                     # :272 / :371
-    x = relu(batch_norm(x, sd, "bn1", train, ns), pins, "bn1")          # :273-274
+    x = q(F.conv3d(q(x), q(sd["conv1.weight"]), None, 2, 3))            # :272 / :371
+    x = q(relu(batch_norm(x, sd, "bn1", train, ns), pins, "bn1"))       # :273-274
     xp = max_pool3(x, pins)                                             # :275
     feats = []
     h = xp
@@ -222,8 +264,8 @@ def forward(sd: Dict[str, Tensor], x: Tensor, lungs: Optional[Tensor], arch: str
     x1, x4 = feats[0], feats[3]
     xup1 = up_block(x4, x1, sd, "us1", 2, train, ns, pins)              # :280 / :379
     xup2 = up_block(xup1, x, sd, "us2", 2, train, ns, pins)             # :281 / :380 (skip = post-ReLU stem)
-    xup3 = F.conv3d(xup2, sd["us3.0.weight"], sd["us3.0.bias"], 1, 1)   # :282 / :381
-    xup3 = relu(batch_norm(xup3, sd, "us3.1", train, ns), pins, "us3.1")
+    xup3 = q(F.conv3d(xup2, q(sd["us3.0.weight"]), sd["us3.0.bias"], 1, 1))   # :282 / :381
+    xup3 = q(relu(batch_norm(xup3, sd, "us3.1", train, ns), pins, "us3.1"))
     if taps is not None:
         taps.update(stem=x, xp=xp, x1=feats[0], x2=feats[1], x3=feats[2], x4=x4,
                     xup1=xup1, xup2=xup2, xup3=xup3)

@@ -397,9 +397,11 @@ def test_network_train_step_bf16_storage(factory, shape, mode):
         # (the 16x64x64 ResNet-50 fixture: 1.5e-1 for the reference's autocast arithmetic too -- its stride-8 stages hold
         # 128 voxels, every BatchNorm statistic there is a 128-sample estimate of bf16-rounded values)
         assert e <= max(2e-2, 1.2 * e_ref)
-        # ABSOLUTE bar next to the relative one (1.5 x the measured 1.5-1.9e-1 of the ResNet-50 fixture; 2e-2 else), so a
-        # regression cannot hide behind the reference's own bf16 error on an ill-conditioned fixture
-        assert e <= (2.8e-1 if factory.startswith("resnet50") else 2e-2)
+        # ABSOLUTE bar next to the relative one for ResNet-18.  The ResNet-50 fixture is a SMOKE case in bf16 (its
+        # stride-8 stages hold 384 voxels: an absolute bar on it would have to sit at 2.8e-1 and hold nothing); the
+        # absolute ResNet-50 bars are test_resnet50_bf16_mid_size_vs_oracle's, at a size where BatchNorm is conditioned
+        if not factory.startswith("resnet50"):
+            assert e <= 2e-2
     # BN running statistics follow the same batch statistics
     ns = {}
     orc.forward(dict(sd0), x, lungs, factory, train=True, new_stats=ns)
@@ -437,9 +439,182 @@ def test_network_train_step_bf16_storage(factory, shape, mode):
         # multiplies bf16 operands here and every activation is ROUNDED to bf16 between layers, which the reference's
         # CPU autocast -- fp32 BatchNorm outputs -- does not do; 1.5x held while the strided convolution ran in fp32)
         assert e <= max(1e-1, 2.0 * e_ref), f"{n}: bf16-storage gradient vs decision-pinned fp64 oracle {e:.2e} (reference autocast vs its fp32 self: {e_ref:.2e})"
-        # absolute cap: 1.5 x the worst measured tensor (ResNet-50 fixture: 0.94 at layer1.1.bn1.weight; ResNet-18: 9.3e-2)
-        assert e <= (1.4 if factory.startswith("resnet50") else 1.4e-1), f"{n}: {e:.2e} above the absolute bar"
+        # absolute cap for ResNet-18: 1.5 x the worst measured tensor (9.3e-2); ResNet-50 at this size: smoke (see above)
+        if not factory.startswith("resnet50"):
+            assert e <= 1.4e-1, f"{n}: {e:.2e} above the absolute bar"
     print(f"[{factory} bf16] worst gradient vs decision-pinned fp64 oracle (hip, reference-autocast-vs-fp32, tensor): {worst}")
+
+
+# ResNet-50, bf16 storage, 1x64x128x128, END TO END against the storage-aware fp64 oracle (measured, round 5: pooled scores
+# 2.8e-3 / 9.7e-4, dRAM volumes 9.3e-2 / 1.28e-1, worst gradient 2.2e-1 (bn1.bias), median 1.1e-1; against the fp32 oracle
+# the same run sits at 2.0e-1 / 2.8e-1 -- exactly where the reference's own autocast arithmetic sits, 1.98e-1 / 2.79e-1).
+# Config 2's bars (1e-3 / 4e-2) are not attainable end to end by ANY bf16 arithmetic on this model: a rounding TIE that
+# falls differently in two correct implementations is amplified like any other rounding.  The un-amplified statement is
+# test_resnet50_bf16_every_unit_vs_oracle_teacher_forced (one rounding per unit); these are the end-to-end caps.
+R50_MID_POOLED_BAR = 4e-3    # max-relative, pooled regression scores
+R50_MID_DENSE_BAR = 1.6e-1   # relative L2, dRAM volumes (1.25 x measured; half the distance to the fp32 oracle)
+R50_MID_GRAD_BAR = 3e-1      # per-tensor relative L2 of the parameter gradients (1.35 x measured)
+
+
+def test_resnet50_bf16_mid_size_vs_oracle():
+    """ResNet-50 + dRAM head (the reference's default model, reference train.py:22) in bf16 storage (Lightning
+    `--precision bf16`, train.py:46; BASELINE configs[4]'s precision) at 1x64x128x128 -- stride-8 stages of 8x16x16 =
+    2,048 voxels, so every BatchNorm has a conditioned statistic -- with ABSOLUTE bars.
+
+    Yardstick.  A randomly initialised ResNet-50 amplifies ANY bf16 rounding by ~100x through its 54 BatchNorm layers:
+    against the fp32 oracle the dRAM volumes sit 2.0e-1 / 2.8e-1 (relative L2) away -- and the reference's own arithmetic
+    under CPU autocast(bfloat16) sits 2.0e-1 / 2.8e-1 away as well (printed below), so no bar against the fp32 forward
+    can hold anything for this model.  The oracle is therefore evaluated in fp64 WITH the build's storage roundings
+    (oracle.forward(storage=bfloat16): input, convolution weights, every stored activation rounded once to bf16; statistics,
+    affine parameters and heads exact) on the HIP forward's own ReLU / max-pool decisions: what is left between the two
+    is accumulation order, bf16 rounding ties, the other rounding points of us1's first convolution (csrc/upmix.hip) and
+    -- for the gradients -- the bf16 rounding of the activation GRADIENTS, which the oracle's backward does not do; all of
+    it amplified by the network.  Bars: R50_MID_* above (absolute)."""
+    from bodyct_dram_emph_subtype_amd.engine import forward_decisions
+    factory = "resnet50segreg"
+    m = _build(factory, 5)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    names = [n for n, _ in m.named_parameters()]
+    g = torch.Generator().manual_seed(11)
+    shape = (1, 1, 64, 128, 128)
+    x = torch.randn(*shape, generator=g)
+    zz, yy, xx = torch.meshgrid(torch.linspace(-1, 1, 64), torch.linspace(-1, 1, 128), torch.linspace(-1, 1, 128), indexing="ij")
+    lungs = (((zz / 0.8) ** 2 + (yy / 0.7) ** 2 + (xx / 0.8) ** 2) <= 1.0).float()[None, None]
+    m = m.to(DEV).train()
+    m.storage_dtype = BF
+    dense, outs = m(x.to(DEV), lungs.to(DEV))
+    saved = dense[0].grad_fn.saved_state
+    assert saved["xs"].dtype == BF and saved["xup3"].dtype == BF
+    pins = {k: v.cpu() for k, v in forward_decisions(saved).items()}
+    _loss(dense, outs, False).backward()
+    torch.cuda.synchronize()
+    # context: the fp32 oracle, and the reference's own arithmetic under `--precision bf16` (CPU autocast)
+    with torch.no_grad():
+        d32, o32 = orc.forward(dict(sd0), x, lungs, factory, train=True)
+        with torch.autocast("cpu", dtype=BF):
+            dac, oac = orc.forward(dict(sd0), x, lungs, factory, train=True)
+    print(f"[resnet50 bf16 1x64x128x128] vs the fp32 oracle: pooled scores "
+          f"{[float((a.detach().cpu() - b).abs().max() / b.abs().max()) for a, b in zip(outs, o32)]} (reference autocast: "
+          f"{[float((r.float() - b).abs().max() / b.abs().max()) for r, b in zip(oac, o32)]}); dRAM volumes relative L2 "
+          f"{[rel_l2(a.detach().cpu(), b) for a, b in zip(dense, d32)]} (reference autocast: "
+          f"{[rel_l2(r.float(), b) for r, b in zip(dac, d32)]})")
+
+    def pinned(storage):
+        lv = {k: (v.clone().double().requires_grad_(True) if k in names else (v.clone().double() if v.is_floating_point() else v.clone()))
+              for k, v in sd0.items()}
+        d, o = orc.forward(lv, x.double(), lungs.double(), factory, train=True, pins=pins, storage=storage)
+        _loss(d, o, False).backward()
+        return [t.detach() for t in d], [t.detach() for t in o], {n: lv[n].grad for n in names}
+    d_st, o_st, g_st = pinned(BF)            # THE yardstick: fp64 arithmetic, the build's storage roundings
+    _, _, g_plain = pinned(None)             # (context: the fp64 oracle without them)
+    e_pool = [float((a.detach().cpu().double() - b).abs().max() / b.abs().max()) for a, b in zip(outs, o_st)]
+    e_dense = [rel_l2(a.detach().cpu(), b) for a, b in zip(dense, d_st)]
+    errs, errs_plain = [], []
+    for n, p in m.named_parameters():
+        if n.endswith(".0.bias") and n.startswith("us"):
+            continue
+        errs.append((rel_l2(p.grad.cpu(), g_st[n]), n))
+        errs_plain.append((rel_l2(p.grad.cpu(), g_plain[n]), n))
+    errs.sort(reverse=True)
+    errs_plain.sort(reverse=True)
+    print(f"[resnet50 bf16 1x64x128x128] vs the storage-aware fp64 oracle on the same decisions: pooled scores {e_pool}, "
+          f"dRAM volumes relative L2 {e_dense}; gradients worst {errs[:3]}, median {errs[len(errs) // 2][0]:.2e} "
+          f"(against the fp64 oracle WITHOUT the storage roundings: worst {errs_plain[0]}, median {errs_plain[len(errs_plain) // 2][0]:.2e})")
+    assert max(e_pool) <= R50_MID_POOLED_BAR and max(e_dense) <= R50_MID_DENSE_BAR
+    assert errs[0][0] <= R50_MID_GRAD_BAR, f"{errs[0][1]}: {errs[0][0]:.2e}"
+
+
+def _ncdhw(t):
+    return t.detach().float().permute(0, 4, 1, 2, 3).contiguous().cpu().double()
+
+
+def test_resnet50_bf16_every_unit_vs_oracle_teacher_forced():
+    """The end-to-end comparison above carries the network's own amplification of a rounding (ResNet-50 at a random
+    initialisation: ~100x).  This one does not: every convolution + BatchNorm (+ residual) + ReLU unit of the SAME
+    1x64x128x128 bf16 forward is checked on its own -- the oracle's arithmetic (fp64 F.conv3d on the bf16-rounded
+    weights, batch statistics of the rounded output, affine + residual + ReLU, one rounding per stored tensor: reference
+    med3d.py:121-124, 153-159, 164-184, 85-89) applied to the INPUT THE HIP UNIT ITSELF READ (its saved bf16 tensor) must
+    reproduce the unit's stored pre-BatchNorm output, its batch mean / inverse standard deviation and its stored
+    activation.  What may differ is a bf16 rounding tie (one ulp = 2^-8 relative on an element whose exact value lies
+    within accumulation error of a rounding boundary): relative L2 <= UNIT_TOL per tensor, statistics <= 1e-4.
+    Covers all 16 Bottleneck blocks (1x1x1, 3x3x3 dilated, the stride-2 convolution through space-to-depth, shortcut-A
+    and identity residuals), both decoder blocks (us1's first convolution runs WITHOUT the up-sampled tensor --
+    csrc/upmix.hip, other rounding points: UPMIX_TOL), us3 and the stem."""
+    import torch.nn.functional as F
+    factory = "resnet50segreg"
+    m = _build(factory, 5)
+    sd0 = {k: v.clone().double() if v.is_floating_point() else v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 1, 64, 128, 128, generator=g)
+    m = m.to(DEV).train()
+    m.storage_dtype = BF
+    dense, outs = m(x.to(DEV), None)
+    saved = dense[0].grad_fn.saved_state
+    UNIT_TOL, UPMIX_TOL, STAT_TOL = 3e-3, 2e-2, 1e-4
+
+    def qd(t):
+        return t.to(BF).double()
+
+    worst = {"y": (0.0, ""), "z": (0.0, ""), "stat": (0.0, "")}
+
+    def check(kind, name, got, ref, tol):
+        e = rel_l2(got, ref)
+        worst[kind] = max(worst[kind], (e, name))
+        assert e <= tol, f"{name} [{kind}]: {e:.2e} > {tol:g}"
+
+    def unit(c, xin, res=None, z=None):
+        """conv -> y (stored), batch statistics, BN + residual + ReLU -> z (stored by the unit, or -- a unit whose
+        BatchNorm-apply was left to its consumer -- the tensor that consumer materialised and read)"""
+        geo = c["g"]
+        w = qd(sd0[c["w"]])
+        b = sd0[c["b"]] if c["b"] else None
+        y_ref = qd(F.conv3d(xin, w, b, geo.stride, geo.pad, geo.dil))
+        y = _ncdhw(c["y"])
+        check("y", c["w"], y, y_ref, UNIT_TOL)
+        bn_z(c, y, res, z)
+
+    def bn_z(c, y, res, z=None):
+        mean, var = y.mean((0, 2, 3, 4)), y.var((0, 2, 3, 4), unbiased=False)
+        check("stat", c["bn"] + ".mean", c["mean"].cpu().double(), mean, STAT_TOL)
+        check("stat", c["bn"] + ".invstd", c["invstd"].cpu().double(), torch.rsqrt(var + 1e-5), STAT_TOL)
+        z = c.get("z") if c.get("z") is not None else z
+        assert z is not None, c["bn"]
+        sh = (1, -1, 1, 1, 1)
+        zz = (y - mean.view(sh)) * torch.rsqrt(var.view(sh) + 1e-5) * sd0[c["bn"] + ".weight"].view(sh) + sd0[c["bn"] + ".bias"].view(sh)
+        if res is not None:
+            zz = zz + res
+        check("z", c["bn"], _ncdhw(z), qd(torch.relu(zz)), UNIT_TOL)
+
+    # stem (reference med3d.py:371-373)
+    y0 = _ncdhw(saved["y0"])
+    check("y", "conv1.weight", y0, qd(F.conv3d(qd(x), qd(sd0["conv1.weight"]), None, 2, 3)), UNIT_TOL)
+    bn_z(dict(bn="bn1", mean=saved["mean0"], invstd=saved["invstd0"], z=saved["xs"]), y0, None)
+    # Bottleneck blocks (med3d.py:164-184)
+    for c1, c2, c3, has_ds in saved["blocks"]:
+        xin = _ncdhw(c1["x"])
+        unit(c1, xin, z=c2["x"])
+        unit(c2, _ncdhw(c2["x"]), z=c3["x"])
+        if has_ds:
+            res = orc.shortcut_a(xin, c3["g"].Cout, c2["g"].stride)
+        else:
+            res = xin
+        unit(c3, _ncdhw(c3["x"]), res)
+    # decoder (med3d.py:85-89): us1 without the up-sampled tensor, us2 on the materialised concat, us3
+    for key in ("cu1", "cu2"):
+        ca, cb = saved[key][:2]
+        if ca.get("kind") == "upmix":
+            cat = orc.crop_concat(qd(orc.upsample2_trilinear(_ncdhw(ca["src"]))), _ncdhw(ca["skip"]))
+            y_ref = qd(F.conv3d(cat, qd(sd0[ca["w"]]), sd0[ca["b"]], 1, 1))
+            ya = _ncdhw(ca["y"])
+            check("y", ca["w"] + " (upmix)", ya, y_ref, UPMIX_TOL)
+            bn_z(ca, ya, None, cb["x"])
+        else:
+            unit(ca, _ncdhw(ca["x"]), z=cb["x"])
+        unit(cb, _ncdhw(cb["x"]), z=(saved["cu2"][0]["src"] if (key == "cu1" and saved["cu2"][0].get("kind") == "upmix") else None)
+             if cb.get("z") is None else None)
+    unit(saved["cu3"], _ncdhw(saved["cu3"]["x"]), z=saved["xup3"])
+    print(f"[resnet50 bf16 1x64x128x128, every unit on its own stored input] worst pre-BN output {worst['y']}, "
+          f"worst activation {worst['z']}, worst statistic {worst['stat']}")
 
 
 def test_bf16_eval_forward_and_train_steps_run_the_optimizer():

@@ -152,11 +152,16 @@ def _nccl_world1(port, outdir):
     try:
         from bodyct_dram_emph_subtype_amd import distributed as ddist
         out = {}
-        for forced in (False, True):
+        for forced in (False, True, "torch"):
+            # True: the context's OWN RCCL communicators (rccl.py: ncclAllReduce on the data stream / a forked bucket
+            # stream); "torch": the same collectives through torch.distributed's ProcessGroupNCCL (A/B switch)
+            os.environ["DRAM_DIST_TRANSPORT"] = "torch" if forced == "torch" else "rccl"
             torch.manual_seed(4)
             m = _build("resnet18segreg").to("cuda:0").train()
-            ctx = ddist.attach(m, bucket_bytes=8 << 20, force=forced)
-            assert (m._dist is not None) == forced
+            ctx = ddist.attach(m, bucket_bytes=8 << 20, force=bool(forced))
+            assert (m._dist is not None) == bool(forced)
+            if forced:
+                assert (ctx._stat is not None) == (forced is True) and ctx.capturable == (forced is True)
             x, lungs = _inputs(1)
             for _ in range(2):                       # two steps: the arena / state is rebuilt every backward
                 m.zero_grad(set_to_none=True)
@@ -176,12 +181,83 @@ def test_rccl_world1_forced_collectives_equal_plain_step():
     with tempfile.TemporaryDirectory() as outdir:
         _run_ranks([ctx.Process(target=_nccl_world1, args=(35500 + (os.getpid() % 2000), outdir))])
         out = torch.load(os.path.join(outdir, "w1.pt"))
-    (g0, s0, st0), (g1, s1, st1) = out[False], out[True]
-    assert st0["bn_allreduce"] == 0 and st1["bn_allreduce"] == 2 * 2 * 22 and st1["grad_allreduce"] >= 2 * 2
-    for n in g0:
-        assert torch.equal(g0[n], g1[n]), n
-    for k in s0:
-        assert torch.equal(s0[k], s1[k]), k
+    (g0, s0, st0) = out[False]
+    assert st0["bn_allreduce"] == 0
+    for mode in (True, "torch"):
+        g1, s1, st1 = out[mode]
+        assert st1["bn_allreduce"] == 2 * 2 * 22 and st1["grad_allreduce"] >= 2 * 2
+        for n in g0:
+            assert torch.equal(g0[n], g1[n]), (mode, n)
+        for k in s0:
+            assert torch.equal(s0[k], s1[k]), (mode, k)
+
+
+def _nccl_world1_graph(port, outdir):
+    """The data-parallel step captured into ONE hipGraph with its collectives (own RCCL communicators: plain stream
+    work): three replays against three eager data-parallel steps and three plain steps, from the same state."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from bodyct_dram_emph_subtype_amd import distributed as ddist
+        from bodyct_dram_emph_subtype_amd.graph import GraphedTrainStep
+        from bodyct_dram_emph_subtype_amd.optim import FusedAdam
+        x, lungs = _inputs(1)
+        batch = (x.cuda(), lungs.cuda())
+        out = {}
+        for mode in ("plain", "dp-eager", "dp-graph"):
+            for storage in (torch.float32, torch.bfloat16):
+                torch.manual_seed(4)
+                m = _build("resnet18segreg").to("cuda:0").train()
+                m.storage_dtype = storage
+                ctx = ddist.attach(m, bucket_bytes=8 << 20, force=(mode != "plain"))
+                opt = FusedAdam(m.parameters(), lr=1e-3, capturable=True)
+
+                def loss_fn(xx, ll, m=m):
+                    dense, outs = m(xx, ll)
+                    return _loss(0, dense, outs)
+
+                def eager(*b, opt=opt, loss_fn=loss_fn):
+                    opt.zero_grad(set_to_none=True)
+                    loss = loss_fn(*b)
+                    loss.backward()
+                    opt.step()
+                    return loss.detach()
+                if mode == "dp-graph":
+                    step = GraphedTrainStep(m, opt, loss_fn, batch, warmup=2)
+                    assert step.graph is not None, "the data-parallel step was not captured"
+                else:
+                    eager(*batch); eager(*batch)
+                    step = eager
+                before = dict(ctx.stats)
+                for _ in range(3):
+                    loss = step(*batch).clone()
+                torch.cuda.synchronize()
+                out[(mode, str(storage))] = (float(loss), {k: v.cpu() for k, v in m.state_dict().items()}, before, dict(ctx.stats))
+        torch.save(out, os.path.join(outdir, "w1g.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world1_data_parallel_step_captured_in_a_hipgraph():
+    import tempfile
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as outdir:
+        _run_ranks([ctx.Process(target=_nccl_world1_graph, args=(35700 + (os.getpid() % 2000), outdir))])
+        out = torch.load(os.path.join(outdir, "w1g.pt"))
+    for storage in ("torch.float32", "torch.bfloat16"):
+        lp, sp, _, _ = out[("plain", storage)]
+        for mode in ("dp-eager", "dp-graph"):
+            l, sd, st_before, st_after = out[(mode, storage)]
+            assert l == lp, (mode, storage, l, lp)
+            for k in sp:
+                assert torch.equal(sd[k], sp[k]), (mode, storage, k)
+            # eager steps issue their collectives every step; a replayed graph issues none from the host
+            issued = st_after["bn_allreduce"] - st_before["bn_allreduce"]
+            assert issued == (3 * 2 * 22 if mode == "dp-eager" else 0), (mode, issued)
 
 
 def _nccl_worker(rank, world, port, outdir):
@@ -273,7 +349,12 @@ def test_bench_line_is_alone_on_stdout_with_rccl_up():
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["host_issue_ms_per_step"] > 0
-    assert rec["collectives_per_step"]["bn_allreduce"] == 2 * 38 and rec["exposed_collective_ms"] >= 0
+    # config 0 replays a hipGraph by default, data parallel too: the host issues the collectives of the two warm-up
+    # steps and of the capture only (per-step counts are those of the eager second pass)
+    assert rec["collective_transport"] == "rccl-c-api" and rec["config"]["hip_graph"] is True
+    assert rec["collectives_per_step"]["bn_allreduce"] > 0
+    assert abs(rec["exposed_collective_ms"] - (rec["ms_per_step"] - rec["plain_ms_per_step"])) < 1e-6
+    assert rec["stat_exchange_ms_bracketed"] >= 0
 
 
 def test_two_rank_bf16_storage_matches_ddp_syncbn_emulation():

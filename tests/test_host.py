@@ -357,3 +357,17 @@ def test_streaming_kernels_carry_no_hidden_lds_or_spills():
         if not name.startswith(("upcat_fwd_tiled_kernel", "upproject_kernel")):       # the two kernels that declare LDS
             assert lds == 0, l
         assert vgpr <= 128, l
+
+
+def test_rccl_c_api_binding_loads_every_symbol_it_calls():
+    """rccl.py binds librccl's C API by ctypes (the data-parallel transport under the nccl backend): the library torch
+    ships must load here and export every entry point the module calls, with the by-value ncclUniqueId of rccl.h:40-43."""
+    import ctypes
+    from bodyct_dram_emph_subtype_amd import rccl
+    L = rccl.lib()
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommAbort", "ncclAllReduce", "ncclBroadcast",
+                 "ncclGetErrorString"):
+        assert getattr(L, name) is not None, name
+    assert ctypes.sizeof(rccl._UniqueId) == rccl.NCCL_UNIQUE_ID_BYTES == 128
+    assert (rccl.SUM, rccl.AVG) == (0, 4) and rccl._DTYPES[__import__("torch").float64] == 8
+    assert b"success" in L.ncclGetErrorString(0).lower() or L.ncclGetErrorString(0)

@@ -35,6 +35,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 NET_FILES = sorted(glob.glob(os.path.join(GOLDEN, "net_*.npz")))
 OUT_TOL = 1e-3
+OUT_HEADROOM = 8e-4      # full-size outputs: the 1e-3 bar with 20 % of headroom, so a plan change that eats the margin fails loudly
 NORM_TOL = 3e-2
 GRAD_TOL = 1e-4          # decision-pinned gradients vs the fp64 oracle, per tensor, relative L2
 DENSE_L2_TOL = 1e-4      # dense maps vs the reference's recorded ones, relative L2 (element-wise, unlike the max-norm bar)
@@ -105,6 +106,7 @@ def assert_close_rel(a, b, tol, what):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
     assert err < tol, f"{what}: max-rel {err:.3e} >= {tol}"
+    return float(err)
 
 
 # every golden network on the library's own plan, and once more with the Winograd path forced
@@ -285,7 +287,8 @@ def _oracle_backward(sd0, names, factory, x, lungs, pins, upstream, dtype):
     lv = {k: (v.clone().to(dtype).requires_grad_(True) if k in names
               else (v.clone().to(dtype) if v.is_floating_point() else v.clone())) for k, v in sd0.items()}
     d, o = orc.forward(lv, x.to(dtype), None if lungs is None else lungs.to(dtype), factory, train=True, pins=pins)
-    torch.autograd.backward(d + o, [u.to(dtype) for u in upstream])
+    pairs = [(t, u.to(dtype)) for t, u in zip(d + o, upstream) if u is not None]
+    torch.autograd.backward([t for t, _ in pairs], [u for _, u in pairs])
     return {n: lv[n].grad.double() for n in names}
 
 
@@ -313,19 +316,25 @@ def _dram_loss_checks(models, dd, od, lungs, ems, cle, pse, cw, pw):
     return loss, ups
 
 
-@pytest.mark.parametrize("factory", ["resnet18segreg", "resnet50segreg"])
+R50_DRAM_GRAD_TOL = 3e-4
+
+
+@pytest.mark.parametrize("factory", ["resnet34segcls", "resnet18segreg", "resnet50segreg"])
 def test_mid_size_train_step_vs_oracle(factory):
-    """1x64x128x128 (BASELINE configs[0] volume), full dRAM train loss through the fused loss kernels, on the
+    """1x64x128x128 (BASELINE configs[0] volume).  resnet34segcls IS configs[0] (conf/med3d.yaml:1, batch 1, class-
+    weighted CE of reference models.py:253-258); the two regression networks run the
+    full dRAM train loss through the fused loss kernels, on the
     library's OWN plan: S2 = 8x16x16 = 2,048 voxels, so for ResNet-50 the 1x1x1 convolutions run as plain
     GEMMs (plan 3) and the 2304->64 decoder convolution runs the Winograd pipeline unforced.
     Outputs 1e-3 vs the fp32 oracle; loss + its gradient fields (see _dram_loss_checks); then the network backward
     of exactly those fields: HIP vs the decision-pinned fp64 oracle given the same upstream, every parameter
-    <= max(GRAD_TOL, 3 x the CPU fp32 oracle's own distance), at most 2e-3 (the outlier-dominated upstream field
-    makes the weight-gradient sums cancel: CPU fp32 itself sits 2e-5 (R18) / 3e-4 (R50) from fp64)."""
+    <= GRAD_TOL (ResNet-18 / -34) or R50_DRAM_GRAD_TOL (absolute bars; the CPU fp32 oracle's own distance from fp64
+    on the same piece is printed next to it: 2e-5 (R18) / 7e-5 (R50))."""
     from bodyct_dram_emph_subtype_amd import med3d, models
     dims = (64, 128, 128)
+    cls = factory.endswith("cls")
     torch.manual_seed(5)
-    m = getattr(med3d, factory)()
+    m = getattr(med3d, factory)(**(dict(n_classes=[6, 3]) if cls else {}))
     sd0 = {k: v.clone() for k, v in m.state_dict().items()}
     names = [n for n, _ in m.named_parameters()]
     x, lungs = _synthetic(1, dims, 11)
@@ -337,26 +346,40 @@ def test_mid_size_train_step_vs_oracle(factory):
     md = m.to(DEV).train()
     dd, od = md(x.to(DEV), lungs.to(DEV))
     pins = pinned_decisions(dd[0])
+    worst_out = 0.0
     for a, b in zip(od, o32):
-        assert_close_rel(a.detach().cpu(), b, OUT_TOL, "regression score")
+        worst_out = max(worst_out, assert_close_rel(a.detach().cpu(), b, OUT_TOL, "class logits" if cls else "regression score"))
     for a, b in zip(dd, d32):
-        assert_close_rel(a.detach().cpu(), b, OUT_TOL, "dRAM volume")
-    loss, ups = _dram_loss_checks(models, dd, od, lungs, ems, cle, pse, cw, pw)
+        worst_out = max(worst_out, assert_close_rel(a.detach().cpu(), b, OUT_TOL, "dense map"))
+    if cls:
+        cwt, pwt = torch.tensor([.1, .2, .1, .3, .2, .1]), torch.tensor([.5, .2, .3])
+        loss = models.cls_train_loss(od, cle.to(DEV), pse.to(DEV), cwt.to(DEV), pwt.to(DEV))[0]
+        ups = [None, None] + [u.detach().cpu() for u in torch.autograd.grad(loss, od, retain_graph=True)]
+        l_ref = orc.cls_train_loss([t.detach().cpu() for t in od], cle, pse, cwt, pwt)[0]
+        assert abs(float(loss) - float(l_ref)) < OUT_TOL * max(1.0, abs(float(l_ref)))
+    else:
+        loss, ups = _dram_loss_checks(models, dd, od, lungs, ems, cle, pse, cw, pw)
     loss.backward()
     g64 = _oracle_backward(sd0, names, factory, x, lungs, pins, ups, torch.float64)
     g32 = _oracle_backward(sd0, names, factory, x, lungs, pins, ups, torch.float32)
     worst = (0.0, 0.0, "")
+    table = []
     for n, p in md.named_parameters():
         if is_noise_param(n):
             continue
         e, e_cpu = rel_l2(p.grad.double().cpu(), g64[n]), rel_l2(g32[n], g64[n])
         worst = max(worst, (e, e_cpu, n))
-        # ResNet-50 with the dRAM loss: ABSOLUTE bar 1.5e-3 = 1.5 x the worst measured tensor (conv1.weight, 8.4-9.5e-4
-        # over rounds 2-4) -- the CPU oracle's own distance moves with its thread count (2.7-3.8e-4), a bar that
-        # floats with it is not one
-        floor = 1.5e-3 if factory.startswith("resnet50") else GRAD_TOL
-        assert e <= min(max(floor, 3.0 * e_cpu), 2e-3), f"{n}: hip {e:.2e} vs decision-pinned fp64 oracle (CPU fp32: {e_cpu:.2e})"
-    print(f"[{factory} 1x64x128x128, dRAM loss] worst gradient error vs decision-pinned fp64 oracle (hip, cpu-fp32, tensor): {worst}")
+        table.append((e, e_cpu, n))
+        # ABSOLUTE bars (the CPU oracle's own distance from fp64 moves with its thread count: a bar that floats with
+        # it is not one): GRAD_TOL for the BasicBlock networks (measured 5.3-5.6e-5), 3e-4 for ResNet-50 under the dRAM
+        # loss = 2 x the worst measured tensor of round 5 (us1.conv_blocks.1.1.weight 1.45e-4; the CPU fp32 oracle
+        # itself sits 7.5e-5 from fp64 there).  Rounds 2-4 carried 1.5e-3 for conv1.weight (8.4-9.5e-4 then).
+        bar = R50_DRAM_GRAD_TOL if factory.startswith("resnet50") else GRAD_TOL
+        assert e <= bar, f"{n}: hip {e:.2e} vs decision-pinned fp64 oracle (CPU fp32: {e_cpu:.2e})"
+    table.sort(reverse=True)
+    print(f"[{factory} 1x64x128x128] per-tensor gradient errors, largest five (hip, cpu-fp32, tensor): {table[:5]}")
+    print(f"[{factory} 1x64x128x128, {'CE' if cls else 'dRAM'} loss] worst output vs the fp32 oracle {worst_out:.2e}; worst gradient "
+          f"error vs decision-pinned fp64 oracle (hip, cpu-fp32, tensor): {worst}")
 
 
 FULL_CASES = {
@@ -432,8 +455,9 @@ def test_full_size_train_step_vs_oracle(config):
     lv = {k: (v.to(dt).requires_grad_(True) if k in names else (v.to(dt) if v.is_floating_point() else v))
           for k, v in sd0.items()}
     d, o = orc.forward(lv, x.to(dt), lungs.to(dt), factory, train=True, pins=pins)
+    worst_out = 0.0
     for a, b in zip(outs_hip + dense_hip, o + d):
-        assert_close_rel(a, b.detach(), OUT_TOL, "pooled output / dense map")
+        worst_out = max(worst_out, assert_close_rel(a, b.detach(), OUT_HEADROOM, "pooled output / dense map"))
     pairs = [(t, u.to(dt)) for t, u in zip(d + o, ups) if u is not None]
     torch.autograd.backward([t for t, _ in pairs], [u for _, u in pairs])
     worst = (0.0, "")
@@ -444,7 +468,8 @@ def test_full_size_train_step_vs_oracle(config):
         e = rel_l2(got[n], lv[n].grad)
         worst = max(worst, (e, n))
         assert e <= bar, f"{n}: full-size gradient vs decision-pinned fp64 oracle {e:.2e}"
-    print(f"[config {config} full size] loss {loss_hip:.6f}; worst gradient vs decision-pinned fp64 oracle {worst}")
+    print(f"[config {config} full size] loss {loss_hip:.6f}; worst output (pooled / dense, max-rel vs the pinned fp64 oracle) "
+          f"{worst_out:.2e} (bar {OUT_HEADROOM:g}); worst gradient vs decision-pinned fp64 oracle {worst}")
     if config == 1:
         # decision INDEPENDENCE at full size (the headline configuration, where the full-size-only launch shapes run):
         # the free-running fp32 oracle's own ReLU / max-pool decisions against the ones the HIP forward took -- every

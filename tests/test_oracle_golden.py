@@ -248,3 +248,38 @@ def test_augmentations_match_reference():
     m4 = orc.crop_and_resize(m3, g["crop_center"].tolist(), g["crop_size"].tolist(), mask=True)
     assert torch.allclose(a4, torch.from_numpy(g["after_crop"]), atol=1e-6)
     assert torch.equal(m4, torch.from_numpy(g["mask_after_crop"]))
+
+
+def test_storage_rounding_mode_of_the_oracle():
+    """oracle.forward(storage=bfloat16): the same graph with the build's bf16 storage roundings (tests/test_bf16_gpu.py's
+    yardstick for ResNet-50).  storage=None is the golden-checked path bit for bit; with bf16 every stored activation is
+    representable in bf16, the pooled scores of a ResNet-18 stay within 2e-3 and its dense maps within 3e-2 of the
+    fp32 forward (measured 1.1e-3 / 2.2e-2 on this 16x32x32 fixture; torch's CPU autocast: 1.3e-3 / 2.2e-2), and the rounding is
+    straight-through for gradients (every parameter receives one)."""
+    torch.manual_seed(0)
+    factory = "resnet18segreg"
+    import importlib
+    med3d = importlib.import_module("bodyct_dram_emph_subtype_amd.med3d")
+    m = med3d.resnet18segreg()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    names = [n for n, _ in m.named_parameters()]
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 1, 16, 32, 32, generator=g)
+    lungs = (torch.rand(1, 1, 16, 32, 32, generator=g) > 0.3).float()
+    with torch.no_grad():
+        d0, o0 = orc.forward(dict(sd), x, lungs, factory, train=True)
+        d1, o1 = orc.forward(dict(sd), x, lungs, factory, train=True, storage=None)
+        taps = {}
+        d2, o2 = orc.forward(dict(sd), x, lungs, factory, train=True, storage=torch.bfloat16, taps=taps)
+    assert all(torch.equal(a, b) for a, b in zip(d0 + o0, d1 + o1))
+    assert orc._STORAGE is None
+    for k in ("stem", "x1", "x4", "xup3"):
+        assert torch.equal(taps[k], taps[k].bfloat16().float()), k
+    for a, b in zip(o2, o0):
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-3
+    for a, b in zip(d2, d0):
+        assert float((a - b).norm() / b.norm()) < 3e-2 and not torch.equal(a, b)
+    lv = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in sd.items()}
+    d, o = orc.forward(lv, x, lungs, factory, train=True, storage=torch.bfloat16)
+    (o[0].sum() + 0.1 * (d[0] * d[1]).mean()).backward()
+    assert all(lv[n].grad is not None and torch.isfinite(lv[n].grad).all() for n in names)
