@@ -20,7 +20,7 @@ P, I, LL, F, D, SZ = c_void_p, c_int, c_longlong, c_float, c_double, c_size_t
 
 class DramConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
-                ("B", "D", "H", "W", "Cin", "Do", "Ho", "Wo", "Cout", "k", "stride", "pad", "dil")]
+                ("B", "D", "H", "W", "Cin", "Do", "Ho", "Wo", "Cout", "k", "stride", "pad", "dil", "flags")]
 
 
 class DramTensorRef(ctypes.Structure):
@@ -91,6 +91,7 @@ SIGNATURES = {
     "dram_wino_v_elems": (SZ, [DP]),
     "dram_wino_conv3d_fwd": (I, [P, P, P, P, P, P, DP, P, SZ, P]),
     "dram_wino_prologue_supported": (I, [DP]),
+    "dram_wino_conv3d_fwd_cat": (I, [P, I, P, I, P, P, P, P, P, DP, P, SZ, P]),
     "dram_wino_conv3d_fwd_bn": (I, [P, P, P, P, P, P, P, P, DP, P, SZ, P]),
     "dram_wino_conv3d_bwd_data": (I, [P, P, P, P, P, DP, P, SZ, P]),
     "dram_wino_conv3d_bwd_weight": (I, [P, P, P, P, DP, P, SZ, P]),
@@ -178,7 +179,7 @@ SIGNATURES = {
 }
 
 OPT_CHUNK = 16384
-ABI_VERSION = 5
+ABI_VERSION = 6
 _LIB = None
 
 

@@ -347,7 +347,9 @@ template <int MODE, int HX, bool SPLIT, bool NT, bool PRO = false>
 __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float* __restrict__ out, const WinoGeom& g,
                                             const int C, const int cb, const int lane, const int t, const int b,
                                             const int z0, const int y0, const int x0, const float* __restrict__ pscale = nullptr,
-                                            const float* __restrict__ pshift = nullptr) {
+                                            const float* __restrict__ pshift = nullptr, const int Cd = 0, const int cofs = 0) {
+  // Cd / cofs: the image this source's channels go into has Cd channels per row and they start at channel cofs (a
+  // convolution whose input is given as two channel blocks, dram_wino_conv3d_fwd_cat); Cd = 0: the source's own C
   constexpr int NI = 6, NJ = 6, NK = 6;
   float v[NI][NJ][3];
   const int d = g.d;
@@ -382,7 +384,19 @@ __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float
         for (int k = 0; k < NK; ++k) {
           const unsigned so = zy + xo[k];
           row[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, (int)(so + c4), 0, 0));
-          if (PRO) row[k] = so < WINO_OOB ? fmaxf(__builtin_fmaf(row[k], psc, psh), 0.f) : 0.f;     // (scalar condition)
+          // Outside the volume the result must be 0, not max(shift, 0).  NO select here: a `cond ? f(x) : 0` per element
+          // became 360 v_cndmask on scalar-derived masks, the scheduler then kept every load next to its consumer and
+          // the kernel ran with TWO loads in flight (190 s_waitcnt vmcnt in the ISA against 4 in the plain form:
+          // 700 us against 477 us on the 2x64x128x128 launch, tools/isa_waits.py).  Arithmetic instead: a scalar 0 / -3e38
+          // added to the shift drives max(0 * scale + shift', 0) to 0 for a zero-filled load and leaves shift + 0.0f
+          // = shift otherwise (bit-identical to bn_apply_kernel's fma + max).
+          // (the 0 / -3e38 term as SCALAR integer arithmetic on the offset's out-of-range bits: written as a float select
+          // the compiler moved it to the vector unit again, one v_cndmask per element)
+          if (PRO) {
+            const unsigned ob = so >> 30;
+            const float moff = __builtin_bit_cast(float, (ob < 1u ? ob : 1u) * 0xff61b1e6u);       // 0.0f, or -3.0e38f when out of range
+            row[k] = fmaxf(__builtin_fmaf(row[k], psc, psh + moff), 0.f);
+          }
         }
         bt4(row);
 #pragma unroll
@@ -462,10 +476,11 @@ __device__ __forceinline__ void wino_half444(const float* __restrict__ in, float
       }
   }
   // output: the tile's [point][t % 256][C] block; lane offset constant, point offset scalar
-  const unsigned pplane = 256u * (unsigned)C * 4u;              // bytes between two points of a tile
-  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + wino_index(t, g.npts, C), 0,
+  const int Co = Cd ? Cd : C;
+  const unsigned pplane = 256u * (unsigned)Co * 4u;             // bytes between two points of a tile
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + wino_index(t, g.npts, Co), 0,
                                                                         (int)(216u * pplane), WINO_RSRC_FLAGS);
-  const unsigned co4 = (unsigned)(SPLIT ? cb + split_pos(lane) : cb + lane) * 4u;
+  const unsigned co4 = (unsigned)(SPLIT ? cofs + cb + split_pos(lane) : cofs + cb + lane) * 4u;
   // the point offset as ONE running scalar (opaque to the optimiser: left alone it precomputes all 108 products
   // point x pplane up front and the scalar file spills into VGPR lanes)
   unsigned so = (unsigned)(3 * HX) * pplane;
@@ -489,7 +504,8 @@ template <int MODE, bool SPLIT, bool NT, bool PRO = false>
 __global__ __launch_bounds__(256, 2) void wino_in444_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                          const WinoGeom g, const int C,
                                                          const float* __restrict__ pscale = nullptr,
-                                                         const float* __restrict__ pshift = nullptr) {
+                                                         const float* __restrict__ pshift = nullptr, const int Cd = 0,
+                                                         const int cofs = 0) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: see wino_half444
   const int cblks = C >> 6;
@@ -500,10 +516,11 @@ __global__ __launch_bounds__(256, 2) void wino_in444_kernel(const float* __restr
     const int t = (int)(w / cblks);
     const int cb = (int)(w - (long)t * cblks) * 64;
     if (t >= g.T) {                        // padding rows of the GEMM M tile: zeros (the TN GEMM contracts over t)
-      const unsigned pplane = 256u * (unsigned)C * 4u;
-      const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + wino_index(t, g.npts, C), 0,
+      const int Co = Cd ? Cd : C;
+      const unsigned pplane = 256u * (unsigned)Co * 4u;
+      const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + wino_index(t, g.npts, Co), 0,
                                                                             (int)(216u * pplane), WINO_RSRC_FLAGS);
-      const unsigned co4 = (unsigned)(cb + lane) * 4u;
+      const unsigned co4 = (unsigned)(cofs + cb + lane) * 4u;
 #pragma unroll
       for (int i = 0; i < 36; ++i)
 #pragma unroll
@@ -513,8 +530,8 @@ __global__ __launch_bounds__(256, 2) void wino_in444_kernel(const float* __restr
     }
     int b, z0, y0, x0;
     tile_origin(g, t, b, z0, y0, x0);
-    if (hx == 0) wino_half444<MODE, 0, SPLIT, NT, PRO>(in, out, g, C, cb, lane, t, b, z0, y0, x0, pscale, pshift);
-    else wino_half444<MODE, 1, SPLIT, NT, PRO>(in, out, g, C, cb, lane, t, b, z0, y0, x0, pscale, pshift);
+    if (hx == 0) wino_half444<MODE, 0, SPLIT, NT, PRO>(in, out, g, C, cb, lane, t, b, z0, y0, x0, pscale, pshift, Cd, cofs);
+    else wino_half444<MODE, 1, SPLIT, NT, PRO>(in, out, g, C, cb, lane, t, b, z0, y0, x0, pscale, pshift, Cd, cofs);
   }
 }
 
@@ -1047,6 +1064,221 @@ __global__ __launch_bounds__(512) void wino_gemm_nn_kernel(const float* __restri
       for (int w = 0; w < 4; ++w) v += red[((cwn * 4 + w) * 2 + which) * 32 * NJ + c2];   // wave = wn * 4 + wm
       ep.stats[((long)mt * 2 + which) * N + nt * BN + cc] = v;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent form of wino_gemm_nn_kernel (round 5) for the matrix-bound launches.  A workgroup of the one-tile kernel
+// lives for K / 32 = 4-16 main-loop iterations: it starts with a cold pipeline (the first 48-64 KB stage is a full
+// memory round trip with nothing to compute), ends with an epilogue during which the matrix pipe idles, and the
+// launch runs in whole rounds of 256 workgroups -- the 128- / 256-channel stages of the network (432 / 864 tiles) sat
+// at 0.48 / 0.68 of the pipe where the 512-channel ones (1 728 tiles) reach 0.76.  Here gridDim.x <= 256 workgroups
+// (one per CU) walk the tiles b, b + gridDim.x, ...; the FIRST stage of a workgroup's next tile is issued under the
+// last k-group of the current one, so it lands during that k-group and the epilogue, and the next tile's MFMAs start
+// right behind the epilogue's stores.  Needs an even number of iterations (the stage parity is then the same for
+// every tile; K is a multiple of 64 everywhere in the network) and the two stages as separate LDS objects: the
+// epilogue turns its accumulators through stage 1 (16 rows per wave at a time, 37 KB) while the prefetch fills
+// stage 0, and the wait-count pass must be able to tell the two apart (wait-count traps).
+// Accumulation order, epilogue arithmetic and results are those of the one-tile kernel, bit for bit (tested).
+template <int NJ>
+__global__ __launch_bounds__(512) void wino_gemm_nn_pers_kernel(const float* __restrict__ A, const float* __restrict__ Bw,
+                                                                float* __restrict__ Y, const int Mpad, const int N,
+                                                                const int K, const int m_tiles, const int n_tiles,
+                                                                const int nblk, const int npts, const GemmEpilogue ep) {
+  constexpr int BN = 64 * NJ;
+  constexpr int STAGE = (256 + BN) * 32;
+  // (NJ = 1: 2 x 40 KB would let two persistent workgroups share a CU and leave others empty -- pad past half the LDS)
+  __shared__ __attribute__((aligned(1024))) float s0[STAGE];
+  __shared__ __attribute__((aligned(1024))) float s1[STAGE + (NJ == 1 ? 1024 : 0)];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sub = lane >> 3, pslot = lane & 7;
+  const int s_even = pslot ^ (lane >> 4), s_odd = s_even ^ 4;
+  int aoff[4], boff[NJ];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) aoff[j] = (32 * wave + 8 * j + sub) * K + ((j & 1) ? s_odd : s_even) * 4;
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int nrow = 8 * NJ * wave + 8 * jj + sub;
+    boff[jj] = nrow * K + (pslot ^ ((nrow >> 1) & 7)) * 4;
+  }
+  auto issue = [&](const float* Ab, const float* Bb, int it, float* stage) __attribute__((always_inline)) {
+    float* as = stage + 32 * wave * 32;
+    float* bs = stage + 256 * 32 + 8 * NJ * wave * 32;
+    const float* ag = Ab + it * 32;
+    const float* bg = Bb + it * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ag + aoff[j]),
+                                       (__attribute__((address_space(3))) void*)(as + j * 8 * 32), 16, 0, 0);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bg + boff[jj]),
+                                       (__attribute__((address_space(3))) void*)(bs + jj * 8 * 32), 16, 0, 0);
+  };
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int rsw = (li >> 1) & 7;
+  const int a_row = (wm * 64 + li) * 32;
+  const int b_row = 256 * 32 + (wn * NJ * 32 + li) * 32;
+  const int niter = K / 32;                                  // even (host-checked)
+  const bool fused = ep.bias || ep.add || ep.stats;          // uniform
+
+  f32x16 acc[2][NJ];
+  auto compute = [&](const float* st) __attribute__((always_inline)) {
+    f32x4 a0[2], a1[2], bf[2][NJ];
+    auto frag = [&](int gk, int buf) __attribute__((always_inline)) {
+      const int so = ((2 * gk + lh) ^ rsw) * 4;
+      a0[buf] = *reinterpret_cast<const f32x4*>(st + a_row + so);
+      a1[buf] = *reinterpret_cast<const f32x4*>(st + a_row + 32 * 32 + so);
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) bf[buf][nj] = *reinterpret_cast<const f32x4*>(st + b_row + nj * 32 * 32 + so);
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int gk = 0; gk < 4; ++gk) {
+      if (gk + 1 < 4) frag(gk + 1, (gk + 1) & 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+          acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[gk & 1][e], bf[gk & 1][nj][e], acc[0][nj], 0, 0, 0);
+          acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[gk & 1][e], bf[gk & 1][nj][e], acc[1][nj], 0, 0, 0);
+        }
+      }
+      if (gk + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8 * NJ, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  struct Tile { const float* Ab; const float* Bb; float* Yb; int mt, nt; };
+  auto tile_of = [&](int idx) __attribute__((always_inline)) {
+    const int L = xcd_remap(idx, nblk);
+    Tile t;
+    t.nt = L % n_tiles;
+    const int r0 = L / n_tiles;
+    t.mt = r0 % m_tiles;
+    const int xi = r0 / m_tiles;
+    t.Ab = A + (((long)t.mt * npts + xi) * 256) * K;
+    t.Bb = Bw + ((long)xi * N + (long)t.nt * BN) * K;
+    t.Yb = Y + (((long)t.mt * npts + xi) * 256) * N + t.nt * BN;
+    return t;
+  };
+
+  int idx = blockIdx.x;
+  Tile cur = tile_of(idx);
+  issue(cur.Ab, cur.Bb, 0, s0);
+  for (;;) {
+    const int nxt = idx + gridDim.x;
+    const bool more = nxt < nblk;                             // uniform
+    Tile nx = cur;
+    if (more) nx = tile_of(nxt);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
+    for (int it = 0; it < niter; it += 2) {
+      __syncthreads();                 // stage 0 (iteration it) has landed; stage 1 is free
+      issue(cur.Ab, cur.Bb, it + 1, s1);
+      compute(s0);
+      __syncthreads();                 // stage 1 has landed; stage 0 is free
+      if (it + 2 < niter) issue(cur.Ab, cur.Bb, it + 2, s0);
+      else if (more) issue(nx.Ab, nx.Bb, 0, s0);             // the NEXT tile's first stage: lands under the epilogue
+      compute(s1);
+    }
+
+    // epilogue through LDS (stage 1's space; the prefetch owns stage 0): per wave 16 rows x CW columns at a time
+    constexpr int CW = NJ >= 2 ? 64 : 32;                 // columns per round
+    constexpr int NR = NJ >= 2 ? NJ / 2 : 1;              // column rounds
+    constexpr int P = CW + 8;
+    constexpr int Q = CW / 4;                             // 4-column groups per row
+    __syncthreads();                                      // every wave is done with the last operand stage
+    float* reg = s1 + wave * (16 * P);
+    const int cq = lane % Q, rs = lane / Q;
+    float s1v[NR][4], s2v[NR][4];
+#pragma unroll
+    for (int cr = 0; cr < NR; ++cr)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1v[cr][j] = 0.f; s2v[cr][j] = 0.f; }
+#pragma unroll
+    for (int cr = 0; cr < NR; ++cr) {
+      const int col = cur.nt * BN + wn * NJ * 32 + cr * CW + 4 * cq;          // column of Y (and of bias)
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (ep.bias) bv = *reinterpret_cast<const f32x4*>(ep.bias + col);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                     // accumulator rows 16 h .. 16 h + 15 of the 32-row block
+#pragma unroll
+          for (int e = 8 * h; e < 8 * h + 8; ++e)
+#pragma unroll
+            for (int j = 0; j < CW / 32; ++j)
+              reg[((e & 3) + 8 * ((e >> 2) & 1) + 4 * lh) * P + j * 32 + li] = acc[mi][cr * (CW / 32) + j][e];
+#pragma unroll
+          for (int r = 0; r < 16 / (64 / Q); ++r) {
+            const int row = r * (64 / Q) + rs;
+            f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * P + 4 * cq);
+            float* o = cur.Yb + (long)(wm * 64 + mi * 32 + 16 * h + row) * N + wn * NJ * 32 + cr * CW + 4 * cq;
+            if (fused) {
+              v += bv;
+              if (ep.add) {
+                const long oo = o - Y;
+                const f32x4 av = *reinterpret_cast<const f32x4*>(ep.add + oo);
+                if (ep.gate) {
+                  const f32x4 gv = *reinterpret_cast<const f32x4*>(ep.gate + oo);
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) v[j] += gv[j] > 0.f ? av[j] : 0.f;
+                } else {
+                  v += av;
+                }
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { s1v[cr][j] += v[j]; s2v[cr][j] += v[j] * v[j]; }
+            }
+            *reinterpret_cast<f32x4*>(o) = v;
+          }
+        }
+      }
+    }
+    if (ep.stats) {
+#pragma unroll
+      for (int cr = 0; cr < NR; ++cr)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int o = Q; o < 64; o <<= 1) {
+            s1v[cr][j] += __shfl_xor(s1v[cr][j], o, 64);
+            s2v[cr][j] += __shfl_xor(s2v[cr][j], o, 64);
+          }
+      __syncthreads();                                    // every wave is done with its turn region
+      float* red = s1;  // [8 waves][2][32 * NJ]
+      if (rs == 0) {
+#pragma unroll
+        for (int cr = 0; cr < NR; ++cr)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            red[(wave * 2 + 0) * 32 * NJ + cr * CW + 4 * cq + j] = s1v[cr][j];
+            red[(wave * 2 + 1) * 32 * NJ + cr * CW + 4 * cq + j] = s2v[cr][j];
+          }
+      }
+      __syncthreads();
+      if (tid < 2 * BN) {
+        const int which = tid / BN, cc = tid - which * BN;       // column within the workgroup's BN
+        const int cwn = cc / (32 * NJ), c2 = cc - cwn * 32 * NJ;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += red[((cwn * 4 + w) * 2 + which) * 32 * NJ + c2];   // wave = wn * 4 + wm
+        ep.stats[((long)cur.mt * 2 + which) * N + cur.nt * BN + cc] = v;
+      }
+    }
+    if (!more) break;
+    idx = nxt;
+    cur = nx;
   }
 }
 
@@ -1796,15 +2028,17 @@ int grid_for(long waves) {
 // tile transform into the Winograd domain (MODE 0: B^T x B, MODE 1: A dy A^T), fp32 or split-bf16 image
 template <int MODE>
 int launch_wino_in(const float* src, float* dst, const WinoGeom& g, const int C, const int math, hipStream_t s,
-                   const float* pscale = nullptr, const float* pshift = nullptr) {
+                   const float* pscale = nullptr, const float* pshift = nullptr, const int Cd = 0, const int cofs = 0) {
   const long units = (long)g.Tpad * (C / 64);
+  // (a source that fills a channel range of a wider image: the F(4,3)^3 transform's fp32 form only)
+  if (Cd && (math || !(g.nz == 4 && g.ny == 4 && g.nx == 4) || C % 64 || cofs % 64 || cofs + C > Cd)) return DRAM_ERR_UNSUPPORTED;
   if (pscale) {                                  // BatchNorm-apply + ReLU prologue: the F(4,3)^3 input transform only
     if (MODE != 0 || math || !pshift || !(g.nz == 4 && g.ny == 4 && g.nx == 4)) return DRAM_ERR_UNSUPPORTED;
     const double in_elems = (double)g.B * g.D * g.H * g.W * C;
     DramProf prof(DRAM_FAM_WINO_IN, 9444, 0.0, 4.0 * (in_elems + (double)g.npts * g.Tpad * C), s);
     if constexpr (MODE == 0) {
-      if (wino_nt() & 1) hipLaunchKernelGGL((wino_in444_kernel<0, false, true, true>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C, pscale, pshift);
-      else hipLaunchKernelGGL((wino_in444_kernel<0, false, false, true>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C, pscale, pshift);
+      if (wino_nt() & 1) hipLaunchKernelGGL((wino_in444_kernel<0, false, true, true>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C, pscale, pshift, Cd, cofs);
+      else hipLaunchKernelGGL((wino_in444_kernel<0, false, false, true>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C, pscale, pshift, Cd, cofs);
     }
     DRAM_LAUNCH_CHECK();
     return DRAM_OK;
@@ -1814,10 +2048,10 @@ int launch_wino_in(const float* src, float* dst, const WinoGeom& g, const int C,
   DramProf prof(DRAM_FAM_WINO_IN, MODE * 1000 + g.nz * 100 + g.ny * 10 + g.nx, 0.0,
                 4.0 * (in_elems + (double)g.npts * g.Tpad * C), s);
   static const int half = tune_env("DRAM_WINO_HALF") ? atoi(tune_env("DRAM_WINO_HALF")) : 1;   // A/B switch (tools)
-  if (half && g.nz == 4 && g.ny == 4 && g.nx == 4) {
-    if (math) hipLaunchKernelGGL((wino_in444_kernel<MODE, true, false>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C, nullptr, nullptr);
-    else if (wino_nt() & 1) hipLaunchKernelGGL((wino_in444_kernel<MODE, false, true>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C, nullptr, nullptr);
-    else hipLaunchKernelGGL((wino_in444_kernel<MODE, false, false>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C, nullptr, nullptr);
+  if ((half || Cd) && g.nz == 4 && g.ny == 4 && g.nx == 4) {
+    if (math) hipLaunchKernelGGL((wino_in444_kernel<MODE, true, false>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C, nullptr, nullptr, 0, 0);
+    else if (wino_nt() & 1) hipLaunchKernelGGL((wino_in444_kernel<MODE, false, true>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C, nullptr, nullptr, Cd, cofs);
+    else hipLaunchKernelGGL((wino_in444_kernel<MODE, false, false>), dim3(grid_for(2 * units)), dim3(256), 0, s, src, dst, g, C, nullptr, nullptr, Cd, cofs);
     DRAM_LAUNCH_CHECK();
     return DRAM_OK;
   }
@@ -1894,6 +2128,26 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
       return DRAM_OK;
     }
   }
+  // matrix-bound launches: the persistent form (the next tile's first stage prefetched under the epilogue), when the
+  // main loop has an even number of iterations; DRAM_NN_PERSIST=0 (DRAM_TUNING=1): the one-tile kernel (A/B, tests)
+  const char* pe = tune_env("DRAM_NN_PERSIST");          // (read per call: the tests switch it between cases)
+  const int persist = pe ? atoi(pe) : 1;
+  if (persist && epi_lds && nj <= 2 && (K / 32) % 2 == 0) {     // (256-column tiles: 256 accumulator + state registers spill)
+    // every workgroup the same number of tiles where that costs no round: 432 tiles -> 216 workgroups x 2 (the other
+    // 40 CUs stay free for the second stream's kernels) instead of 176 x 2 + 80 x 1
+    const int rounds = (nblk + 255) / 256;
+    int grid = ((nblk + rounds - 1) / rounds + 7) / 8 * 8;
+    if (grid > 256) grid = 256;
+    if (grid > nblk) grid = nblk;
+#define WNP(NJ_)                                                                                                   \
+  hipLaunchKernelGGL((wino_gemm_nn_pers_kernel<NJ_>), dim3(grid), dim3(512), 0, s, A, U, Y, g.Tpad, N, K, m_tiles, \
+                     n_tiles, nblk, g.npts, ep)
+    if (nj == 2) WNP(2);
+    else WNP(1);
+#undef WNP
+    DRAM_LAUNCH_CHECK();
+    return DRAM_OK;
+  }
   if (nj == 4) WNN(4);
   else if (nj == 2) WNN(2);
   else WNN(1);
@@ -1905,14 +2159,23 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
 // shared by forward (x, uf) and data gradient (dy, ub): in[..., K] -> out[..., N]
 int run_conv(const float* in, const float* U, const float* bias, const float* add, const float* gate, float* out,
              float* stats, float* v_keep, const DramConvDesc* d, int pass, int K, int N, void* ws, size_t ws_bytes,
-             hipStream_t s, const float* pscale = nullptr, const float* pshift = nullptr) {
+             hipStream_t s, const float* pscale = nullptr, const float* pshift = nullptr, const float* in1 = nullptr,
+             const int C0 = 0) {
   const WinoGeom g = make_geom(d, pass);
   const size_t need = (size_t)g.npts * g.Tpad * ((size_t)K + N) * sizeof(float);
   if (!ws || ws_bytes < need) return DRAM_ERR_WORKSPACE;
   float* V = v_keep ? v_keep : (float*)ws;          // kept for the weight gradient when the caller asks
   float* Mh = (float*)ws + (size_t)g.npts * g.Tpad * K;
   const int math = math_mode();
-  { const int rc0 = launch_wino_in<0>(in, V, g, K, math, s, pscale, pshift); if (rc0 != DRAM_OK) return rc0; }
+  if (in1) {
+    // input given as two channel blocks [in: C0 | in1: K - C0] (pass 0 only): two transforms into one image
+    int rc0 = launch_wino_in<0>(in, V, g, C0, math, s, nullptr, nullptr, K, 0);
+    if (rc0 == DRAM_OK) rc0 = launch_wino_in<0>(in1, V, g, K - C0, math, s, nullptr, nullptr, K, C0);
+    if (rc0 != DRAM_OK) return rc0;
+  } else {
+    const int rc0 = launch_wino_in<0>(in, V, g, K, math, s, pscale, pshift);
+    if (rc0 != DRAM_OK) return rc0;
+  }
   const int rc = run_nn(V, U, Mh, g, N, K, s, GemmEpilogue{nullptr, nullptr, nullptr, nullptr}, math);
   if (rc != DRAM_OK) return rc;
   const int ntb = (g.T + WINO_TPB - 1) / WINO_TPB;
@@ -2134,7 +2397,11 @@ extern "C" int dram_conv_algo(const DramConvDesc* d) {
     // ResNet-50 on the pipeline the full-size dRAM volumes sit 1.47e-3 from the fp64 oracle (bar 1e-3; 54 BatchNorm
     // layers amplify an early error), with the margin kept there they pass as before.  (DRAM_W2D_MARGIN[_BIG]: A/B)
     const char* me = tune_env(d->D >= 64 ? "DRAM_W2D_MARGIN_BIG" : "DRAM_W2D_MARGIN");
-    const double margin = me ? atof(me) : (d->D >= 64 ? 1.0 : 1.15);
+    // Round 5: the caller may say that its network amplifies a layer's rounding little (DRAM_CONV_ROUNDING_TOLERANT: the
+    // BasicBlock ResNets -- full-size outputs 6.0e-5 / 1.9e-4 from the fp64 oracle with every 64->64 layer on F(4,3)^3):
+    // the cheaper estimate then wins everywhere (config 1: 39.6 -> 38.5 ms).
+    const bool tolerant = (d->flags & DRAM_CONV_ROUNDING_TOLERANT) != 0;
+    const double margin = me ? atof(me) : ((d->D >= 64 || tolerant) ? 1.0 : 1.15);
     if (w2d < 0.92 * direct && w2d < margin * best) { best = w2d; pick = 2; }
   }
   return pick;
@@ -2266,6 +2533,16 @@ extern "C" int dram_wino_conv3d_fwd_bn(const float* x_pre, const float* pscale, 
   if (!dram_wino_prologue_supported(d)) return DRAM_ERR_UNSUPPORTED;
   return run_conv(x_pre, uf, bias, nullptr, nullptr, y, stats_partial, v_keep, d, 0, d->Cin, d->Cout, workspace,
                   workspace_bytes, (hipStream_t)stream, pscale, pshift);
+}
+
+extern "C" int dram_wino_conv3d_fwd_cat(const float* x0, int C0, const float* x1, int C1, const float* uf, const float* bias,
+                                        float* y, float* stats_partial, float* v_keep, const DramConvDesc* d,
+                                        void* workspace, size_t workspace_bytes, dram_stream_t stream) {
+  if (!x0 || !x1 || !uf || !y || !d || C0 < 64 || C1 < 64 || (C0 % 64) || (C1 % 64) || C0 + C1 != d->Cin)
+    return DRAM_ERR_BAD_ARG;
+  if (!dram_wino_prologue_supported(d)) return DRAM_ERR_UNSUPPORTED;        // (F(4,3)^3 tiles, fp32 images)
+  return run_conv(x0, uf, bias, nullptr, nullptr, y, stats_partial, v_keep, d, 0, d->Cin, d->Cout, workspace,
+                  workspace_bytes, (hipStream_t)stream, nullptr, nullptr, x1, C0);
 }
 
 extern "C" size_t dram_wino_v_elems(const DramConvDesc* d) {

@@ -643,7 +643,9 @@ extern "C" int dram_maxpool_bwd_bf16(const void* dy, const uint8_t* argmax, cons
 template <typename T>
 static int upcat_fwd_impl(const T* src, const T* skip, T* cat, int B, int Ds, int Hs, int Ws, int Cu, int Dk, int Hk,
                           int Wk, int Ck, dram_stream_t stream) {
-  if (!src || !skip || !cat || B < 1 || Cu < 4 || Ck < 4 || (Cu & 3) || (Ck & 3)) return DRAM_ERR_BAD_ARG;
+  // (skip == NULL with Ck == 0: the up-sampled tensor alone, cropped to [Dk/2*2 ...] like the concatenation would be --
+  // the convolution behind it then takes the skip tensor as its own second source, dram_wino_conv3d_fwd_cat)
+  if (!src || !cat || B < 1 || Cu < 4 || (Cu & 3) || (skip ? (Ck < 4 || (Ck & 3)) : Ck != 0)) return DRAM_ERR_BAD_ARG;
   const int Do = 2 * Ds, Ho = 2 * Hs, Wo = 2 * Ws;
   if (Dk < Do || Hk < Ho || Wk < Wo) return DRAM_ERR_BAD_ARG;  // crop_concat_5d assumes t1 <= t2
   const int oz = (Dk - Do + 1) / 2, oy = (Hk - Ho + 1) / 2, ox = (Wk - Wo + 1) / 2;  // ceil((b-a)/2)

@@ -65,6 +65,9 @@ class Engine:
         self.net, self.head = net, head
         self.kind, self.layers = ARCHS[net]
         self.e = EXPANSION[self.kind]
+        # plan hint (include/dram_hip.h DRAM_CONV_ROUNDING_TOLERANT): the BasicBlock networks hand a layer's rounding
+        # error on with little amplification, so the cheaper convolution estimate may win on every layer
+        self.tol = 1 if self.kind == "basic" else 0
         self._conv_lists: Dict[tuple, list] = {}     # input shape -> [(weight name, geometry)] of a forward
         self._inflight: List[torch.cuda.Event] = []  # end-of-backward events of the steps the host has issued
         self.throttle_wait_s = 0.0                   # host time spent waiting in _throttle (bench.py reports it)
@@ -143,15 +146,22 @@ class Engine:
         consumer the same way -- the first return value is then such a deferred input."""
         w = st.P[wname]
         pro = None
-        if isinstance(x, dict):
+        split = None
+        if isinstance(x, tuple):                        # (x0, x1): the input as two channel blocks, never concatenated
+            split = x
+            x = None
+            B, D, H, W, _ = split[0].shape
+            Cin = split[0].shape[4] + split[1].shape[4]
+        elif isinstance(x, dict):
             B, D, H, W, Cin = x["y"].shape
-            g = ConvGeom(B, D, H, W, Cin, w.shape[0], k, stride, pad, dil)
+            g = ConvGeom(B, D, H, W, Cin, w.shape[0], k, stride, pad, dil, self.tol)
             if k == 3 and ops.conv_prologue_ok(g, x["y"].dtype):
                 pro, x = x["ss"], x["y"]
             else:
                 x = ops.bn_apply(x["y"], x["ss"][0], x["ss"][1], None, 1, True)
-        B, D, H, W, Cin = x.shape
-        g = ConvGeom(B, D, H, W, Cin, w.shape[0], k, stride, pad, dil)
+        if split is None:
+            B, D, H, W, Cin = x.shape
+        g = ConvGeom(B, D, H, W, Cin, w.shape[0], k, stride, pad, dil, self.tol)
         st.convs.append((wname, g))
         if st.need_grad:
             pre = st.packed.pop(wname, None)
@@ -164,15 +174,20 @@ class Engine:
                 wf, wb = ops.pack_conv_weight(w, True, True, g, st.storage)
         else:                                           # inference: packed / transformed once per weight version
             wf, wb = ops.packed_forward_weight(w, g, st.storage), None
-        y, sp, v = ops.conv3d_fwd_keep(x, wf, st.P[bname] if bname else None, g, st.training,
-                                       st.need_grad and not st.recompute, prologue=pro)
+        if split is not None:
+            y, sp, v = ops.conv3d_fwd_cat(split[0], split[1], wf, st.P[bname] if bname else None, g, st.training,
+                                          st.need_grad and not st.recompute)
+        else:
+            y, sp, v = ops.conv3d_fwd_keep(x, wf, st.P[bname] if bname else None, g, st.training,
+                                           st.need_grad and not st.recompute, prologue=pro)
         defer_z = defer_z and residual is None
         z, mean, invstd, count, ss = self._bn_fwd(st, y, sp, bnp, residual, rs, apply=not defer_z)
         c = None
         if st.need_grad:
-            if pro is not None and xr is None:
-                raise RuntimeError("a fused BatchNorm prologue needs the producing unit's context (xr)")
-            drop_x = (st.recompute and xr is not None) or pro is not None     # (pro: x is the producer's y, not the input)
+            if (pro is not None or split is not None) and xr is None:
+                raise RuntimeError("a fused BatchNorm prologue / a split input needs the recipe of the input (xr)")
+            # (pro: x is the producer's y, not the input; split: the concatenated input was never built)
+            drop_x = (st.recompute and xr is not None) or pro is not None or split is not None
             c = dict(x=None if drop_x else x, xr=xr if drop_x else None, y=y,
                      z=None if (st.recompute and residual is None) else z, mean=mean, invstd=invstd, g=g, wb=wb,
                      count=count, w=wname, b=bname, bn=bnp, v=v, ss=ss)
@@ -296,8 +311,7 @@ class Engine:
         return self._conv_bn_bwd(st, cs[0], d, need_dx=need_dx, add=dz_out, gate=last["z"])
 
     # ------------------------------------------------------------------ decoder block
-    @staticmethod
-    def _upmix_geoms(src, skip, w):
+    def _upmix_geoms(self, src, skip, w):
         """(low-resolution mixing geometry, skip-convolution geometry) when the first decoder convolution can run
         without the up-sampled tensor (csrc/upmix.hip), else None: no crop (skip is exactly twice the source), channel
         counts the GEMM / convolution kernels take, and -- unless forced -- an up-sampled operand wide enough to pay
@@ -311,8 +325,8 @@ class Engine:
             return None
         if mode == 1 and (Cu < 256 or (B * Ds * Hs * Ws) % 256 or B * Ds * Hs * Ws < 2048):
             return None                                 # the mixing GEMM wants whole 256-row tiles and a filled chip
-        g_lo = ConvGeom(B, Ds, Hs, Ws, Cu, 27 * Co, 1, 1, 0, 1)
-        g_s = ConvGeom(B, 2 * Ds, 2 * Hs, 2 * Ws, Cs, Co, 3, 1, 1, 1)
+        g_lo = ConvGeom(B, Ds, Hs, Ws, Cu, 27 * Co, 1, 1, 0, 1, self.tol)
+        g_s = ConvGeom(B, 2 * Ds, 2 * Hs, 2 * Ws, Cs, Co, 3, 1, 1, 1, self.tol)
         return g_lo, g_s
 
     def _upmix_fwd(self, st, src, skip, wname, bname, bnp, geoms):
@@ -359,9 +373,20 @@ class Engine:
             if st.recompute and cb is not None:
                 cb["z"] = zb
             return zb, (ca, cb, tuple(src.shape), tuple(skip.shape))
-        cat = ops.upcat_fwd(src, skip)
+        # the up-sampled + concatenated input of conv_blocks[0] (med3d.py:86-87) is NOT built where the convolution can
+        # take two sources (fp32 pipeline, F(4,3)^3 tiles, no crop): only the up-sampled half is written, the skip tensor
+        # is read in place -- half the pass, 0.5 GB less on config 1's us2.  Elsewhere: the materialised concatenation.
+        B, Ds, Hs, Ws, Cu = src.shape
+        wc = st.P[f"{p}.conv_blocks.0.0.weight"]
+        gc = ConvGeom(B, 2 * Ds, 2 * Hs, 2 * Ws, wc.shape[1], wc.shape[0], 3, 1, 1, 1, self.tol)
+        if (tuple(skip.shape[1:4]) == (2 * Ds, 2 * Hs, 2 * Ws) and wc.shape[1] == Cu + skip.shape[4]
+                and ops.conv_cat_ok(gc, Cu, src.dtype)):
+            cat = (ops.up_fwd(src), skip)
+        else:
+            cat = ops.upcat_fwd(src, skip)
         za, ca = self._conv_bn_fwd(st, cat, f"{p}.conv_blocks.0.0.weight", f"{p}.conv_blocks.0.0.bias",
                                    f"{p}.conv_blocks.0.1", 3, 1, 1, 1, xr=("upcat", src, skip), defer_z=True)
+        del cat
         zb, cb = self._conv_bn_fwd(st, za, f"{p}.conv_blocks.1.0.weight", f"{p}.conv_blocks.1.0.bias",
                                    f"{p}.conv_blocks.1.1", 3, 1, 1, 1, xr=("bn", ca))
         if st.recompute and cb is not None:

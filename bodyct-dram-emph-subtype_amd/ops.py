@@ -277,6 +277,7 @@ class ConvGeom:
     stride: int
     pad: int
     dil: int
+    tol: int = 0        # DRAM_CONV_ROUNDING_TOLERANT (include/dram_hip.h): plan hint set by the engine for BasicBlock networks
 
     def out(self, n: int) -> int:
         return (n + 2 * self.pad - (self.dil * (self.k - 1) + 1)) // self.stride + 1
@@ -312,7 +313,7 @@ class ConvGeom:
 
     def desc(self) -> DramConvDesc:
         return DramConvDesc(self.B, self.D, self.H, self.W, self.Cin, self.Do, self.Ho, self.Wo, self.Cout,
-                            self.k, self.stride, self.pad, self.dil)
+                            self.k, self.stride, self.pad, self.dil, self.tol)
 
 
 # --------------------------------------------------------------------------- conv
@@ -459,7 +460,7 @@ def s2_geom(g: "ConvGeom") -> Optional["ConvGeom"]:
     if (g.k != 3 or g.stride != 2 or g.pad != 1 or g.dil != 1 or ((g.D | g.H | g.W) & 1) or g.Cin % 8
             or tuning_env("DRAM_BF16_S2", "1") == "0"):
         return None
-    g8 = ConvGeom(g.B, g.D // 2, g.H // 2, g.W // 2, 8 * g.Cin, g.Cout, 3, 1, 1, 1)
+    g8 = ConvGeom(g.B, g.D // 2, g.H // 2, g.W // 2, 8 * g.Cin, g.Cout, 3, 1, 1, 1, g.tol)
     return g8 if (conv_plan(g8).bf16 and tuple(g8.out_shape) == tuple(g.out_shape)) else None
 
 
@@ -1063,6 +1064,48 @@ def upcat_fwd(src: Tensor, skip: Tensor) -> Tensor:
     _chk(_fn("dram_upcat_fwd", sfx)(_p(src), _p(skip), _p(cat), B, Ds, Hs, Ws, Cu, Dk, Hk, Wk, Ck, _stream()),
          "dram_upcat_fwd")
     return cat
+
+
+def up_fwd(src: Tensor) -> Tensor:
+    """x2 trilinear up-sampling (align_corners) alone: the first Cu channels of upcat_fwd(src, skip), bit for bit,
+    without the concatenation (the convolution behind it reads the skip tensor as its second source: conv3d_fwd_cat)."""
+    sfx = _act(src, "src")
+    B, Ds, Hs, Ws, Cu = src.shape
+    up = torch.empty((B, 2 * Ds, 2 * Hs, 2 * Ws, Cu), device=src.device, dtype=src.dtype)
+    _chk(_fn("dram_upcat_fwd", sfx)(_p(src), None, _p(up), B, Ds, Hs, Ws, Cu, 2 * Ds, 2 * Hs, 2 * Ws, 0, _stream()),
+         "dram_upcat_fwd (up only)")
+    return up
+
+
+def conv_cat_ok(g: "ConvGeom", C0: int, dtype=torch.float32) -> bool:
+    """Can the convolution take its input as two channel blocks [C0 | g.Cin - C0] (conv3d_fwd_cat)?  The fp32 Winograd
+    pipeline with F(4,3)^3 tiles, both blocks multiples of 64; DRAM_CONV_CAT=0 under DRAM_TUNING=1 switches it off (A/B)."""
+    return (dtype == torch.float32 and tuning_env("DRAM_CONV_CAT", "1") != "0" and conv_plan(g).prologue
+            and C0 >= 64 and C0 % 64 == 0 and (g.Cin - C0) >= 64 and (g.Cin - C0) % 64 == 0)
+
+
+def conv3d_fwd_cat(x0: Tensor, x1: Tensor, wf: Tensor, bias: Optional[Tensor], g: "ConvGeom", want_stats: bool, keep: bool):
+    """Forward convolution of concat([x0, x1], channels) WITHOUT the concatenated tensor (reference med3d.py:87 feeding
+    :67): each source's input transform fills its channel range of the Winograd-domain image.  Returns (y, stats, V) like
+    conv3d_fwd_keep; bit-identical to it on the concatenation."""
+    plan = conv_plan(g)
+    C0, C1 = x0.shape[-1], x1.shape[-1]
+    if not conv_cat_ok(g, C0, x0.dtype) or C0 + C1 != g.Cin:
+        raise RuntimeError(f"conv3d_fwd_cat: not available for {g} with blocks {C0} | {C1}")
+    _req(x0, "x0", shape=g.in_shape[:4] + (C0,))
+    _req(x1, "x1", shape=g.in_shape[:4] + (C1,))
+    _req(wf, "wf", shape=(plan.taps_f, g.Cout, g.Cin))
+    if bias is not None:
+        _req(bias, "bias", shape=(g.Cout,))
+    y = torch.empty(g.out_shape, device=x0.device, dtype=torch.float32)
+    stats = torch.empty((plan.stat_rows, 2, g.Cout), device=x0.device, dtype=torch.float32) if want_stats else None
+    nbytes = plan.ws_fwd
+    ws = _workspace(nbytes, x0.device)
+    v = torch.empty((plan.v_elems,), device=x0.device, dtype=torch.float32) if keep else None
+    with _span("conv_wino_kernels", g.flops, f"fwd {g}"):
+        _chk(_L().dram_wino_conv3d_fwd_cat(_p(x0), C0, _p(x1), C1, _p(wf), _p(bias), _p(y), _p(stats), _p(v), plan.dref, _p(ws),
+                                           nbytes, _stream()), f"dram_wino_conv3d_fwd_cat{g}")
+    return y, stats, v
 
 
 def upcat_bwd(dcat: Tensor, src_shape, skip_shape, need_src=True, need_skip=True):

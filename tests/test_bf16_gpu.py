@@ -536,7 +536,7 @@ def test_resnet50_bf16_every_unit_vs_oracle_teacher_forced():
     med3d.py:121-124, 153-159, 164-184, 85-89) applied to the INPUT THE HIP UNIT ITSELF READ (its saved bf16 tensor) must
     reproduce the unit's stored pre-BatchNorm output, its batch mean / inverse standard deviation and its stored
     activation.  What may differ is a bf16 rounding tie (one ulp = 2^-8 relative on an element whose exact value lies
-    within accumulation error of a rounding boundary): relative L2 <= UNIT_TOL per tensor, statistics <= 1e-4.
+    within accumulation error of a rounding boundary): relative L2 <= UNIT_TOL = 2e-4 per tensor, statistics <= 1e-6.
     Covers all 16 Bottleneck blocks (1x1x1, 3x3x3 dilated, the stride-2 convolution through space-to-depth, shortcut-A
     and identity residuals), both decoder blocks (us1's first convolution runs WITHOUT the up-sampled tensor --
     csrc/upmix.hip, other rounding points: UPMIX_TOL), us3 and the stem."""
@@ -550,12 +550,13 @@ def test_resnet50_bf16_every_unit_vs_oracle_teacher_forced():
     m.storage_dtype = BF
     dense, outs = m(x.to(DEV), None)
     saved = dense[0].grad_fn.saved_state
-    UNIT_TOL, UPMIX_TOL, STAT_TOL = 3e-3, 2e-2, 1e-4
+    # measured (round 5): pre-BatchNorm outputs 4.7e-5, activations 2.6e-5, statistics 6.4e-8; the upmix unit 2.7e-3
+    UNIT_TOL, UPMIX_TOL, STAT_TOL = 2e-4, 8e-3, 1e-6
 
     def qd(t):
         return t.to(BF).double()
 
-    worst = {"y": (0.0, ""), "z": (0.0, ""), "stat": (0.0, "")}
+    worst = {"y": (0.0, ""), "y-upmix": (0.0, ""), "z": (0.0, ""), "stat": (0.0, "")}
 
     def check(kind, name, got, ref, tol):
         e = rel_l2(got, ref)
@@ -606,14 +607,14 @@ def test_resnet50_bf16_every_unit_vs_oracle_teacher_forced():
             cat = orc.crop_concat(qd(orc.upsample2_trilinear(_ncdhw(ca["src"]))), _ncdhw(ca["skip"]))
             y_ref = qd(F.conv3d(cat, qd(sd0[ca["w"]]), sd0[ca["b"]], 1, 1))
             ya = _ncdhw(ca["y"])
-            check("y", ca["w"] + " (upmix)", ya, y_ref, UPMIX_TOL)
+            check("y-upmix", ca["w"] + " (upmix)", ya, y_ref, UPMIX_TOL)
             bn_z(ca, ya, None, cb["x"])
         else:
             unit(ca, _ncdhw(ca["x"]), z=cb["x"])
         unit(cb, _ncdhw(cb["x"]), z=(saved["cu2"][0]["src"] if (key == "cu1" and saved["cu2"][0].get("kind") == "upmix") else None)
              if cb.get("z") is None else None)
     unit(saved["cu3"], _ncdhw(saved["cu3"]["x"]), z=saved["xup3"])
-    print(f"[resnet50 bf16 1x64x128x128, every unit on its own stored input] worst pre-BN output {worst['y']}, "
+    print(f"[resnet50 bf16 1x64x128x128, every unit on its own stored input] worst pre-BN output {worst['y']} (us1's first convolution, other rounding points: {worst['y-upmix']}), "
           f"worst activation {worst['z']}, worst statistic {worst['stat']}")
 
 

@@ -274,6 +274,77 @@ def test_winograd_streaming_gemm_equals_tiled_gemm(ops, monkeypatch, case):
     assert rel_l2(to_ncdhw(res["2"][0]).double(), ref) < 3e-5
 
 
+@pytest.mark.parametrize("case", [(1, 8, 16, 16, 64, 64, 64), (2, 8, 8, 16, 128, 64, 64), (1, 6, 10, 12, 64, 128, 64)], ids=str)
+def test_conv_of_two_channel_blocks_equals_conv_of_their_concatenation(ops, monkeypatch, case):
+    """crop_concat_5d feeding conv_blocks[0] (reference med3d.py:39-48, :87, :67) without the concatenated tensor: the
+    up-sampled half alone (ops.up_fwd == the first Cu channels of upcat_fwd, bit for bit) and the convolution reading the
+    two blocks as two sources (ops.conv3d_fwd_cat) give the output, the BatchNorm partial sums and the kept
+    Winograd-domain image of the convolution of the materialised concatenation, bit for bit (ragged tiles included)."""
+    monkeypatch.setenv("DRAM_CONV_ALGO", "2")
+    monkeypatch.setenv("DRAM_WINO_TILING", "4,4,4")
+    B, Ds, Hs, Ws, Cu, Cs, Co = case
+    src = to_ndhwc(rnd(B, Cu, Ds, Hs, Ws, seed=1))
+    skip = to_ndhwc(rnd(B, Cs, 2 * Ds, 2 * Hs, 2 * Ws, seed=2))
+    cat = ops.upcat_fwd(src, skip)
+    up = ops.up_fwd(src)
+    assert torch.equal(up, cat[..., :Cu].contiguous())
+    g = ops.ConvGeom(B, 2 * Ds, 2 * Hs, 2 * Ws, Cu + Cs, Co, 3, 1, 1, 1)
+    assert ops.conv_cat_ok(g, Cu)
+    w = (rnd(Co, Cu + Cs, 3, 3, 3, seed=3) * 0.1).to(DEV)
+    bias = rnd(Co, seed=4).to(DEV)
+    wf, _ = ops.pack_conv_weight(w, True, False, g)
+    y0, s0, v0 = ops.conv3d_fwd_keep(cat, wf, bias, g, True, True)
+    y1, s1, v1 = ops.conv3d_fwd_cat(up, skip, wf, bias, g, True, True)
+    assert torch.equal(y0, y1) and torch.equal(s0, s1) and torch.equal(v0, v1)
+    gy = to_ndhwc(rnd(B, Co, 2 * Ds, 2 * Hs, 2 * Ws, seed=5))
+    assert torch.equal(ops.conv3d_bwd_weight(None, gy, g, v_cache=v1), ops.conv3d_bwd_weight(cat, gy, g, v_cache=v0))
+    monkeypatch.setenv("DRAM_WINO_TILING", "4,4,2")            # other tilings: the engine materialises the concatenation
+    assert not ops.conv_cat_ok(g, Cu)
+
+
+PERSIST_CASES = [
+    # kind, B, D, H, W, Cin, Cout, dil: Winograd-domain GEMMs whose workgroups walk SEVERAL tiles (> 256 tiles: 216
+    # points x 2 M tiles x column tiles) and 1x1x1 convolutions (one point, fused epilogues), 64- and 128-column tiles
+    ("wino", 2, 16, 32, 32, 128, 128, 1),      # config 1's layer2: 432 tiles of 256 x 128
+    ("wino", 1, 16, 16, 32, 256, 192, 2),      # 216 x 1 x 3 tiles of 64 columns, dilation lattice
+    ("c1", 2, 16, 32, 32, 256, 512, 1),        # 1x1x1, 128 x 4 = 512 tiles of 128 columns (K = 256: 8 iterations)
+    ("c1", 1, 8, 16, 16, 512, 64, 1),          # 1x1x1, 8 tiles of 64 columns: fewer tiles than CUs
+]
+
+
+@pytest.mark.parametrize("case", PERSIST_CASES, ids=[str(c) for c in PERSIST_CASES])
+def test_persistent_nn_gemm_equals_one_tile_gemm(ops, monkeypatch, case):
+    """wino_gemm_nn_pers_kernel (workgroups that walk several tiles, the next tile's first stage prefetched under the
+    epilogue, accumulators turned through LDS 16 rows at a time) against the one-tile kernel: forward, data gradient
+    (with the fused shortcut-gradient epilogue) and the fused BatchNorm partial sums bit for bit."""
+    kind, B, D, H, W, Cin, Cout, dil = case
+    k = 3 if kind == "wino" else 1
+    if kind == "wino":
+        monkeypatch.setenv("DRAM_CONV_ALGO", "2")
+        monkeypatch.setenv("DRAM_WINO_TILING", "4,4,4")
+    else:
+        monkeypatch.delenv("DRAM_CONV_ALGO", raising=False)
+    monkeypatch.setenv("DRAM_NN_STREAM", "0")
+    g = ops.ConvGeom(B, D, H, W, Cin, Cout, k, 1, dil if k == 3 else 0, dil if k == 3 else 1)
+    assert ops.conv_algo(g) == (1 if kind == "wino" else 3)
+    x = to_ndhwc(rnd(B, Cin, D, H, W, seed=1))
+    gy = to_ndhwc(rnd(B, Cout, D, H, W, seed=4))
+    add, gate = to_ndhwc(rnd(B, Cin, D, H, W, seed=5)), to_ndhwc(rnd(B, Cin, D, H, W, seed=6))
+    w = (rnd(Cout, Cin, k, k, k, seed=2) * 0.1).to(DEV)
+    bias = rnd(Cout, seed=3).to(DEV)
+    wf, wb = ops.pack_conv_weight(w, True, True, g)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DRAM_NN_PERSIST", mode)
+        y, st = ops.conv3d_fwd(x, wf, bias, g, True)
+        res[mode] = (y, st, ops.conv3d_bwd_data(gy, wb, g), ops.conv3d_bwd_data(gy, wb, g, add, gate))
+    for a, b in zip(res["0"], res["1"]):
+        assert torch.equal(a, b)
+    ref = F.conv3d(rnd(B, Cin, D, H, W, seed=1).double(), w.cpu().double(), bias.cpu().double(), 1, dil if k == 3 else 0,
+                   dil if k == 3 else 1)
+    assert rel_l2(to_ncdhw(res["1"][0]).double(), ref) < 3e-5
+
+
 @pytest.mark.parametrize("case", [WINO_CASES[0], WINO_CASES[2], WINO_CASES[5], WINO_CASES[7]], ids=str)
 def test_winograd_batchnorm_prologue_is_bit_identical(ops, monkeypatch, case):
     """K7(b) (med3d.py:121-124: bn, relu, conv): the F(4,3)^3 input transform applies the producing unit's

@@ -21,6 +21,12 @@ python bench.py --config 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_co
 python bench.py --config 2 --dtype f32 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config2_f32.json.log 2>$O/bench_config2_f32.json.log.err
 python bench.py --config 3 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_config3_bf16.json.log 2>$O/bench_config3_bf16.json.log.err
 python bench.py --config 4 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_config4.json.log 2>$O/bench_config4.json.log.err           # bf16 + recompute
+# the data-parallel step at world size 1 with every collective in place (own RCCL communicators), next to the plain step
+# of the same process (plain_ms_per_step / exposed_collective_ms in each line)
+for spec in "1 f32" "2 bf16" "3 bf16"; do
+  set -- $spec
+  python bench.py --config $1 --dtype $2 --force-dist --steps 20 --warmup 5 --no-cpu-baseline --timeline off > $O/bench_config$1_$2_forcedist.json.log 2>$O/bench_config$1_$2_forcedist.json.log.err
+done
 cd /tmp && export TMPDIR=/tmp
 # the profiled passes run the step on ONE stream, like bench.py's timeline pass: with the weight-gradient kernels
 # overlapping the data-gradient chain on a second stream, per-kernel durations contain the time a kernel shared its
