@@ -1667,7 +1667,12 @@ int launch_gemm1(const bf16_t* x, const bf16_t* w, const bf16_t* add, const bf16
   g.M = (long)d->B * d->D * d->H * d->W;
   g.Cin = cin; g.Cout = cout;
   g.m_tiles = (int)((g.M + 255) / 256);
-  const int nb = cout % 128 == 0 ? 4 : 2;
+  // 128-column tiles, unless they leave the chip under-filled (two workgroups per CU: 512 slots): the 16 x 32 x 32 stages
+  // of ResNet-50 have 64 row tiles, so 1024->256 was 128 workgroups on 256 CUs (26 us for 42 MB: 1.6 TB/s).  64-column
+  // tiles double the workgroups; the A tile they re-read comes from L2.  DRAM_BF16_GEMM1_NB=4 (DRAM_TUNING=1): A/B.
+  int nb = cout % 128 == 0 ? 4 : 2;
+  static const int force_nb = tune_env("DRAM_BF16_GEMM1_NB") ? atoi(tune_env("DRAM_BF16_GEMM1_NB")) : 0;
+  if (nb == 4 && force_nb != 4 && (long)g.m_tiles * (cout / 128) < 512) nb = 2;
   g.n_tiles = cout / (32 * nb);
   g.nblk = g.m_tiles * g.n_tiles;
   DramProf prof(DRAM_FAM_CONV_BF16, 8 + epi * 2 + (nb == 4), 2.0 * (double)g.m_tiles * 256.0 * cin * cout,

@@ -543,7 +543,9 @@ __global__ __launch_bounds__(256, 2) void wino_in444_kernel(const float* __restr
 constexpr int WINO_TPB = 16;
 __constant__ float c_at4[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};   // A^T of F(4,3)
 
-template <int NZ, int NY, int NX, bool NT>
+// ADD: 0 plain; 1 `+= add`; 2 `+= add * (gate > 0)` (the shortcut-gradient epilogue) -- compile-time, so that the plane of
+// epilogue operands is loaded without a branch in between
+template <int NZ, int NY, int NX, bool NT, int ADD = 0>
 __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ mh, const float* __restrict__ bias,
                                                        const float* __restrict__ add, const float* __restrict__ gate,
                                                        float* __restrict__ out, float* __restrict__ stats,
@@ -657,6 +659,28 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
       const int z = z0 + i * g.d;
+      // shortcut-gradient operands of the whole output plane first (up to 2 x NY x NX loads in flight), then the
+      // arithmetic and the stores: with each load next to its use the epilogue ran one or two loads at a time -- the
+      // three 512-channel data-gradient launches of config 1 took 186 us for 427 MB (2.3 TB/s) where the plain ones of
+      // the same size stream at 4.5-5 TB/s, and ResNet-34 / -50 have one such launch per identity block
+      float av[ADD ? NY : 1][ADD ? NX : 1], gv[ADD ? NY : 1][ADD ? NX : 1];
+      if (ADD) {
+#pragma unroll
+        for (int j = 0; j < NY; ++j) {
+          const int y = y0 + j * g.d;
+#pragma unroll
+          for (int k = 0; k < NX; ++k) {
+            const int x = x0 + k * g.d;
+            // NO branch around the loads (a wave-uniform `if` per element keeps each load next to its use: the plane's
+            // loads must be issued back to back): an out-of-volume element gets an offset beyond the descriptor's range
+            // and reads 0 in hardware (its result is never stored)
+            const bool ok = (z < g.D) & (y < g.H) & (x < g.W);                                               // wave-uniform
+            const unsigned so = ok ? (unsigned)(i * g.d) * plane_b + (unsigned)y * line_b + (unsigned)x * row_b : WINO_OOB;
+            av[ADD ? j : 0][ADD ? k : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)c4, (int)so, 0));
+            gv[ADD ? j : 0][ADD ? k : 0] = ADD == 2 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rgate, (int)c4, (int)so, 0)) : 1.f;
+          }
+        }
+      }
 #pragma unroll
       for (int j = 0; j < NY; ++j) {
         const int y = y0 + j * g.d;
@@ -666,15 +690,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
           if ((z < g.D) & (y < g.H) & (x < g.W)) {          // wave-uniform
             const int so = (int)((unsigned)(i * g.d) * plane_b + (unsigned)y * line_b + (unsigned)x * row_b);   // scalar
             float v = o[i][j][k] + bv;
-            if (add) {
-              const float av = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(radd, (int)c4, so, 0));
-              if (gate) {
-                const float gv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rgate, (int)c4, so, 0));
-                v += gv > 0.f ? av : 0.f;
-              } else {
-                v += av;
-              }
-            }
+            if (ADD) v += gv[ADD ? j : 0][ADD ? k : 0] > 0.f ? av[ADD ? j : 0][ADD ? k : 0] : 0.f;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)c4, so, 0);
             s1 += v;
             s2 += v * v;
@@ -2132,7 +2148,10 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
   // main loop has an even number of iterations; DRAM_NN_PERSIST=0 (DRAM_TUNING=1): the one-tile kernel (A/B, tests)
   const char* pe = tune_env("DRAM_NN_PERSIST");          // (read per call: the tests switch it between cases)
   const int persist = pe ? atoi(pe) : 1;
-  if (persist && epi_lds && nj <= 2 && (K / 32) % 2 == 0) {     // (256-column tiles: 256 accumulator + state registers spill)
+  // (256-column tiles: accumulators + state spill.  Fused epilogues -- the 1x1x1 convolutions of the Bottleneck blocks --
+  // keep the one-tile kernel: their bias / shortcut-gradient loads wait on vmcnt, which the prefetch DMA shares, so the
+  // epilogue serialises behind the prefetch it was meant to hide: ResNet-50 fp32 38.8 -> 45.6 ms with it, measured)
+  if (persist && epi_lds && !fused && nj <= 2 && (K / 32) % 2 == 0) {
     // every workgroup the same number of tiles where that costs no round: 432 tiles -> 216 workgroups x 2 (the other
     // 40 CUs stay free for the second stream's kernels) instead of 176 x 2 + 80 x 1
     const int rounds = (nblk + 255) / 256;
@@ -2182,17 +2201,26 @@ int run_conv(const float* in, const float* U, const float* bias, const float* ad
   const double out_elems = (double)g.B * g.D * g.H * g.W * N;
   DramProf prof(DRAM_FAM_WINO_OUT, g.nz * 100 + g.ny * 10 + g.nx, 0.0,
                 4.0 * ((double)g.npts * g.Tpad * N + out_elems * (1 + (add ? 1 : 0) + (gate ? 1 : 0))), s);
+#define W_OUT2(NZ_, NY_, NX_, NT_)                                                                                        \
+  do {                                                                                                                    \
+    if (add && gate)                                                                                                      \
+      hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_, NX_, NT_, 2>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add,     \
+                         gate, out, stats, g, N);                                                                         \
+    else if (add)                                                                                                         \
+      hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_, NX_, NT_, 1>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add,     \
+                         gate, out, stats, g, N);                                                                         \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_, NX_, NT_, 0>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add,     \
+                         gate, out, stats, g, N);                                                                         \
+  } while (0)
 #define W_OUT(NZ_, NY_, NX_)                                                                                              \
   do {                                                                                                                    \
-    if (wino_nt() & 2)                                                                                                    \
-      hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_, NX_, true>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add, gate, \
-                         out, stats, g, N);                                                                               \
-    else                                                                                                                  \
-      hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_, NX_, false>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add,     \
-                         gate, out, stats, g, N);                                                                         \
+    if (wino_nt() & 2) W_OUT2(NZ_, NY_, NX_, true);                                                                       \
+    else W_OUT2(NZ_, NY_, NX_, false);                                                                                    \
   } while (0)
   WINO_TILING_DISPATCH(g, W_OUT);
 #undef W_OUT
+#undef W_OUT2
   DRAM_LAUNCH_CHECK();
   return DRAM_OK;
 }

@@ -1,5 +1,5 @@
 """GPU box: per-launch view of the library's kernel timeline for one train step of a bench config
-   python tools/timeline_dump.py [config] [family substring]
+   python tools/timeline_dump.py [config] [family substring] [--bf16]
 prints, per (family, variant, flops, bytes) group: launches/step, avg us, executed TFLOP/s, algorithmic GB/s."""
 import collections
 import os
@@ -14,12 +14,16 @@ import bench  # noqa: E402
 from bodyct_dram_emph_subtype_amd import _lib, med3d, ops  # noqa: E402
 from bodyct_dram_emph_subtype_amd.optim import FusedAdam  # noqa: E402
 
-cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-pat = sys.argv[2] if len(sys.argv) > 2 else ""
+BF16 = "--bf16" in sys.argv
+args = [a for a in sys.argv[1:] if a != "--bf16"]
+cfg = int(args[0]) if len(args) > 0 else 1
+pat = args[1] if len(args) > 1 else ""
 os.environ["DRAM_WGRAD_STREAM"] = "0"
 factory, B, dims, *_ = bench.CONFIGS[cfg]
 torch.manual_seed(0)
 m = getattr(med3d, factory)(**(dict(n_classes=[6, 3]) if factory.endswith("cls") else {})).cuda().train()
+if BF16:
+    m.storage_dtype = torch.bfloat16
 opt = FusedAdam(m.parameters(), lr=1e-4)
 step = bench.make_step(factory, m, opt, bench.synth_batch(B, dims, 0, "cuda"))
 for _ in range(3):
