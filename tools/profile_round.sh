@@ -1,15 +1,18 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): the bench lines, the rocprofv3 kernel trace and the two PMC
 # passes (FETCH_SIZE / WRITE_SIZE in separate runs) behind profiles/rNN_*.  Output: gpurun_out/prof/.
-#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh'
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh bench'     (the bench lines)
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh prof'      (the rocprofv3 passes; two calls: one exceeds 20 min)
 # (delete the local gpurun_out/prof first: gpurun merges, it does not mirror)
 # every command's stderr is kept in a file next to its output (an empty .json.log then has its cause on record)
 # then locally:  python tools/summarize_profile.py gpurun_out/prof profiles r02
 set -e
+PHASE=${1:-all}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof
-rm -rf $O && mkdir -p $O
+mkdir -p $O
 cd $R
+if [ "$PHASE" != "prof" ]; then
 python bench.py --steps 20 --warmup 5 > $O/bench_config1.json.log 2>$O/bench_config1.err
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --detail $O/bench_config1_per_layer.txt > $O/bench_config1_detail.json.log 2>$O/bench_config1_detail.json.log.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --timeline off --no-graph > $O/bench_config1_no_timeline.json.log 2>$O/bench_config1_no_timeline.json.log.err
@@ -27,6 +30,8 @@ for spec in "1 f32" "2 bf16" "3 bf16"; do
   set -- $spec
   python bench.py --config $1 --dtype $2 --force-dist --steps 20 --warmup 5 --no-cpu-baseline --timeline off > $O/bench_config$1_$2_forcedist.json.log 2>$O/bench_config$1_$2_forcedist.json.log.err
 done
+fi
+if [ "$PHASE" = "bench" ]; then ls -la $O | head -60; exit 0; fi
 cd /tmp && export TMPDIR=/tmp
 # the profiled passes run the step on ONE stream, like bench.py's timeline pass: with the weight-gradient kernels
 # overlapping the data-gradient chain on a second stream, per-kernel durations contain the time a kernel shared its
