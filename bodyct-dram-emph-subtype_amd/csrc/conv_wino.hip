@@ -1309,6 +1309,14 @@ __global__ __launch_bounds__(512) void wino_gemm_nn_pers_kernel(const float* __r
 // counted s_waitcnt vmcnt + one barrier per item).  Results leave through a wave-private LDS turn (16 B per lane).
 // LDS rows are K floats; 16-B slot s of row r lives at slot (s & ~15) | ((s ^ r) & 15) (applied on the DMA source
 // side and on the reads: the 16 lanes of a ds_read_b128 group hit 16 different 16-B columns).
+// Cache policy of the streaming GEMM's once-read A stream (aux of global_load_lds: 2 = non-temporal); A/B build flag
+// (DRAM_EXTRA_HIPCC_FLAGS under DRAM_TUNING=1).  Measured, config 1: 765 -> 743-754 us (64->64 @ 64x128x128), 1 260 ->
+// 1 227-1 245: kept.  Non-temporal STORES of the result (gated by image size or not) and non-temporal operand loads in the
+// TN GEMMs: no effect beyond the run-to-run drift inside one process (the second run of a pair is ~2 % faster whatever
+// it runs); not kept.
+#ifndef DRAM_STREAM_NT
+#define DRAM_STREAM_NT 2
+#endif
 template <int NJ, int KT, int S>
 __global__ __launch_bounds__(256, 1) void wino_gemm_nn_stream_kernel(const float* __restrict__ A,
                                                                     const float* __restrict__ Bw, float* __restrict__ Y,
@@ -1356,7 +1364,8 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_nn_stream_kernel(const float
 #pragma unroll
     for (int j = 0; j < IPW; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + aoff[j]),
-                                       (__attribute__((address_space(3))) void*)(stage + (wave + 4 * j) * 256), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(stage + (wave + 4 * j) * 256), 16, 0,
+                                       DRAM_STREAM_NT);
   };
   auto stage_of = [&](int k) __attribute__((always_inline)) -> float* {
     return k == 0 ? st0 : (k == 1 ? st1 : (k == 2 ? st2 : st3));
