@@ -87,10 +87,27 @@ class DistContext:
         self._stat = self._grad = self._comm_stream = None       # own RCCL communicators (rccl.py) + the bucket stream
         if self.active and self._backend == "nccl" and self._transport() == "rccl":
             from . import rccl
-            self._stat = rccl.Communicator(process_group)        # used on the data stream itself
-            self._grad = rccl.Communicator(process_group)        # used on _comm_stream
-            self._comm_stream = torch.cuda.Stream()
-        elif self.active and (self.world > 1 or self._backend == "nccl"):
+            # (every rank takes the same branch: a failure to come up is agreed upon below before anybody uses either path)
+            try:
+                self._stat = rccl.Communicator(process_group)    # used on the data stream itself
+                self._grad = rccl.Communicator(process_group)    # used on _comm_stream
+                self._comm_stream = torch.cuda.Stream()
+                ok = 1
+            except (RuntimeError, OSError) as exc:
+                import sys
+                print(f"distributed: own RCCL communicators did not come up on rank {self.rank} ({exc}); "
+                      "falling back to torch.distributed's collectives", file=sys.stderr)
+                ok = 0
+            if self.world > 1:
+                flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+                ok = int(flag.item())
+            if not ok:
+                for c in (self._stat, self._grad):
+                    if c is not None:
+                        c.destroy()
+                self._stat = self._grad = self._comm_stream = None
+        if self._stat is None and self.active and (self.world > 1 or self._backend == "nccl"):
             # torch.distributed transport (gloo; nccl under DRAM_DIST_TRANSPORT=torch): under RCCL the group gets a
             # high-priority HIP stream, torch hands the results over with events
             self.stat_pg = self._new_stat_group(process_group)

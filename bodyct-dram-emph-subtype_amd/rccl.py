@@ -73,6 +73,29 @@ def available() -> bool:
         return False
 
 
+def _uid_bytes(uid: "_UniqueId") -> bytes:
+    """All 128 bytes of an ncclUniqueId (a c_char ARRAY FIELD reads back as a NUL-terminated string: `bytes(uid.internal)`
+    stops at the first zero byte, and the ids contain zeros)."""
+    return ctypes.string_at(ctypes.addressof(uid), NCCL_UNIQUE_ID_BYTES)
+
+
+def broadcast_id(raw: Optional[bytes], process_group=None) -> bytes:
+    """The 128-byte id from the group's rank 0 (which passes `raw`) to every rank, as a CPU object over whatever backend
+    the group has; returns it on every rank.  Collective."""
+    world = dist.get_world_size(process_group)
+    rank = dist.get_rank(process_group)
+    if rank == 0 and (raw is None or len(raw) != NCCL_UNIQUE_ID_BYTES):
+        raise ValueError("broadcast_id: rank 0 must pass the 128-byte id")
+    if world == 1:
+        return raw
+    box = [raw if rank == 0 else None]
+    src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+    dist.broadcast_object_list(box, src=src, group=process_group)
+    if not isinstance(box[0], (bytes, bytearray)) or len(box[0]) != NCCL_UNIQUE_ID_BYTES:
+        raise RuntimeError("broadcast_id: did not receive a 128-byte id")
+    return bytes(box[0])
+
+
 class Communicator:
     """One ncclComm_t over the ranks of a torch.distributed process group, bound to this process's current device.
     Construction is collective (every rank of the group must call it, in the same order)."""
@@ -87,12 +110,8 @@ class Communicator:
         uid = _UniqueId()
         if self.rank == 0:
             _chk(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
-        if self.world > 1:
-            # the id travels as a CPU object over whatever backend the group has (nccl groups move it through the GPU)
-            box = [bytes(uid.internal) if self.rank == 0 else None]
-            src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
-            dist.broadcast_object_list(box, src=src, group=process_group)
-            ctypes.memmove(ctypes.byref(uid), box[0], NCCL_UNIQUE_ID_BYTES)
+        raw = broadcast_id(_uid_bytes(uid) if self.rank == 0 else None, process_group)
+        ctypes.memmove(ctypes.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
         self._comm = ctypes.c_void_p()
         _chk(L.ncclCommInitRank(ctypes.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
 

@@ -24,6 +24,12 @@ def _worker(rank, world, port, q):
         ctx = DistContext(bucket_bytes=40000)
         # gloo: torch.distributed's host-side collectives -- no own RCCL communicator, not capturable into a hipGraph
         assert ctx._stat is None and ctx._grad is None and ctx.capturable is False
+        # the control-plane step of the RCCL transport: rank 0's 128-byte communicator id (zero bytes included) reaches
+        # every rank intact (rccl.broadcast_id; the id itself comes from ncclGetUniqueId on a GPU box)
+        from bodyct_dram_emph_subtype_amd import rccl
+        raw = bytes([(3 * i) % 7 for i in range(128)])
+        assert raw.count(0) > 10
+        assert rccl.broadcast_id(raw if rank == 0 else None) == raw
         # --- SyncBN statistics: global mean/var from per-rank [sum, sum^2, count]; ranks hold DIFFERENT counts
         rows = 5 + 2 * rank
         x = torch.randn(rows, 8, dtype=torch.float64)            # local "activations" [rows, C]

@@ -370,4 +370,9 @@ def test_rccl_c_api_binding_loads_every_symbol_it_calls():
         assert getattr(L, name) is not None, name
     assert ctypes.sizeof(rccl._UniqueId) == rccl.NCCL_UNIQUE_ID_BYTES == 128
     assert (rccl.SUM, rccl.AVG) == (0, 4) and rccl._DTYPES[__import__("torch").float64] == 8
+    # an id's zero bytes survive the trip into bytes and back (a c_char array FIELD reads as a NUL-terminated string)
+    raw = bytes([7, 0, 0, 9] * 32)
+    uid = rccl._UniqueId()
+    ctypes.memmove(ctypes.byref(uid), raw, 128)
+    assert rccl._uid_bytes(uid) == raw and len(bytes(uid.internal)) < 128
     assert b"success" in L.ncclGetErrorString(0).lower() or L.ncclGetErrorString(0)
