@@ -540,7 +540,10 @@ __global__ __launch_bounds__(256, 2) void wino_in444_kernel(const float* __restr
 // (identity-shortcut gradient), per-channel BatchNorm partial sums.  A workgroup owns
 // TPB consecutive tiles x 64 channels; stats row = tile block.  One xi_z plane at a time: its
 // in-plane A^T . A result is folded into the NZ output planes with the z column of A^T.
-constexpr int WINO_TPB = 16;
+// TPB: 16 tiles (four per wave) on the large grids; 4 where that leaves the chip under-filled -- the 16 x 32 x 32 stages have
+// 512 tiles, i.e. 32 tile blocks x N / 64 = 64-256 workgroups of four waves (the 128- / 256-channel launches ran at 2.1 /
+// 3.3 TB/s, latency-bound).  Also the number of statistic rows (dram_wino_num_stat_rows).
+__host__ __device__ inline int wino_tpb(int T) { return T >= 4096 ? 16 : 4; }
 __constant__ float c_at4[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};   // A^T of F(4,3)
 
 // ADD: 0 plain; 1 `+= add`; 2 `+= add * (gate > 0)` (the shortcut-gradient epilogue) -- compile-time, so that the plane of
@@ -562,8 +565,9 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
   const int c = cb * 64 + lane;
   const float bv = bias ? bias[c] : 0.f;
   float s1 = 0.f, s2 = 0.f;
-  for (int q = wave; q < WINO_TPB; q += 4) {
-    const int t = tb * WINO_TPB + q;
+  const int tpb = wino_tpb(g.T);
+  for (int q = wave; q < tpb; q += 4) {
+    const int t = tb * tpb + q;
     if (t >= g.T) break;
     // the tile's [point][t % 256][N] block of the image: buffer loads, lane offset constant, point offset scalar
     // (wino_half444: no per-lane address arithmetic)
@@ -2206,7 +2210,7 @@ int run_conv(const float* in, const float* U, const float* bias, const float* ad
   }
   const int rc = run_nn(V, U, Mh, g, N, K, s, GemmEpilogue{nullptr, nullptr, nullptr, nullptr}, math);
   if (rc != DRAM_OK) return rc;
-  const int ntb = (g.T + WINO_TPB - 1) / WINO_TPB;
+  const int ntb = (g.T + wino_tpb(g.T) - 1) / wino_tpb(g.T);
   const double out_elems = (double)g.B * g.D * g.H * g.W * N;
   DramProf prof(DRAM_FAM_WINO_OUT, g.nz * 100 + g.ny * 10 + g.nx, 0.0,
                 4.0 * ((double)g.npts * g.Tpad * N + out_elems * (1 + (add ? 1 : 0) + (gate ? 1 : 0))), s);
@@ -2532,7 +2536,7 @@ extern "C" int dram_wino_pack_weight(const float* w, float* uf, float* ub, const
 extern "C" int dram_wino_num_stat_rows(const DramConvDesc* d) {
   if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
   const WinoGeom g = make_geom(d);
-  return (g.T + WINO_TPB - 1) / WINO_TPB;
+  return (g.T + wino_tpb(g.T) - 1) / wino_tpb(g.T);
 }
 
 /* pass: 0 forward, 1 data gradient, 2 weight gradient */

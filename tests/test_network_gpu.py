@@ -587,6 +587,8 @@ def test_activation_recompute_is_bit_identical_and_smaller(factory, shape):
     for mode in (False, True):
         m = build(factory, 4).to(DEV).train()
         m.activation_recompute = mode
+        import gc
+        gc.collect()                      # (reference cycles of earlier tests would be collected -- and their tensors freed -- mid-forward)
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats()
         base = torch.cuda.memory_allocated()
