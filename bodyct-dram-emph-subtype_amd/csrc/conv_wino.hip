@@ -540,10 +540,15 @@ __global__ __launch_bounds__(256, 2) void wino_in444_kernel(const float* __restr
 // (identity-shortcut gradient), per-channel BatchNorm partial sums.  A workgroup owns
 // TPB consecutive tiles x 64 channels; stats row = tile block.  One xi_z plane at a time: its
 // in-plane A^T . A result is folded into the NZ output planes with the z column of A^T.
-// TPB: 16 tiles (four per wave) on the large grids; 4 where that leaves the chip under-filled -- the 16 x 32 x 32 stages have
-// 512 tiles, i.e. 32 tile blocks x N / 64 = 64-256 workgroups of four waves (the 128- / 256-channel launches ran at 2.1 /
-// 3.3 TB/s, latency-bound).  Also the number of statistic rows (dram_wino_num_stat_rows).
-__host__ __device__ inline int wino_tpb(int T) { return T >= 4096 ? 16 : 4; }
+// TPB: FOUR tiles per workgroup, one per wave (round 5; 16 before).  On the 16 x 32 x 32 stages 16-tile blocks were 64-256
+// workgroups -- an under-filled chip, 2.1-3.3 TB/s -- and on the large grids one tile per wave still streams better than
+// four (more workgroups in flight per CU as waves retire at different times): 483 -> 423 us on the 1.8-GB images (5.6 TB/s),
+// 59.5 -> 53.0 us on layer1's, 45 -> 30 / 36 -> 17 us on the 256- / 128-channel ones.  Also the number of statistic rows
+// (dram_wino_num_stat_rows): 8 192 rows on the largest grids, folded in stages.  -DWINO_TPB=16: A/B build flag.
+#ifndef WINO_TPB
+#define WINO_TPB 4
+#endif
+__host__ __device__ inline int wino_tpb(int) { return WINO_TPB; }
 __constant__ float c_at4[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};   // A^T of F(4,3)
 
 // ADD: 0 plain; 1 `+= add`; 2 `+= add * (gate > 0)` (the shortcut-gradient epilogue) -- compile-time, so that the plane of

@@ -36,16 +36,27 @@ __device__ __forceinline__ float4 axis_gather(const TIN* __restrict__ in, const 
                                               const int c4, const int Ni, const int m, const int C, const float scale) {
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
+  // all six loads first, no branch in between (an out-of-range tap reads a clamped address with zero weights: a
+  // per-lane `continue` around each pair kept two loads in flight)
+  float4 x0[3], x1[3];
+  float w0[3], w1[3];
+#pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int u = v + k - 1;
-    if (u < 0 || u >= 2 * Ni) continue;
+    const bool ok = u >= 0 && u < 2 * Ni;
+    const int uc = u < 0 ? 0 : (u >= 2 * Ni ? 2 * Ni - 1 : u);
     int i0, i1;
-    float w0, w1;
-    lin_src(u, scale, Ni, i0, i1, w0, w1);
+    lin_src(uc, scale, Ni, i0, i1, w0[k], w1[k]);
+    if (!ok) { w0[k] = 0.f; w1[k] = 0.f; }
     const long base = ((long)mi * 3 + k) * C + 4 * c4;
     const long row = (long)m * 3 * C;
-    acc = f4_fma(w0, ld4<TIN>(in, (o * Ni + i0) * row + base), acc);
-    acc = f4_fma(w1, ld4<TIN>(in, (o * Ni + i1) * row + base), acc);
+    x0[k] = ld4<TIN>(in, (o * Ni + i0) * row + base);
+    x1[k] = ld4<TIN>(in, (o * Ni + i1) * row + base);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    acc = f4_fma(w0[k], x0[k], acc);
+    acc = f4_fma(w1[k], x1[k], acc);
   }
   return acc;
 }
