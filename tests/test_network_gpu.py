@@ -317,6 +317,7 @@ def _dram_loss_checks(models, dd, od, lungs, ems, cle, pse, cw, pw):
 
 
 R50_DRAM_GRAD_TOL = 3e-4
+MID_GRAD_TOL = 2e-4
 
 
 @pytest.mark.parametrize("factory", ["resnet34segcls", "resnet18segreg", "resnet50segreg"])
@@ -328,7 +329,7 @@ def test_mid_size_train_step_vs_oracle(factory):
     GEMMs (plan 3) and the 2304->64 decoder convolution runs the Winograd pipeline unforced.
     Outputs 1e-3 vs the fp32 oracle; loss + its gradient fields (see _dram_loss_checks); then the network backward
     of exactly those fields: HIP vs the decision-pinned fp64 oracle given the same upstream, every parameter
-    <= GRAD_TOL (ResNet-18 / -34) or R50_DRAM_GRAD_TOL (absolute bars; the CPU fp32 oracle's own distance from fp64
+    <= MID_GRAD_TOL (ResNet-18 / -34) or R50_DRAM_GRAD_TOL (absolute bars; the CPU fp32 oracle's own distance from fp64
     on the same piece is printed next to it: 2e-5 (R18) / 7e-5 (R50))."""
     from bodyct_dram_emph_subtype_amd import med3d, models
     dims = (64, 128, 128)
@@ -371,10 +372,12 @@ def test_mid_size_train_step_vs_oracle(factory):
         worst = max(worst, (e, e_cpu, n))
         table.append((e, e_cpu, n))
         # ABSOLUTE bars (the CPU oracle's own distance from fp64 moves with its thread count: a bar that floats with
-        # it is not one): GRAD_TOL for the BasicBlock networks (measured 5.3-5.6e-5), 3e-4 for ResNet-50 under the dRAM
-        # loss = 2 x the worst measured tensor of round 5 (us1.conv_blocks.1.1.weight 1.45e-4; the CPU fp32 oracle
-        # itself sits 7.5e-5 from fp64 there).  Rounds 2-4 carried 1.5e-3 for conv1.weight (8.4-9.5e-4 then).
-        bar = R50_DRAM_GRAD_TOL if factory.startswith("resnet50") else GRAD_TOL
+        # it is not one): 2e-4 for the BasicBlock networks -- the full-size bar; measured 5.3-5.6e-5 while layer1 ran the
+        # fused in-plane kernels and 1.2e-4 (layer1.0.bn2.weight, dRAM loss) on the round-5 plan, whose F(4,3)^3 tiles
+        # round 10 x more per layer there --, 3e-4 for ResNet-50 under the dRAM loss = 2 x the worst measured tensor of
+        # round 5 (us1.conv_blocks.1.1.weight 1.45e-4; the CPU fp32 oracle itself sits 7.5e-5 from fp64 there).
+        # Rounds 2-4 carried 1.5e-3 for conv1.weight (8.4-9.5e-4 then).
+        bar = R50_DRAM_GRAD_TOL if factory.startswith("resnet50") else MID_GRAD_TOL
         assert e <= bar, f"{n}: hip {e:.2e} vs decision-pinned fp64 oracle (CPU fp32: {e_cpu:.2e})"
     table.sort(reverse=True)
     print(f"[{factory} 1x64x128x128] per-tensor gradient errors, largest five (hip, cpu-fp32, tensor): {table[:5]}")
