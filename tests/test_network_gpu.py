@@ -317,6 +317,8 @@ def _dram_loss_checks(models, dd, od, lungs, ems, cle, pse, cw, pw):
 
 
 R50_DRAM_GRAD_TOL = 3e-4
+R50_DRAM_OUTLIERS = ("conv1.weight", "bn1.weight", "bn1.bias")
+R50_STEM_GRAD_TOL = 1.5e-3
 MID_GRAD_TOL = 2e-4
 
 
@@ -377,7 +379,14 @@ def test_mid_size_train_step_vs_oracle(factory):
         # round 10 x more per layer there --, 3e-4 for ResNet-50 under the dRAM loss = 2 x the worst measured tensor of
         # round 5 (us1.conv_blocks.1.1.weight 1.45e-4; the CPU fp32 oracle itself sits 7.5e-5 from fp64 there).
         # Rounds 2-4 carried 1.5e-3 for conv1.weight (8.4-9.5e-4 then).
-        bar = R50_DRAM_GRAD_TOL if factory.startswith("resnet50") else MID_GRAD_TOL
+        # The NAMED outliers of ResNet-50 under the dRAM loss are the stem's tensors: their gradient sums over 10^6 voxels of
+        # an outlier-dominated field cancel, and the result moves between 1e-4 and 9.5e-4 with the rounding realisation
+        # (8.4-9.5e-4 in rounds 2-4, 9e-5 and 8.1e-4 on two builds of round 5 that differ in the order of BatchNorm partial
+        # sums only): 1.5e-3 for them, as rounds 2-4 had for every tensor.
+        if factory.startswith("resnet50"):
+            bar = R50_STEM_GRAD_TOL if n in R50_DRAM_OUTLIERS else R50_DRAM_GRAD_TOL
+        else:
+            bar = MID_GRAD_TOL
         assert e <= bar, f"{n}: hip {e:.2e} vs decision-pinned fp64 oracle (CPU fp32: {e_cpu:.2e})"
     table.sort(reverse=True)
     print(f"[{factory} 1x64x128x128] per-tensor gradient errors, largest five (hip, cpu-fp32, tensor): {table[:5]}")
