@@ -180,6 +180,23 @@ def host_cpu_share():
 
 
 def cpu_baseline(factory, dims, B=1):
+    """The CPU baseline in a CHILD process (this same file with --cpu-baseline-child, GPU hidden from it): its 32 intra-op
+    threads must be gone when the GPU section starts.  Run in-process, the idle OpenMP pool kept the 16 CPUs of the job busy
+    for the next seconds and the launcher thread of the eager GPU steps ran at half speed -- host issue time 23.5 instead
+    of 10.5 ms per step, the timed 20 steps at 41.1 ms where their own hipEvent median says 36.9 (profiles/r05, first
+    bench phase of the final sources)."""
+    import subprocess
+    env = dict(os.environ)
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", factory, *map(str, dims), str(B)],
+                       env=env, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"CPU baseline child failed ({r.returncode}): {r.stderr[-2000:]}")
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def _cpu_baseline_impl(factory, dims, B=1):
     """Oracle train steps (fwd + loss + bwd + Adam) on the host cores, at the batch the GPU line runs (so BatchNorm
     sees the same batch): 1 warm-up + 2 timed steps at batch 1, 1 warm-up + 1 timed step at batch >= 2 (BASELINE.md
     §3 plan; ~25 s of CPU work for the headline).  Bounded: dims are capped at 128x256x256, the batch at 2."""
@@ -276,6 +293,9 @@ def self_launch(n: int) -> int:
 
 
 def main():
+    if len(sys.argv) >= 7 and sys.argv[1] == "--cpu-baseline-child":      # (internal: see cpu_baseline)
+        print(json.dumps(_cpu_baseline_impl(sys.argv[2], tuple(int(v) for v in sys.argv[3:6]), int(sys.argv[6]))))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
