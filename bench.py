@@ -318,9 +318,13 @@ def main():
                          "number for DESIGN.md, not the BASELINE metric")
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="capture the train step (fwd + loss + bwd + Adam) in one hipGraph and time its replays "
-                         "(bit-identical to eager steps): the default on one GPU for bf16 storage and for config 0; "
-                         "fp32 configs 1 / 3 / 5, data-parallel runs and --detail / --predict default to eager steps")
+                         "(bit-identical to eager steps): the default on one GPU (fp32 storage: with two branches, see "
+                         "--graph-streams) and for bf16 data-parallel runs; fp32 data-parallel runs, a gloo rehearsal and "
+                         "--detail / --predict default to eager steps")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="time eager steps on one GPU too")
+    ap.add_argument("--graph-streams", type=int, choices=(1, 2), default=None,
+                    help="branches of the captured step: 2 keeps the weight-gradient side stream inside the graph (default for "
+                         "fp32 storage on one GPU), 1 = single-stream capture (default for bf16 storage and config 0)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend; gloo + --share-gpu rehearses the N>1 control flow on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only, not a measurement)")
@@ -362,14 +366,21 @@ def main():
     import torch.distributed as dist
     use_dist = world > 1 or args.force_dist
     if args.graph is None:
-        # default: hipGraph replay where the step is gap-bound -- bf16 storage (config 2: 104 -> 110 volumes/s, config 3
-        # in bf16: 41.5 -> 44.6) and the small config 0 (67-93 -> 99); the fp32 steps of configs 1 / 3 / 5 stay eager:
-        # the captured step is single-stream, and the weight-gradient side stream is worth as much as the gaps there
-        # (config 1: 44.0 ms eager, 44.7 as a graph, 11 GB more for the graph's private pool)
-        # data parallel: the same rule -- under RCCL the collectives are plain stream work and are captured with the step
-        # (distributed.DistContext.capturable); a gloo rehearsal runs eager
-        args.graph = (not (args.predict or args.detail or (use_dist and args.backend != "nccl"))) and \
-            (args.dtype == "bf16" or args.config == 0)
+        # default on ONE GPU: the step replayed as a hipGraph.  bf16 storage and the small config 0: one branch (gap-bound
+        # steps: config 2 104 -> 110 volumes/s, config 0 67-93 -> 99 in round 3).  fp32 configs 1 / 3 / 5: TWO branches (the
+        # eager step's second stream kept inside the capture, GraphedTrainStep(streams=2)): 37.0 ms against 36.8-37.1 for the
+        # eager two-stream step, and independent of the host -- a cold host (first process on a fresh box) issued the eager
+        # step in 23.7 instead of 6.9 ms and left gaps: 42.3 ms for a step whose hipEvent median said 37.0 (round 5).
+        # Data parallel: bf16 storage replays a graph WITH its collectives (RCCL through its C API is plain stream work,
+        # distributed.DistContext.capturable); fp32 data-parallel steps and a gloo rehearsal run eager.
+        if args.predict or args.detail or (use_dist and args.backend != "nccl"):
+            args.graph = False
+        elif use_dist:
+            args.graph = args.dtype == "bf16" or args.config == 0
+        else:
+            args.graph = True
+    if args.graph_streams is None:
+        args.graph_streams = 2 if (args.dtype == "f32" and args.config != 0 and not use_dist) else 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -436,7 +447,7 @@ def main():
                 return reg_train_loss(dense, outs, lung, em, cle, pse, cwt, pwt)[0]
         eager_step = step
         try:
-            graphed = GraphedTrainStep(module, opt, loss_fn, batch, warmup=2)
+            graphed = GraphedTrainStep(module, opt, loss_fn, batch, warmup=2, streams=args.graph_streams)
             if graphed.graph is None:           # (data parallel: the runtime refused to record the collectives)
                 args.graph = False
             else:
@@ -497,7 +508,7 @@ def main():
         try:
             pstep = eager_step if args.graph else step
             if args.graph:
-                g2 = GraphedTrainStep(module, opt, loss_fn, batch, warmup=2)
+                g2 = GraphedTrainStep(module, opt, loss_fn, batch, warmup=2, streams=args.graph_streams)
                 pstep = lambda: g2(*batch)      # noqa: E731
             for _ in range(max(2, args.warmup)):
                 pstep()
@@ -572,7 +583,8 @@ def main():
                                    f"{'fp32' if args.dtype == 'f32' else 'bf16 storage / fp32 accumulation, statistics and parameters'}, "
                                    f"inputs resident in HBM",
                        "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(args.graph),
-                       "streams": 1 if (args.detail or args.graph or ops.tuning_env("DRAM_WGRAD_STREAM", "1") == "0") else 2,
+                       "streams": (args.graph_streams if args.graph else
+                                   (1 if (args.detail or ops.tuning_env("DRAM_WGRAD_STREAM", "1") == "0") else 2)),
                        "train_gflop_per_volume": gflop_per_vol},
             # host time to issue a step (waits for the GPU excluded); close to ms_per_step = the step is launch-bound
             "host_issue_ms_per_step": host_issue_s / args.steps * 1e3,

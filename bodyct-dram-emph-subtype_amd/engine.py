@@ -71,6 +71,7 @@ class Engine:
         self._conv_lists: Dict[tuple, list] = {}     # input shape -> [(weight name, geometry)] of a forward
         self._inflight: List[torch.cuda.Event] = []  # end-of-backward events of the steps the host has issued
         self.throttle_wait_s = 0.0                   # host time spent waiting in _throttle (bench.py reports it)
+        self.graph_streams = 1                       # branches of a hipGraph capture of the step (graph.GraphedTrainStep)
 
     # ------------------------------------------------------------------ BN helpers
     def _bn_fwd(self, st: _State, y: Tensor, sp: Optional[Tensor], bnp: str, residual, rs, relu=True, pool=False,
@@ -447,19 +448,21 @@ class Engine:
                 self._inflight.pop(0).synchronize()
             self.throttle_wait_s += time.perf_counter() - t0
 
-    @staticmethod
-    def _two_streams() -> bool:
+    def _two_streams(self) -> bool:
         """Weight-gradient kernels and the per-step weight packing on the engine's second stream?  Eager steps: yes.
-        While the step is being captured into a hipGraph: no -- the two-branch schedule CAN be captured (the side stream
-        forks from the capturing stream by wait_stream / event and rejoins it before the step ends;
-        DRAM_GRAPH_STREAMS=2 under DRAM_TUNING=1), but measured it buys little once the launch gaps are gone: config 1
-        42.91 / 42.92 ms, config 3 fp32 41.45 / 41.83, config 2 bf16 17.47 / 18.07, config 3 bf16 17.94 / 18.83 (one /
-        two branches) mid-round 4; 40.28 / 39.82 ms (config 1), 39.65 / 39.40 (config 3 fp32) once layer1's weight
-        gradients ran the HBM-bound pipeline, which does overlap the matrix-bound data-gradient chain -- against 5.6 GB
-        more for the graph's pool and an eager two-stream step that is as fast (39.2 ms)."""
+        While the step is being captured into a hipGraph: when the capture asks for it (`graph_streams` = 2, set by
+        graph.GraphedTrainStep(streams=2); DRAM_GRAPH_STREAMS=2 under DRAM_TUNING=1 forces it) -- the side stream forks from
+        the capturing stream by wait_stream / event and rejoins it before the step ends, so the graph has two branches.
+        Measured: in round 4 it bought little once the launch gaps were gone (config 1 42.91 / 42.92 ms, config 3 fp32
+        41.45 / 41.83, config 2 bf16 17.47 / 18.07 one / two branches); in round 5, with layer1's weight gradients on the
+        HBM-bound pipeline, config 1 replays at 37.20 / 37.00 ms against 36.8-37.1 for the eager two-stream step -- and the
+        replay does not depend on the host (a cold host issues the eager step in 23.7 instead of 6.9 ms and leaves gaps:
+        42.3 ms), for 14 GB more (the graph's private pool)."""
         if ops.tuning_env("DRAM_WGRAD_STREAM", "1") == "0":
             return False
-        return not (torch.cuda.is_current_stream_capturing() and ops.tuning_env("DRAM_GRAPH_STREAMS", "1") != "2")
+        if not torch.cuda.is_current_stream_capturing():
+            return True
+        return self.graph_streams == 2 or ops.tuning_env("DRAM_GRAPH_STREAMS", "1") == "2"
 
     def _prepack(self, st: _State, key):
         """Training steps repack / re-transform every convolution weight (21 launches for ResNet-18, independent

@@ -33,14 +33,20 @@ from .optim import FusedAdam
 
 class GraphedTrainStep:
     def __init__(self, module: torch.nn.Module, optimizer: FusedAdam, loss_fn: Callable[..., torch.Tensor],
-                 example_inputs: Sequence[torch.Tensor], warmup: int = 2):
+                 example_inputs: Sequence[torch.Tensor], warmup: int = 2, streams: int = 1):
+        """streams = 2: the captured step keeps the eager step's second branch (weight-gradient kernels and the per-step
+        weight packing fork from the capturing stream and rejoin it) -- worth it where the two chains use different pipes
+        (fp32 configs: matrix-bound weight-gradient GEMMs beside the HBM-bound transforms of the data-gradient chain)."""
         if not isinstance(optimizer, FusedAdam) or not optimizer.capturable:
             raise TypeError("GraphedTrainStep needs FusedAdam(..., capturable=True)")
         ctx = getattr(getattr(module, "model", module), "_dist", None)
         if ctx is not None and not ctx.capturable:
             raise NotImplementedError("graph capture of a data-parallel step needs the RCCL transport (a gloo process "
                                       "group runs its collectives on the host)")
+        if streams not in (1, 2):
+            raise ValueError("GraphedTrainStep: streams must be 1 or 2")
         self.module, self.optimizer, self.loss_fn = module, optimizer, loss_fn
+        engine = getattr(getattr(module, "model", module), "_engine", None)
         self.static = [t.clone() for t in example_inputs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -51,10 +57,15 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         self._keep: list = []                         # scratch buffers / device work lists the captured launches point at
+        prev_streams = engine.graph_streams if engine is not None else 1
+        if engine is not None:
+            engine.graph_streams = streams
         try:
             with ops.capture_keepalive(self._keep), torch.cuda.graph(self.graph):
                 self.static_loss = self._eager()
         except RuntimeError as exc:
+            if engine is not None:
+                engine.graph_streams = prev_streams
             if ctx is None:
                 raise
             # collectives the runtime would not record: the data-parallel step stays correct, eagerly
@@ -64,6 +75,8 @@ class GraphedTrainStep:
             self.graph = None
             self._keep.clear()
             torch.cuda.synchronize()
+        if engine is not None:
+            engine.graph_streams = prev_streams
         self.steps_captured_eagerly = max(1, warmup)          # the capture pass itself does not execute
 
     def _eager(self):

@@ -263,9 +263,11 @@ def test_graphed_train_step_equals_eager_steps():
             opt.step()
             return loss.detach().clone()
         losses = []
-        if mode == "graph":
+        if mode.startswith("graph"):
             # the constructor runs 2 eager warm-up steps on the example batch: mirror them in the other modes
-            step = GraphedTrainStep(m, opt, loss_fn, batches[0], warmup=2)
+            # ("graph2": the capture keeps the weight-gradient side stream as a second branch of the graph)
+            step = GraphedTrainStep(m, opt, loss_fn, batches[0], warmup=2, streams=2 if mode == "graph2" else 1)
+            assert m._engine.graph_streams == 1          # (the setting is the capture's, not the engine's)
         else:
             eager(batches[0]); eager(batches[0])
             step = lambda *b: eager(b)
@@ -279,6 +281,11 @@ def test_graphed_train_step_equals_eager_steps():
         return losses, sd, st
 
     l_g, sd_g, st_g = run("graph")
+    l_g2, sd_g2, st_g2 = run("graph2")
+    for a, b in zip(l_g, l_g2):
+        assert torch.equal(a, b)
+    for k in sd_g:
+        assert torch.equal(sd_g[k], sd_g2[k]), k
     l_e, sd_e, st_e = run("eager-capturable")
     l_p, sd_p, st_p = run("plain")
     print("graph", [float(v) for v in l_g], "eager-capturable", [float(v) for v in l_e], "plain", [float(v) for v in l_p])
