@@ -318,13 +318,13 @@ def main():
                          "number for DESIGN.md, not the BASELINE metric")
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="capture the train step (fwd + loss + bwd + Adam) in one hipGraph and time its replays "
-                         "(bit-identical to eager steps): the default on one GPU (fp32 storage: with two branches, see "
-                         "--graph-streams) and for bf16 data-parallel runs; fp32 data-parallel runs, a gloo rehearsal and "
+                         "(bit-identical to eager steps; the number then does not depend on how fast the host issues "
+                         "launches): the default on one GPU and for bf16 data-parallel runs; fp32 data-parallel runs, a gloo rehearsal and "
                          "--detail / --predict default to eager steps")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="time eager steps on one GPU too")
-    ap.add_argument("--graph-streams", type=int, choices=(1, 2), default=None,
-                    help="branches of the captured step: 2 keeps the weight-gradient side stream inside the graph (default for "
-                         "fp32 storage on one GPU), 1 = single-stream capture (default for bf16 storage and config 0)")
+    ap.add_argument("--graph-streams", type=int, choices=(1, 2), default=1,
+                    help="branches of the captured step: 1 = single-stream capture (default); 2 keeps the weight-gradient side "
+                         "stream inside the graph (measured equal on config 1, slower on config 0 / 2: DESIGN.md section 6)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend; gloo + --share-gpu rehearses the N>1 control flow on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only, not a measurement)")
@@ -379,8 +379,6 @@ def main():
             args.graph = args.dtype == "bf16" or args.config == 0
         else:
             args.graph = True
-    if args.graph_streams is None:
-        args.graph_streams = 2 if (args.dtype == "f32" and args.config != 0 and not use_dist) else 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")

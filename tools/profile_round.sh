@@ -17,7 +17,7 @@ python bench.py --steps 20 --warmup 5 > $O/bench_config1.json.log 2>$O/bench_con
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --detail $O/bench_config1_per_layer.txt > $O/bench_config1_detail.json.log 2>$O/bench_config1_detail.json.log.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --timeline off --no-graph > $O/bench_config1_no_timeline.json.log 2>$O/bench_config1_no_timeline.json.log.err
 for c in 0 3 5; do python bench.py --config $c --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_config$c.json.log 2>$O/bench_config$c.json.log.err; done
-python bench.py --config 1 --graph --graph-streams 1 --steps 10 --warmup 3 --no-cpu-baseline --timeline off > $O/bench_config1_graph1.json.log 2>$O/bench_config1_graph1.json.log.err     # (default: two branches)
+python bench.py --config 1 --graph --graph-streams 2 --steps 10 --warmup 3 --no-cpu-baseline --timeline off > $O/bench_config1_graph2.json.log 2>$O/bench_config1_graph2.json.log.err     # (default: one branch)
 python bench.py --config 3 --no-graph --steps 10 --warmup 3 --no-cpu-baseline --timeline off > $O/bench_config3_eager.json.log 2>$O/bench_config3_eager.json.log.err
 python bench.py --config 2 --no-graph --steps 10 --warmup 3 --no-cpu-baseline --timeline off > $O/bench_config2_eager.json.log 2>$O/bench_config2_eager.json.log.err
 python bench.py --config 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_config2.json.log 2>$O/bench_config2.json.log.err          # bf16, as specified
