@@ -94,6 +94,8 @@ SIGNATURES = {
     "dram_wino_conv3d_fwd_cat": (I, [P, I, P, I, P, P, P, P, P, DP, P, SZ, P]),
     "dram_wino_conv3d_fwd_bn": (I, [P, P, P, P, P, P, P, P, DP, P, SZ, P]),
     "dram_wino_conv3d_bwd_data": (I, [P, P, P, P, P, DP, P, SZ, P]),
+    "dram_wino_num_stat_rows_bwd": (I, [DP]),
+    "dram_wino_conv3d_bwd_data_bn": (I, [P, P, P, P, P, P, P, P, P, DP, P, SZ, P]),
     "dram_wino_conv3d_bwd_weight": (I, [P, P, P, P, DP, P, SZ, P]),
     "dram_stem_num_tiles": (I, [I, I, I, I]),
     "dram_stem_fwd": (I, [P, P, P, P, I, I, I, I, P]),
@@ -179,7 +181,7 @@ SIGNATURES = {
 }
 
 OPT_CHUNK = 16384
-ABI_VERSION = 6
+ABI_VERSION = 7
 _LIB = None
 
 

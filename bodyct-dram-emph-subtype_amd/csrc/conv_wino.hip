@@ -553,11 +553,18 @@ __constant__ float c_at4[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 
 
 // ADD: 0 plain; 1 `+= add`; 2 `+= add * (gate > 0)` (the shortcut-gradient epilogue) -- compile-time, so that the plane of
 // epilogue operands is loaded without a branch in between
-template <int NZ, int NY, int NX, bool NT, int ADD = 0>
-__global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ mh, const float* __restrict__ bias,
+// BST (data gradient): the tensor written here is dz of the BatchNorm + ReLU unit in FRONT of this convolution
+// (reference med3d.py:121-124 backward); its statistics pass -- g = dz * (y*scale + shift > 0), rows (sum g, sum g*xhat),
+// bn.hip colreduce_kernel<1> -- is taken here on the values being stored: one read of that unit's y beside the store
+// instead of a pass of its own over dz and y.
+struct BnBwdStat { const float* y; const float* mean; const float* invstd; const float* scale; const float* shift; };
+// (F(4,3)^3: four workgroups per CU = 128 registers; the statistics form would otherwise take 129 and lose a wave per SIMD)
+template <int NZ, int NY, int NX, bool NT, int ADD = 0, int BST = 0>
+__global__ __launch_bounds__(256, (BST && NZ == 4 && NY == 4 && NX == 4) ? 4 : 1) void wino_out_kernel(const float* __restrict__ mh, const float* __restrict__ bias,
                                                        const float* __restrict__ add, const float* __restrict__ gate,
                                                        float* __restrict__ out, float* __restrict__ stats,
-                                                       const WinoGeom g, const int N) {
+                                                       const WinoGeom g, const int N, const BnBwdStat bs) {
+  static_assert(!(ADD && BST), "statistics of the unit in front: plain data gradient only");
   constexpr int NI = NZ + 2, NJ = NY + 2, NK = NX + 2;
   __shared__ float red[4][2][64];
   const int lane = threadIdx.x & 63;
@@ -570,6 +577,8 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
   const int c = cb * 64 + lane;
   const float bv = bias ? bias[c] : 0.f;
   float s1 = 0.f, s2 = 0.f;
+  float bmu = 0.f, bis = 0.f, bsc = 0.f, bsh = 0.f;
+  if (BST) { bmu = bs.mean[c]; bis = bs.invstd[c]; bsc = bs.scale[c]; bsh = bs.shift[c]; }
   const int tpb = wino_tpb(g.T);
   for (int q = wave; q < tpb; q += 4) {
     const int t = tb * tpb + q;
@@ -665,9 +674,25 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(add ? add : out) + wbase, 0, wbytes, WINO_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rgate =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gate ? gate : out) + wbase, 0, wbytes, WINO_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rbn =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BST ? bs.y : out) + wbase, 0, wbytes, WINO_RSRC_FLAGS);
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
       const int z = z0 + i * g.d;
+      float yv[BST ? NY : 1][BST ? NX : 1];
+      if (BST) {                   // the plane of y values, back to back like the shortcut-gradient operands below
+#pragma unroll
+        for (int j = 0; j < NY; ++j) {
+          const int y = y0 + j * g.d;
+#pragma unroll
+          for (int k = 0; k < NX; ++k) {
+            const int x = x0 + k * g.d;
+            const bool ok = (z < g.D) & (y < g.H) & (x < g.W);                                               // wave-uniform
+            const unsigned so = ok ? (unsigned)(i * g.d) * plane_b + (unsigned)y * line_b + (unsigned)x * row_b : WINO_OOB;
+            yv[BST ? j : 0][BST ? k : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbn, (int)c4, (int)so, 0));
+          }
+        }
+      }
       // shortcut-gradient operands of the whole output plane first (up to 2 x NY x NX loads in flight), then the
       // arithmetic and the stores: with each load next to its use the epilogue ran one or two loads at a time -- the
       // three 512-channel data-gradient launches of config 1 took 186 us for 427 MB (2.3 TB/s) where the plain ones of
@@ -701,8 +726,15 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
             float v = o[i][j][k] + bv;
             if (ADD) v += gv[ADD ? j : 0][ADD ? k : 0] > 0.f ? av[ADD ? j : 0][ADD ? k : 0] : 0.f;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)c4, so, 0);
-            s1 += v;
-            s2 += v * v;
+            if (BST) {             // (the expressions of colreduce_kernel<1>: mask re-derived with the forward's own fma)
+              const float yy = yv[BST ? j : 0][BST ? k : 0];
+              const float gg = __builtin_fmaf(yy, bsc, bsh) > 0.f ? v : 0.f;
+              s1 += gg;
+              s2 += gg * ((yy - bmu) * bis);
+            } else {
+              s1 += v;
+              s2 += v * v;
+            }
           }
         }
       }
@@ -2197,8 +2229,9 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
 int run_conv(const float* in, const float* U, const float* bias, const float* add, const float* gate, float* out,
              float* stats, float* v_keep, const DramConvDesc* d, int pass, int K, int N, void* ws, size_t ws_bytes,
              hipStream_t s, const float* pscale = nullptr, const float* pshift = nullptr, const float* in1 = nullptr,
-             const int C0 = 0) {
+             const int C0 = 0, const BnBwdStat bst = BnBwdStat{nullptr, nullptr, nullptr, nullptr, nullptr}) {
   const WinoGeom g = make_geom(d, pass);
+  if (bst.y && (add || gate || !stats)) return DRAM_ERR_BAD_ARG;
   const size_t need = (size_t)g.npts * g.Tpad * ((size_t)K + N) * sizeof(float);
   if (!ws || ws_bytes < need) return DRAM_ERR_WORKSPACE;
   float* V = v_keep ? v_keep : (float*)ws;          // kept for the weight gradient when the caller asks
@@ -2218,18 +2251,21 @@ int run_conv(const float* in, const float* U, const float* bias, const float* ad
   const int ntb = (g.T + wino_tpb(g.T) - 1) / wino_tpb(g.T);
   const double out_elems = (double)g.B * g.D * g.H * g.W * N;
   DramProf prof(DRAM_FAM_WINO_OUT, g.nz * 100 + g.ny * 10 + g.nx, 0.0,
-                4.0 * ((double)g.npts * g.Tpad * N + out_elems * (1 + (add ? 1 : 0) + (gate ? 1 : 0))), s);
+                4.0 * ((double)g.npts * g.Tpad * N + out_elems * (1 + (add ? 1 : 0) + (gate ? 1 : 0) + (bst.y ? 1 : 0))), s);
 #define W_OUT2(NZ_, NY_, NX_, NT_)                                                                                        \
   do {                                                                                                                    \
     if (add && gate)                                                                                                      \
       hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_, NX_, NT_, 2>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add,     \
-                         gate, out, stats, g, N);                                                                         \
+                         gate, out, stats, g, N, bst);                                                                    \
     else if (add)                                                                                                         \
       hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_, NX_, NT_, 1>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add,     \
-                         gate, out, stats, g, N);                                                                         \
+                         gate, out, stats, g, N, bst);                                                                    \
+    else if (bst.y)                                                                                                       \
+      hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_, NX_, NT_, 0, 1>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add,  \
+                         gate, out, stats, g, N, bst);                                                                    \
     else                                                                                                                  \
       hipLaunchKernelGGL((wino_out_kernel<NZ_, NY_, NX_, NT_, 0>), dim3(ntb * (N / 64)), dim3(256), 0, s, Mh, bias, add,     \
-                         gate, out, stats, g, N);                                                                         \
+                         gate, out, stats, g, N, bst);                                                                    \
   } while (0)
 #define W_OUT(NZ_, NY_, NX_)                                                                                              \
   do {                                                                                                                    \
@@ -2604,6 +2640,24 @@ extern "C" int dram_wino_conv3d_bwd_data(const float* dy, const float* ub, float
   if (!dram_wino_applicable(d)) return DRAM_ERR_UNSUPPORTED;
   return run_conv(dy, ub, nullptr, add, gate, dx, nullptr, nullptr, d, 1, d->Cout, d->Cin, workspace, workspace_bytes,
                   (hipStream_t)stream);
+}
+
+extern "C" int dram_wino_num_stat_rows_bwd(const DramConvDesc* d) {
+  if (!dram_wino_applicable(d)) return 0;
+  const WinoGeom g = make_geom(d, 1);
+  return (g.T + wino_tpb(g.T) - 1) / wino_tpb(g.T);
+}
+
+extern "C" int dram_wino_conv3d_bwd_data_bn(const float* dy, const float* ub, float* dx, const float* bn_y,
+                                            const float* bn_mean, const float* bn_invstd, const float* bn_scale,
+                                            const float* bn_shift, float* stats_partial, const DramConvDesc* d,
+                                            void* workspace, size_t workspace_bytes, dram_stream_t stream) {
+  if (!dy || !ub || !dx || !bn_y || !bn_mean || !bn_invstd || !bn_scale || !bn_shift || !stats_partial)
+    return DRAM_ERR_BAD_ARG;
+  if (!dram_wino_applicable(d) || d->Cin % 64) return DRAM_ERR_UNSUPPORTED;
+  return run_conv(dy, ub, nullptr, nullptr, nullptr, dx, stats_partial, nullptr, d, 1, d->Cout, d->Cin, workspace,
+                  workspace_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, 0,
+                  BnBwdStat{bn_y, bn_mean, bn_invstd, bn_scale, bn_shift});
 }
 
 extern "C" int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache, const float* dy, float* dw,

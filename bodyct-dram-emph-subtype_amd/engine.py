@@ -112,7 +112,9 @@ class Engine:
     def _bn_bwd(self, st: _State, c: dict, dz: Tensor) -> Tensor:
         bnp = c["bn"]
         zmask, (sc, sh) = (c["z"], (None, None)) if c.get("ss") is None else (None, c["ss"])
-        part = ops.bn_bwd_reduce(dz, zmask, c["y"], c["mean"], c["invstd"], True, sc, sh)
+        part = c.pop("part", None)      # taken by the data gradient that produced dz (_conv_bn_bwd, nxt), or a pass here
+        if part is None:
+            part = ops.bn_bwd_reduce(dz, zmask, c["y"], c["mean"], c["invstd"], True, sc, sh)
         # parameter gradients use the LOCAL sums (DDP averages them afterwards), the input
         # gradient the all-reduced ones -- torch SyncBatchNorm semantics.
         sums, sf = ops.reduce_partials(part, want_f32=True)     # (the float copy: the two parameter gradients, its rows)
@@ -194,7 +196,10 @@ class Engine:
                      count=count, w=wname, b=bname, bn=bnp, v=v, ss=ss)
         return (dict(y=y, ss=ss) if defer_z else z), c
 
-    def _conv_bn_bwd(self, st: _State, c: dict, dz: Tensor, need_dx=True, add=None, gate=None):
+    def _conv_bn_bwd(self, st: _State, c: dict, dz: Tensor, need_dx=True, add=None, gate=None, nxt: Optional[dict] = None):
+        """nxt: the context of the unit whose BatchNorm + ReLU output is this convolution's (only) input -- the returned
+        gradient is that unit's dz.  Where the data gradient can take that unit's backward statistics on its way out
+        (ops.conv_bwd_bnstats_ok) they are left in nxt['part'] and its _bn_bwd skips the pass over dz and y."""
         dy = self._bn_bwd(st, c, dz)
         if st.side is not None:
             # second stream: concurrent with the data-gradient chain (and, data parallel, with the host-visible
@@ -208,6 +213,11 @@ class Engine:
             self._wgrad(st, c, dy)
         if not need_dx:
             return None
+        if (nxt is not None and add is None and gate is None and nxt.get("ss") is not None
+                and ops.conv_bwd_bnstats_ok(c["g"], dy.dtype)):
+            dx, nxt["part"] = ops.conv3d_bwd_data_bnstats(dy, c["wb"], c["g"], nxt["y"], nxt["mean"], nxt["invstd"],
+                                                          *nxt["ss"])
+            return dx
         return ops.conv3d_bwd_data(dy, c["wb"], c["g"], add, gate)
 
     @staticmethod
@@ -303,8 +313,8 @@ class Engine:
         *cs, has_ds = ctx
         last = cs[-1]
         d = dz_out
-        for c in reversed(cs[1:]):
-            d = self._conv_bn_bwd(st, c, d)
+        for i in range(len(cs) - 1, 0, -1):
+            d = self._conv_bn_bwd(st, cs[i], d, nxt=cs[i - 1])
         if has_ds:
             return self._conv_bn_bwd(st, cs[0], d, need_dx=need_dx, add=extra_add, gate=None)
         if extra_add is not None:
@@ -396,7 +406,7 @@ class Engine:
 
     def _up_bwd(self, st, ctx, dz, skip_view=False):
         ca, cb, src_shape, skip_shape = ctx
-        dza = self._conv_bn_bwd(st, cb, dz)
+        dza = self._conv_bn_bwd(st, cb, dz, nxt=ca)
         if ca.get("kind") == "upmix":
             return self._upmix_bwd(st, ca, dza)
         dcat = self._conv_bn_bwd(st, ca, dza)
@@ -604,7 +614,7 @@ class Engine:
         if st.dist is not None:
             st.dist.grads_ready(st.grads, ["fcs.0.weight", "fcs.0.bias", "fcs.1.weight", "fcs.1.bias"])
 
-        dxup2 = self._conv_bn_bwd(st, saved["cu3"], dxup3)
+        dxup2 = self._conv_bn_bwd(st, saved["cu3"], dxup3, nxt=saved["cu2"][1])
         dxup1, dskip_stem = self._up_bwd(st, saved["cu2"], dxup2, skip_view=True)   # consumed by maxpool_bwd
         d, dskip_x1 = self._up_bwd(st, saved["cu1"], dxup1)
 

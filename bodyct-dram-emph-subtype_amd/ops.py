@@ -726,6 +726,41 @@ def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] =
     return dx
 
 
+def conv_bwd_bnstats_ok(g: ConvGeom, dtype=torch.float32) -> bool:
+    """Can the data gradient of this convolution also take the BatchNorm-backward statistics of the unit in front of it
+    (conv3d_bwd_data_bnstats)?  The fp32 Winograd pipeline; DRAM_BWD_BNSTATS=0 under DRAM_TUNING=1 switches it off (A/B)."""
+    return (dtype == torch.float32 and tuning_env("DRAM_BWD_BNSTATS", "1") != "0" and conv_plan(g).algo == 1
+            and g.Cin % 64 == 0)
+
+
+def conv3d_bwd_data_bnstats(dy: Tensor, wb: Tensor, g: ConvGeom, bn_y: Tensor, mean: Tensor, invstd: Tensor,
+                            scale: Tensor, shift: Tensor):
+    """-> (dx, partial): the data gradient (bit-identical to conv3d_bwd_data) and, from its output transform, the rows
+    bn_bwd_reduce(dx, None, bn_y, mean, invstd, True, scale, shift) would produce in a pass of its own -- dx is dz of the
+    BatchNorm + ReLU unit in front of this convolution (reference med3d.py:121-124 backward), bn_y that unit's
+    pre-BatchNorm output."""
+    plan = conv_plan(g)
+    if not conv_bwd_bnstats_ok(g, dy.dtype):
+        raise RuntimeError(f"conv3d_bwd_data_bnstats: not available for {g}")
+    _req(dy, "dy", shape=g.out_shape)
+    _req(wb, "wb", shape=(plan.taps_b, g.Cin, g.Cout))
+    _req(bn_y, "bn_y", shape=g.in_shape)
+    for name, t in (("mean", mean), ("invstd", invstd), ("scale", scale), ("shift", shift)):
+        _req(t, name, shape=(g.Cin,))
+    rows = int(_L().dram_wino_num_stat_rows_bwd(plan.dref))
+    if rows <= 0:
+        raise RuntimeError(f"conv3d_bwd_data_bnstats: no statistic rows for {g}")
+    dx = torch.empty(g.in_shape, device=dy.device, dtype=torch.float32)
+    partial = torch.empty((rows, 2, g.Cin), device=dy.device, dtype=torch.float32)
+    nbytes = plan.ws_bwd
+    ws = _workspace(nbytes, dy.device)
+    with _span("conv_wino_kernels", g.flops, f"dgrad+bnstats {g}"):
+        _chk(_L().dram_wino_conv3d_bwd_data_bn(_p(dy), _p(wb), _p(dx), _p(bn_y), _p(mean), _p(invstd), _p(scale),
+                                               _p(shift), _p(partial), plan.dref, _p(ws), nbytes, _stream()),
+             f"dram_wino_conv3d_bwd_data_bn{g}")
+    return dx, partial
+
+
 def conv3d_bwd_weight(x: Tensor, dy: Tensor, g: ConvGeom, out: Optional[Tensor] = None,
                       v_cache: Optional[Tensor] = None) -> Tensor:
     plan = conv_plan(g)

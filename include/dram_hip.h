@@ -35,7 +35,7 @@ typedef void* dram_stream_t; /* hipStream_t */
 #define DRAM_ERR_UNSUPPORTED (-2)
 #define DRAM_ERR_WORKSPACE (-3)
 
-#define DRAM_ABI_VERSION 6
+#define DRAM_ABI_VERSION 7
 int dram_version(void);
 /* static string: "gfx950" build tag */
 const char* dram_build_info(void);
@@ -212,6 +212,18 @@ int dram_wino_conv3d_fwd_bn(const float* x_pre, const float* pscale, const float
 int dram_wino_conv3d_bwd_data(const float* dy, const float* ub, float* dx, const float* add,
                               const float* gate, const DramConvDesc* desc, void* workspace,
                               size_t workspace_bytes, dram_stream_t stream);
+/* The data gradient that also takes the BatchNorm-backward statistics of the unit IN FRONT of this convolution
+ * (med3d.py:121-124 / :153-161 backward: conv <- relu <- bn): dx is that unit's dz, and with its pre-BatchNorm output
+ * bn_y [B,D,H,W,Cin], its batch mean / invstd and the fused scale / shift of its forward pass the output transform
+ * writes, per tile block, the rows (sum g, sum g * xhat) with g = dx * (bn_y*scale + shift > 0),
+ * xhat = (bn_y - mean) * invstd -- what dram_bn_bwd_reduce (relu = 1, z = NULL) produces in a pass of its own over dx
+ * and bn_y.  stats_partial: [dram_wino_num_stat_rows_bwd(desc)][2][Cin] floats, to be folded with
+ * dram_fold_partials.  dx is bit-identical to dram_wino_conv3d_bwd_data(add = gate = NULL). */
+int dram_wino_num_stat_rows_bwd(const DramConvDesc* desc);
+int dram_wino_conv3d_bwd_data_bn(const float* dy, const float* ub, float* dx, const float* bn_y, const float* bn_mean,
+                                 const float* bn_invstd, const float* bn_scale, const float* bn_shift,
+                                 float* stats_partial, const DramConvDesc* desc, void* workspace, size_t workspace_bytes,
+                                 dram_stream_t stream);
 int dram_wino_conv3d_bwd_weight(const float* x, const float* v_cache, const float* dy, float* dw,
                                 const DramConvDesc* desc, void* workspace, size_t workspace_bytes,
                                 dram_stream_t stream);

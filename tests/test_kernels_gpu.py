@@ -302,6 +302,50 @@ def test_conv_of_two_channel_blocks_equals_conv_of_their_concatenation(ops, monk
     assert not ops.conv_cat_ok(g, Cu)
 
 
+BNSTAT_CASES = [
+    # B, D, H, W, Cin (= channels of the unit in front), Cout, dil, tiling
+    (2, 8, 16, 16, 64, 64, 1, "4,4,4"),
+    (1, 6, 10, 14, 128, 64, 1, "4,4,4"),       # ragged tiles: out-of-volume outputs must not reach the sums
+    (1, 8, 8, 16, 64, 128, 2, "4,4,4"),        # dilation lattice (layer3 / layer4)
+    (1, 6, 12, 12, 64, 64, 1, "2,4,4"),        # an unrolled tiling
+]
+
+
+@pytest.mark.parametrize("case", BNSTAT_CASES, ids=[str(c) for c in BNSTAT_CASES])
+def test_data_gradient_takes_the_batchnorm_backward_statistics_of_the_unit_in_front(ops, monkeypatch, case):
+    """Backward of conv <- relu <- bn (reference med3d.py:121-124, :153-161): the data gradient's output transform also
+    writes the rows (sum g, sum g * xhat), g = dx * (y*scale + shift > 0), of the unit whose output the convolution read
+    (ops.conv3d_bwd_data_bnstats).  dx is bit-identical to the plain data gradient; the folded sums equal the folded sums
+    of the separate pass (ops.bn_bwd_reduce) to fp32 summation-order accuracy."""
+    B, D, H, W, Cin, Cout, dil, tiling = case
+    monkeypatch.setenv("DRAM_CONV_ALGO", "2")
+    monkeypatch.setenv("DRAM_WINO_TILING", tiling)
+    g = ops.ConvGeom(B, D, H, W, Cin, Cout, 3, 1, dil, dil)
+    assert ops.conv_bwd_bnstats_ok(g)
+    w = (rnd(Cout, Cin, 3, 3, 3, seed=1) * 0.1).to(DEV)
+    _, wb = ops.pack_conv_weight(w, False, True, g)
+    dy = to_ndhwc(rnd(B, Cout, D, H, W, seed=2))
+    y = to_ndhwc(rnd(B, Cin, D, H, W, seed=3))
+    mean = (rnd(Cin, seed=4) * 0.1).to(DEV)
+    invstd = (rnd(Cin, seed=5).abs() + 0.5).to(DEV)
+    scale = rnd(Cin, seed=6).to(DEV)                   # both signs: the mask is (y*scale + shift > 0)
+    shift = (rnd(Cin, seed=7) * 0.3).to(DEV)
+    dx0 = ops.conv3d_bwd_data(dy, wb, g)
+    dx1, part1 = ops.conv3d_bwd_data_bnstats(dy, wb, g, y, mean, invstd, scale, shift)
+    assert torch.equal(dx0, dx1)
+    part0 = ops.bn_bwd_reduce(dx0, None, y, mean, invstd, True, scale, shift)
+    s0 = ops.reduce_partials(part0).reshape(2, Cin)
+    s1 = ops.reduce_partials(part1).reshape(2, Cin)
+    # reference in double from the same dx
+    gm = torch.where(torch.addcmul(shift, y, scale) > 0, dx0, torch.zeros_like(dx0)).double()
+    ref = torch.stack([gm.sum((0, 1, 2, 3)), (gm * ((y.double() - mean.double()) * invstd.double())).sum((0, 1, 2, 3))])
+    denom = ref.abs().max()
+    assert ((s1 - ref).abs().max() / denom).item() < 1e-5, ((s1 - ref).abs().max() / denom).item()
+    assert ((s0 - ref).abs().max() / denom).item() < 1e-5
+    monkeypatch.setenv("DRAM_BWD_BNSTATS", "0")
+    assert not ops.conv_bwd_bnstats_ok(g)
+
+
 PERSIST_CASES = [
     # kind, B, D, H, W, Cin, Cout, dil: Winograd-domain GEMMs whose workgroups walk SEVERAL tiles (> 256 tiles: 216
     # points x 2 M tiles x column tiles) and 1x1x1 convolutions (one point, fused epilogues), 64- and 128-column tiles
