@@ -463,11 +463,11 @@ class Engine:
         While the step is being captured into a hipGraph: when the capture asks for it (`graph_streams` = 2, set by
         graph.GraphedTrainStep(streams=2); DRAM_GRAPH_STREAMS=2 under DRAM_TUNING=1 forces it) -- the side stream forks from
         the capturing stream by wait_stream / event and rejoins it before the step ends, so the graph has two branches.
-        Measured: in round 4 it bought little once the launch gaps were gone (config 1 42.91 / 42.92 ms, config 3 fp32
-        41.45 / 41.83, config 2 bf16 17.47 / 18.07 one / two branches); in round 5, with layer1's weight gradients on the
-        HBM-bound pipeline, config 1 replays at 37.20 / 37.00 ms against 36.8-37.1 for the eager two-stream step -- and the
-        replay does not depend on the host (a cold host issues the eager step in 23.7 instead of 6.9 ms and leaves gaps:
-        42.3 ms), for 14 GB more (the graph's private pool)."""
+        Measured: it buys nothing -- config 1 37.11 / 37.24 / 37.38 ms with one branch, 37.16 / 37.23 /
+        37.07 with two (alternating runs on one box; 3.7 GB more), config 0 8.58 vs 8.81-8.85, config 2 in fp32 37.61 vs 37.93;
+        the packing alone as a branch: config 0 8.52 vs 8.9, ResNet-50 bf16 15.41 vs 15.74.  Captured steps default to ONE
+        branch; what the capture is for is a step time that does not depend on the host (a cold host issues the eager step
+        in 23.7 instead of 6.9 ms and leaves gaps: 42.3 instead of 37.0 ms)."""
         if ops.tuning_env("DRAM_WGRAD_STREAM", "1") == "0":
             return False
         if not torch.cuda.is_current_stream_capturing():
