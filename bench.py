@@ -319,7 +319,8 @@ def main():
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="capture the train step (fwd + loss + bwd + Adam) in one hipGraph and time its replays "
                          "(bit-identical to eager steps; the number then does not depend on how fast the host issues "
-                         "launches): the default on one GPU and for bf16 data-parallel runs; fp32 data-parallel runs, a gloo rehearsal and "
+                         "launches): the default for bf16 storage and config 0 on one GPU and for bf16 data-parallel runs; fp32 "
+                         "storage on one GPU picks it when a probe finds the host slow (config.graph_choice); fp32 data-parallel runs, a gloo rehearsal and "
                          "--detail / --predict default to eager steps")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="time eager steps on one GPU too")
     ap.add_argument("--graph-streams", type=int, choices=(1, 2), default=1,
@@ -366,19 +367,24 @@ def main():
     import torch.distributed as dist
     use_dist = world > 1 or args.force_dist
     if args.graph is None:
-        # default on ONE GPU: the step replayed as a hipGraph.  bf16 storage and the small config 0: one branch (gap-bound
-        # steps: config 2 104 -> 110 volumes/s, config 0 67-93 -> 99 in round 3).  fp32 configs 1 / 3 / 5: TWO branches (the
-        # eager step's second stream kept inside the capture, GraphedTrainStep(streams=2)): 37.0 ms against 36.8-37.1 for the
-        # eager two-stream step, and independent of the host -- a cold host (first process on a fresh box) issued the eager
-        # step in 23.7 instead of 6.9 ms and left gaps: 42.3 ms for a step whose hipEvent median said 37.0 (round 5).
+        # default on ONE GPU.  bf16 storage and the small config 0: the step replayed as a hipGraph (gap-bound steps: config
+        # 2 104 -> 110 volumes/s, config 0 67-93 -> 99 in round 3).  fp32 configs 1 / 3 / 5: "auto" -- the eager two-stream
+        # step is 0.2-0.6 ms faster than the replay of its capture (weight gradients overlap the data-gradient chain; a
+        # second graph branch does not reproduce that: DESIGN.md section 6) AS LONG AS the host keeps ahead of the GPU; a cold
+        # host (first process on a fresh box, seen once in round 5) issued the eager step in 23.7 instead of 7-10 ms and left
+        # gaps: 42.3 ms for a step whose hipEvent median said 37.0.  So a probe of a few untimed eager steps measures the
+        # host's issue time against the step time and picks the replay when the host needs more than 0.4 of the step
+        # (`config.graph_choice` in the line says what was measured and picked; --graph / --no-graph override).
         # Data parallel: bf16 storage replays a graph WITH its collectives (RCCL through its C API is plain stream work,
         # distributed.DistContext.capturable); fp32 data-parallel steps and a gloo rehearsal run eager.
         if args.predict or args.detail or (use_dist and args.backend != "nccl"):
             args.graph = False
         elif use_dist:
             args.graph = args.dtype == "bf16" or args.config == 0
-        else:
+        elif args.dtype == "bf16" or args.config == 0:
             args.graph = True
+        else:
+            args.graph = "auto"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -403,9 +409,25 @@ def main():
     if use_dist:
         from bodyct_dram_emph_subtype_amd import distributed as ddist
         dctx = ddist.attach(module, force=args.force_dist)
-    opt = FusedAdam(module.parameters(), lr=args.lr, capturable=args.graph)
+    opt = FusedAdam(module.parameters(), lr=args.lr, capturable=bool(args.graph))
     batch = synth_batch(B, dims, rank, device)
     step = make_step(factory, module, opt, batch)
+    graph_choice = None
+    if args.graph == "auto":
+        for _ in range(3):                   # plans, workspaces, optimizer state, allocator pool
+            step()
+        torch.cuda.synchronize()
+        nprobe = 4
+        w0 = module._engine.throttle_wait_s
+        t0 = time.perf_counter()
+        for _ in range(nprobe):
+            step()
+        issue_s = time.perf_counter() - t0 - (module._engine.throttle_wait_s - w0)
+        torch.cuda.synchronize()
+        total_s = time.perf_counter() - t0
+        args.graph = issue_s > 0.4 * total_s
+        graph_choice = (f"auto: the host issued {nprobe} untimed eager steps in {issue_s / nprobe * 1e3:.1f} ms/step of "
+                        f"{total_s / nprobe * 1e3:.1f} ms/step -> " + ("hipGraph replay" if args.graph else "eager two-stream step"))
     if args.predict:
         from bodyct_dram_emph_subtype_amd import models as dmodels, processor
         if not factory.endswith("reg"):
@@ -580,7 +602,7 @@ def main():
                                    f"batch {B}/GPU, 1x{dims[0]}x{dims[1]}x{dims[2]}, "
                                    f"{'fp32' if args.dtype == 'f32' else 'bf16 storage / fp32 accumulation, statistics and parameters'}, "
                                    f"inputs resident in HBM",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(args.graph),
+                       "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(args.graph), "graph_choice": graph_choice,
                        "streams": (args.graph_streams if args.graph else
                                    (1 if (args.detail or ops.tuning_env("DRAM_WGRAD_STREAM", "1") == "0") else 2)),
                        "train_gflop_per_volume": gflop_per_vol},

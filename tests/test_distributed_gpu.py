@@ -357,6 +357,29 @@ def test_bench_line_is_alone_on_stdout_with_rccl_up():
     assert rec["stat_exchange_ms_bracketed"] >= 0
 
 
+def test_default_bench_line_says_how_the_step_was_timed():
+    """The line the driver records (`python bench.py`, config 1, fp32): a probe of untimed eager steps decides between the
+    eager two-stream step and the replay of its hipGraph capture (a host that cannot keep ahead of the GPU) -- the line
+    must say which and on what measurement, and --graph / --no-graph must override the probe."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--timeline", "off"]
+    r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=420, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    cfg = rec["config"]
+    assert rec["dtype"] == "f32" and rec["n_gpus"] == 1 and rec["value"] > 0
+    assert cfg["graph_choice"].startswith("auto: the host issued 4 untimed eager steps")
+    assert cfg["graph_choice"].endswith("hipGraph replay" if cfg["hip_graph"] else "eager two-stream step")
+    r = subprocess.run(base + ["--graph"], env=env, capture_output=True, text=True, timeout=420, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-3000:]
+    cfg = json.loads(r.stdout.splitlines()[0])["config"]
+    assert cfg["hip_graph"] is True and cfg["graph_choice"] is None and cfg["streams"] == 1
+
+
 def test_two_rank_bf16_storage_matches_ddp_syncbn_emulation():
     """The data-parallel path on bf16 activations (BASELINE configs[3] / [4] ask for bf16 + DDP): two ranks (1 + 2 volumes,
     gloo on device tensors) against the fp64 DDP + SyncBN emulation on the ranks' own decisions.  SyncBN statistics and
