@@ -1358,8 +1358,12 @@ __global__ __launch_bounds__(512) void wino_gemm_nn_pers_kernel(const float* __r
 #ifndef DRAM_STREAM_NT
 #define DRAM_STREAM_NT 2
 #endif
-template <int NJ, int KT, int S>
-__global__ __launch_bounds__(256, 1) void wino_gemm_nn_stream_kernel(const float* __restrict__ A,
+// DB ("direct B", round 5): the point's B fragments are loaded from global memory straight into the registers that hold
+// them (16 KB per point, L2-resident, once per 100-200 items) instead of through a 16-KB LDS image, and the ring is three
+// stages deep: 68 KB of LDS, so TWO workgroups share a CU -- one's MFMAs and LDS turn run under the other's waits and
+// stores (one workgroup per CU = one wave per SIMD leaves every wait of a wave exposed).  64 -> 64 launches only.
+template <int NJ, int KT, int S, bool DB = false>
+__global__ __launch_bounds__(256, DB ? 2 : 1) void wino_gemm_nn_stream_kernel(const float* __restrict__ A,
                                                                     const float* __restrict__ Bw, float* __restrict__ Y,
                                                                     const int npts, const int m64, const int per_wg,
                                                                     const int total) {
@@ -1374,7 +1378,7 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_nn_stream_kernel(const float
   static_assert(S == 3 || S == 4, "ring depth");
   // separate LDS objects per stage (the wait-count pass tells DMA targets apart by object)
   __shared__ __attribute__((aligned(1024))) float st0[STG], st1[STG], st2[STG], st3[S == 4 ? STG : 64];
-  __shared__ __attribute__((aligned(1024))) float bt[N * KT];
+  __shared__ __attribute__((aligned(1024))) float bt[DB ? 64 : N * KT];
   __shared__ __attribute__((aligned(16))) float turn[4 * 32 * P];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1416,6 +1420,17 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_nn_stream_kernel(const float
   const int arow = r0 + li;
   f32x4 bfr[NJ][KG];
   auto load_b = [&](int xi) __attribute__((always_inline)) {
+    if (DB) {
+      const float* srcd = Bw + (long)xi * N * KT;
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg)
+          bfr[nj][kg] = *reinterpret_cast<const f32x4*>(srcd + (c0 + nj * 32 + li) * KT + (2 * kg + lh) * 4);
+      __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the counted waits below start from an empty queue
+      asm volatile("" ::: "memory");
+      return;
+    }
     __syncthreads();                               // (no wave still reads the previous point's image)
     const float* src = Bw + (long)xi * N * KT;
 #pragma unroll
@@ -2186,7 +2201,17 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
 #define WNS(NJ_, KT_, S_)                                                                                          \
   hipLaunchKernelGGL((wino_gemm_nn_stream_kernel<NJ_, KT_, S_>), dim3(grid), dim3(256), 0, s, A, U, Y, g.npts, m64, \
                      per_wg, (int)total)
+      const char* sde = tune_env("DRAM_NN_STREAM_DB");                  // A/B switch (read per call: the tests flip it)
+      const int sdb = sde ? atoi(sde) : 1;
       if (N == 64 && K == 128) WNS(1, 128, 3);
+      else if (N == 64 && sdb) {
+        // two workgroups per CU (the direct-B form, 68 KB of LDS each)
+        const int wgs2 = stream_on == 2 ? 8 : 512;
+        const int per2 = (int)((total + wgs2 - 1) / wgs2);
+        const int grid2 = (int)((total + per2 - 1) / per2);
+        hipLaunchKernelGGL((wino_gemm_nn_stream_kernel<1, 64, 3, true>), dim3(grid2), dim3(256), 0, s, A, U, Y, g.npts, m64,
+                           per2, (int)total);
+      }
       else if (N == 64) WNS(1, 64, 4);
       else WNS(2, 64, 4);
 #undef WNS

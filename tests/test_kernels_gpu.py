@@ -270,6 +270,12 @@ def test_winograd_streaming_gemm_equals_tiled_gemm(ops, monkeypatch, case):
             monkeypatch.setenv("DRAM_NN_STREAM", mode)
             res[mode] = (ops.conv3d_fwd(x, wf, None, g, False)[0], ops.conv3d_bwd_data(gy, wb, g))
         assert torch.equal(res["0"][0], res["2"][0]) and torch.equal(res["0"][1], res["2"][1])
+        # (64, 64) has two forms: B fragments loaded directly into registers, two workgroups per CU (the default), and
+        # the LDS-image form with a four-stage ring
+        monkeypatch.setenv("DRAM_NN_STREAM_DB", "0")
+        assert torch.equal(ops.conv3d_fwd(x, wf, None, g, False)[0], res["0"][0])
+        assert torch.equal(ops.conv3d_bwd_data(gy, wb, g), res["0"][1])
+        monkeypatch.delenv("DRAM_NN_STREAM_DB")
     ref = F.conv3d(rnd(B, Cin, D, H, W, seed=1).double(), w.cpu().double(), None, 1, dil, dil)
     assert rel_l2(to_ncdhw(res["2"][0]).double(), ref) < 3e-5
 
