@@ -1362,7 +1362,10 @@ __global__ __launch_bounds__(512) void wino_gemm_nn_pers_kernel(const float* __r
 // them (16 KB per point, L2-resident, once per 100-200 items) instead of through a 16-KB LDS image, and the ring is three
 // stages deep: 68 KB of LDS, so TWO workgroups share a CU -- one's MFMAs and LDS turn run under the other's waits and
 // stores (one workgroup per CU = one wave per SIMD leaves every wait of a wave exposed).  64 -> 64 launches only.
-template <int NJ, int KT, int S, bool DB = false>
+// KH = 2 (K = 128, DB only): an item is one 64-wide k-HALF of a 64-row tile -- 16-KB stages like the K = 64 forms, so the
+// ring still fits twice on a CU; the accumulators run over the two halves of a tile in k order (bit-identical to the
+// whole-row form) and the turn + store follow the second half.
+template <int NJ, int KT, int S, bool DB = false, int KH = 1>
 __global__ __launch_bounds__(256, DB ? 2 : 1) void wino_gemm_nn_stream_kernel(const float* __restrict__ A,
                                                                     const float* __restrict__ Bw, float* __restrict__ Y,
                                                                     const int npts, const int m64, const int per_wg,
@@ -1374,8 +1377,10 @@ __global__ __launch_bounds__(256, DB ? 2 : 1) void wino_gemm_nn_stream_kernel(co
   constexpr int IPW = 64 / RPI / 4;                // A DMA instructions per wave and stage
   constexpr int BPW = N / RPI / 4;                 // B DMA instructions per wave
   constexpr int KG = KT / 8;                       // k-groups (one ds_read_b128 per lane each)
-  constexpr int P = 32 * NJ + 8;
+  constexpr int P = DB ? 40 : 32 * NJ + 8;         // DB: the turn takes one 32-column block at a time (20 KB whatever NJ)
+  constexpr int KS = KT * KH;                      // row length of A and B in memory (K)
   static_assert(S == 3 || S == 4, "ring depth");
+  static_assert(KH == 1 || (KH == 2 && DB && S == 3), "k halves: direct-B form, three stages");
   // separate LDS objects per stage (the wait-count pass tells DMA targets apart by object)
   __shared__ __attribute__((aligned(1024))) float st0[STG], st1[STG], st2[STG], st3[S == 4 ? STG : 64];
   __shared__ __attribute__((aligned(1024))) float bt[DB ? 64 : N * KT];
@@ -1393,7 +1398,7 @@ __global__ __launch_bounds__(256, DB ? 2 : 1) void wino_gemm_nn_stream_kernel(co
 #pragma unroll
   for (int j = 0; j < IPW; ++j) {
     const int row = RPI * (wave + 4 * j) + lane / SPR, ph = lane % SPR;
-    aoff[j] = row * KT + ((ph & ~15) | ((ph ^ row) & 15)) * 4;
+    aoff[j] = row * KS + ((ph & ~15) | ((ph ^ row) & 15)) * 4;
   }
 #pragma unroll
   for (int j = 0; j < BPW; ++j) {
@@ -1401,8 +1406,9 @@ __global__ __launch_bounds__(256, DB ? 2 : 1) void wino_gemm_nn_stream_kernel(co
     boff[j] = row * KT + ((ph & ~15) | ((ph ^ row) & 15)) * 4;
   }
   auto a_src = [&](int item) __attribute__((always_inline)) {
-    const int xi = item / m64, t = item - xi * m64;
-    return A + (((long)(t >> 2) * npts + xi) * 256 + (t & 3) * 64) * KT;
+    const int ti = item / KH, h = item - ti * KH;
+    const int xi = ti / m64, t = ti - xi * m64;
+    return A + (((long)(t >> 2) * npts + xi) * 256 + (t & 3) * 64) * KS + h * KT;
   };
   auto issue_a = [&](int item, float* stage) __attribute__((always_inline)) {
     const float* src = a_src(item);
@@ -1418,15 +1424,15 @@ __global__ __launch_bounds__(256, DB ? 2 : 1) void wino_gemm_nn_stream_kernel(co
 
   const int r0 = 32 * (wave & 1), c0 = 32 * NJ * (wave >> 1);
   const int arow = r0 + li;
-  f32x4 bfr[NJ][KG];
+  f32x4 bfr[NJ][KG * KH];
   auto load_b = [&](int xi) __attribute__((always_inline)) {
     if (DB) {
-      const float* srcd = Bw + (long)xi * N * KT;
+      const float* srcd = Bw + (long)xi * N * KS;
 #pragma unroll
       for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
-        for (int kg = 0; kg < KG; ++kg)
-          bfr[nj][kg] = *reinterpret_cast<const f32x4*>(srcd + (c0 + nj * 32 + li) * KT + (2 * kg + lh) * 4);
+        for (int kg = 0; kg < KG * KH; ++kg)
+          bfr[nj][kg] = *reinterpret_cast<const f32x4*>(srcd + (c0 + nj * 32 + li) * KS + (2 * kg + lh) * 4);
       __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the counted waits below start from an empty queue
       asm volatile("" ::: "memory");
       return;
@@ -1451,7 +1457,7 @@ __global__ __launch_bounds__(256, DB ? 2 : 1) void wino_gemm_nn_stream_kernel(co
     }
   };
 
-  int xi_cur = i0 / m64;
+  int xi_cur = i0 / KH / m64;
   // prologue: S - 1 stages ahead (the B load below waits for them too: once per point)
 #pragma unroll
   for (int k = 0; k < S - 1; ++k)
@@ -1462,14 +1468,18 @@ __global__ __launch_bounds__(256, DB ? 2 : 1) void wino_gemm_nn_stream_kernel(co
   constexpr int Q = 8 * NJ;                        // 4-column groups per row of the wave's 32 NJ columns
   const int cq = lane % Q, rs = lane / Q;
 
-  for (int itb = 0; itb < n; itb += S) {
+  constexpr int U = S * KH;                        // unroll: stage k % S and k half k % KH are compile-time
+  f32x16 acc[NJ];
+  for (int itb = 0; itb < n; itb += U) {
 #pragma unroll
-    for (int k = 0; k < S; ++k) {
+    for (int k = 0; k < U; ++k) {
       const int it = itb + k;
+      const int h = k % KH;                        // (i0 and itb are multiples of KH)
       if (it < n) {                                // uniform
         const int item = i0 + it;
-        const int xi = item / m64, t = item - xi * m64;
-        if (xi != xi_cur) {                        // next point: its B operand (rare: a run spans 1-3 points)
+        const int ti = item / KH;
+        const int xi = ti / m64, t = ti - xi * m64;
+        if (h == 0 && xi != xi_cur) {              // next point: its B operand (rare: a run spans 1-3 points)
           xi_cur = xi;
           load_b(xi);                              // (its vmcnt(0) also covers the stages in flight)
         }
@@ -1480,12 +1490,13 @@ __global__ __launch_bounds__(256, DB ? 2 : 1) void wino_gemm_nn_stream_kernel(co
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();              // ... and for every wave; all waves are done with stage it - 1
         if (it + S - 1 < n) issue_a(item + S - 1, stage_of((k + S - 1) % S));
-        const float* stg = stage_of(k);
-        f32x16 acc[NJ];
+        const float* stg = stage_of(k % S);
+        if (h == 0) {
 #pragma unroll
-        for (int nj = 0; nj < NJ; ++nj)
+          for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[nj][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[nj][e] = 0.f;
+        }
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
           const int sl = 2 * kg + lh;
@@ -1494,18 +1505,34 @@ __global__ __launch_bounds__(256, DB ? 2 : 1) void wino_gemm_nn_stream_kernel(co
           for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj)
-              acc[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bfr[nj][kg][e], acc[nj], 0, 0, 0);
+              acc[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bfr[nj][h * KG + kg][e], acc[nj], 0, 0, 0);
         }
+        if (h != KH - 1) continue;                 // (compile-time: the second half of the tile follows)
         // turn through the wave's private LDS region, 16 B per lane
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-#pragma unroll
-          for (int nj = 0; nj < NJ; ++nj) reg[((e & 3) + 8 * (e >> 2) + 4 * lh) * P + nj * 32 + li] = acc[nj][e];
         float* yb = Y + (((long)(t >> 2) * npts + xi) * 256 + (t & 3) * 64 + r0) * N + c0;
+        if (DB) {
+          const int cq8 = lane & 7, rs8 = lane >> 3;
 #pragma unroll
-        for (int r = 0; r < Q / 2; ++r) {
-          const int row = r * (64 / Q) + rs;
-          *reinterpret_cast<f32x4*>(yb + (long)row * N + 4 * cq) = *reinterpret_cast<const f32x4*>(reg + row * P + 4 * cq);
+          for (int nj = 0; nj < NJ; ++nj) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) reg[((e & 3) + 8 * (e >> 2) + 4 * lh) * P + li] = acc[nj][e];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = r * 8 + rs8;
+              *reinterpret_cast<f32x4*>(yb + (long)row * N + nj * 32 + 4 * cq8) =
+                  *reinterpret_cast<const f32x4*>(reg + row * P + 4 * cq8);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) reg[((e & 3) + 8 * (e >> 2) + 4 * lh) * P + nj * 32 + li] = acc[nj][e];
+#pragma unroll
+          for (int r = 0; r < Q / 2; ++r) {
+            const int row = r * (64 / Q) + rs;
+            *reinterpret_cast<f32x4*>(yb + (long)row * N + 4 * cq) = *reinterpret_cast<const f32x4*>(reg + row * P + 4 * cq);
+          }
         }
       }
     }
@@ -2150,7 +2177,8 @@ int launch_wino_in(const float* src, float* dst, const WinoGeom& g, const int C,
 }
 
 int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, int K, hipStream_t s,
-           const GemmEpilogue ep = GemmEpilogue{nullptr, nullptr, nullptr, nullptr}, const int math = 0) {
+           const GemmEpilogue ep = GemmEpilogue{nullptr, nullptr, nullptr, nullptr}, const int math = 0,
+           const bool alone = true) {      // alone: no other stream's kernels are expected beside this launch
   // N tile = 64 * nj columns.  One workgroup per CU (64-128 KB of LDS), so a launch runs in whole rounds of 256
   // workgroups: 864 workgroups of 256 columns (layer4, 216 points) take 4 rounds with the last 3/8 full, 1728 of
   // 128 columns take 7 (measured 0.747 -> 0.706 ms).  Pick the width with the least rounds x width x per-column
@@ -2202,16 +2230,30 @@ int run_nn(const float* A, const float* U, float* Y, const WinoGeom& g, int N, i
   hipLaunchKernelGGL((wino_gemm_nn_stream_kernel<NJ_, KT_, S_>), dim3(grid), dim3(256), 0, s, A, U, Y, g.npts, m64, \
                      per_wg, (int)total)
       const char* sde = tune_env("DRAM_NN_STREAM_DB");                  // A/B switch (read per call: the tests flip it)
-      const int sdb = sde ? atoi(sde) : 1;
-      if (N == 64 && K == 128) WNS(1, 128, 3);
-      else if (N == 64 && sdb) {
-        // two workgroups per CU (the direct-B form, 68 KB of LDS each)
-        const int wgs2 = stream_on == 2 ? 8 : 512;
-        const int per2 = (int)((total + wgs2 - 1) / wgs2);
-        const int grid2 = (int)((total + per2 - 1) / per2);
+      // bit 0: 64 -> 64, bit 1: 64 -> 128, bit 2: 128 -> 64 (k halves); not beside another stream's kernels (two of
+      // these workgroups fill a CU's LDS: config 1's eager two-stream step lost in backward what it won in forward)
+      const int sdb = sde ? atoi(sde) : (alone ? 7 : 0);
+      // two workgroups per CU (the direct-B form, 68 KB of LDS each)
+      const int wgs2 = stream_on == 2 ? 8 : 512;
+      const int per2 = (int)((total + wgs2 - 1) / wgs2);
+      const int grid2 = (int)((total + per2 - 1) / per2);
+      if (N == 64 && K == 128 && (sdb & 4)) {
+        // items are k-halves of tiles: an even number per workgroup, so that every run starts on a first half
+        const long total2 = 2 * total;
+        if (total2 < (1L << 31)) {
+          const int perk = 2 * (int)((total + wgs2 - 1) / wgs2);
+          const int gridk = (int)((total2 + perk - 1) / perk);
+          hipLaunchKernelGGL((wino_gemm_nn_stream_kernel<1, 64, 3, true, 2>), dim3(gridk), dim3(256), 0, s, A, U, Y, g.npts,
+                             m64, perk, (int)total2);
+        } else WNS(1, 128, 3);
+      }
+      else if (N == 64 && K == 128) WNS(1, 128, 3);
+      else if (N == 64 && sdb)
         hipLaunchKernelGGL((wino_gemm_nn_stream_kernel<1, 64, 3, true>), dim3(grid2), dim3(256), 0, s, A, U, Y, g.npts, m64,
                            per2, (int)total);
-      }
+      else if (N == 128 && (sdb & 2))
+        hipLaunchKernelGGL((wino_gemm_nn_stream_kernel<2, 64, 3, true>), dim3(grid2), dim3(256), 0, s, A, U, Y, g.npts, m64,
+                           per2, (int)total);
       else if (N == 64) WNS(1, 64, 4);
       else WNS(2, 64, 4);
 #undef WNS
@@ -2271,7 +2313,8 @@ int run_conv(const float* in, const float* U, const float* bias, const float* ad
     const int rc0 = launch_wino_in<0>(in, V, g, K, math, s, pscale, pshift);
     if (rc0 != DRAM_OK) return rc0;
   }
-  const int rc = run_nn(V, U, Mh, g, N, K, s, GemmEpilogue{nullptr, nullptr, nullptr, nullptr}, math);
+  const int rc = run_nn(V, U, Mh, g, N, K, s, GemmEpilogue{nullptr, nullptr, nullptr, nullptr}, math,
+                        !(pass == 1 && (d->flags & DRAM_CONV_BWD_OVERLAPPED)));
   if (rc != DRAM_OK) return rc;
   const int ntb = (g.T + wino_tpb(g.T) - 1) / wino_tpb(g.T);
   const double out_elems = (double)g.B * g.D * g.H * g.W * N;

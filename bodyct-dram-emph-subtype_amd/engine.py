@@ -216,9 +216,10 @@ class Engine:
         if (nxt is not None and add is None and gate is None and nxt.get("ss") is not None
                 and ops.conv_bwd_bnstats_ok(c["g"], dy.dtype)):
             dx, nxt["part"] = ops.conv3d_bwd_data_bnstats(dy, c["wb"], c["g"], nxt["y"], nxt["mean"], nxt["invstd"],
-                                                          *nxt["ss"])
+                                                          *nxt["ss"], overlapped=st.side is not None)
             return dx
-        return ops.conv3d_bwd_data(dy, c["wb"], c["g"], add, gate)
+        # (overlapped: this data gradient shares the device with the weight-gradient kernels of the second stream)
+        return ops.conv3d_bwd_data(dy, c["wb"], c["g"], add, gate, overlapped=st.side is not None)
 
     @staticmethod
     def _recipe_inputs(c: dict):

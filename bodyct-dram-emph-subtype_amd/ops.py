@@ -391,13 +391,18 @@ class ConvPlan:
     (geometry, plan-relevant environment): forward / weight-gradient algorithm, packed-weight leading
     dimensions, statistic rows, workspace sizes, cached-transform size -- ~12 host calls into the library
     (each of which re-derives tilings and reads the environment) instead of that many per launch."""
-    __slots__ = ("desc", "dref", "algo", "walgo", "taps_f", "taps_b", "stat_rows", "ws_fwd", "ws_bwd", "ws_wgrad",
+    __slots__ = ("desc", "dref", "desc_ovl", "dref_ovl", "algo", "walgo", "taps_f", "taps_b", "stat_rows", "ws_fwd", "ws_bwd", "ws_wgrad",
                  "v_elems", "ws_direct_wgrad", "bf16", "bf16_stat_rows", "bf16_ws_wgrad", "prologue")
 
     def __init__(self, g: "ConvGeom"):
         L = _L()
         self.desc = g.desc()
         self.dref = d = ctypes.byref(self.desc)
+        # the same geometry with DRAM_CONV_BWD_OVERLAPPED (include/dram_hip.h): a data gradient launched while another
+        # stream runs weight-gradient kernels (conv3d_bwd_data(..., overlapped=True))
+        self.desc_ovl = g.desc()
+        self.desc_ovl.flags |= 2
+        self.dref_ovl = ctypes.byref(self.desc_ovl)
         self.algo = int(L.dram_conv_algo(d))
         self.walgo = int(L.dram_conv_wgrad_algo(d))
         if self.algo == 1:
@@ -673,7 +678,9 @@ def conv3d_fwd_keep(x: Tensor, wf: Tensor, bias: Optional[Tensor], g: ConvGeom, 
 
 
 def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] = None,
-                    gate: Optional[Tensor] = None) -> Tensor:
+                    gate: Optional[Tensor] = None, overlapped: bool = False) -> Tensor:
+    """overlapped: weight-gradient kernels run on another stream meanwhile (DRAM_CONV_BWD_OVERLAPPED: a hint for the
+    Winograd pipeline's choice of GEMM form; results do not depend on it)."""
     plan = conv_plan(g)
     if _act(dy, "dy", g.out_shape):                    # bf16 storage
         if add is not None:
@@ -707,7 +714,8 @@ def conv3d_bwd_data(dy: Tensor, wb: Tensor, g: ConvGeom, add: Optional[Tensor] =
         nbytes = plan.ws_bwd
         ws = _workspace(nbytes, dy.device)
         with _span("conv_wino_kernels", g.flops, f"dgrad {g}"):
-            _chk(_L().dram_wino_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate), d, _p(ws),
+            _chk(_L().dram_wino_conv3d_bwd_data(_p(dy), _p(wb), _p(dx), _p(add), _p(gate),
+                                                plan.dref_ovl if overlapped else d, _p(ws),
                                                 nbytes, _stream()), f"dram_wino_conv3d_bwd_data{g}")
         return dx
     if algo == 3:
@@ -734,7 +742,7 @@ def conv_bwd_bnstats_ok(g: ConvGeom, dtype=torch.float32) -> bool:
 
 
 def conv3d_bwd_data_bnstats(dy: Tensor, wb: Tensor, g: ConvGeom, bn_y: Tensor, mean: Tensor, invstd: Tensor,
-                            scale: Tensor, shift: Tensor):
+                            scale: Tensor, shift: Tensor, overlapped: bool = False):
     """-> (dx, partial): the data gradient (bit-identical to conv3d_bwd_data) and, from its output transform, the rows
     bn_bwd_reduce(dx, None, bn_y, mean, invstd, True, scale, shift) would produce in a pass of its own -- dx is dz of the
     BatchNorm + ReLU unit in front of this convolution (reference med3d.py:121-124 backward), bn_y that unit's
@@ -756,7 +764,8 @@ def conv3d_bwd_data_bnstats(dy: Tensor, wb: Tensor, g: ConvGeom, bn_y: Tensor, m
     ws = _workspace(nbytes, dy.device)
     with _span("conv_wino_kernels", g.flops, f"dgrad+bnstats {g}"):
         _chk(_L().dram_wino_conv3d_bwd_data_bn(_p(dy), _p(wb), _p(dx), _p(bn_y), _p(mean), _p(invstd), _p(scale),
-                                               _p(shift), _p(partial), plan.dref, _p(ws), nbytes, _stream()),
+                                               _p(shift), _p(partial), plan.dref_ovl if overlapped else plan.dref,
+                                               _p(ws), nbytes, _stream()),
              f"dram_wino_conv3d_bwd_data_bn{g}")
     return dx, partial
 

@@ -117,6 +117,12 @@ typedef struct DramConvDesc {
  * the 3-D pipeline is estimated > 15 % faster -- ResNet-50's 54 BatchNorm layers amplify an early error ~100 x.
  * Results under either plan are within the 1e-3 bar; only the plan differs. */
 #define DRAM_CONV_ROUNDING_TOLERANT 1
+/* Per-call hint for a DATA GRADIENT (dram_wino_conv3d_bwd_data[_bn]): the caller runs weight-gradient kernels on another
+ * stream at the same time.  The HBM-bound Winograd-domain GEMMs then keep the form with ONE workgroup per CU (100 KB of
+ * LDS, room for the other stream's workgroups beside it) instead of the two-workgroups-per-CU form, which is 8-15 %
+ * faster on a device of its own and takes the overlap away when it is not (measured).  Results are
+ * bit-identical either way. */
+#define DRAM_CONV_BWD_OVERLAPPED 2
 
 /* Repack [Cout][Cin][k^3] -> wf[tap][Cout][Cin] (forward B-operand, K=Cin contiguous)
  * and wb[tap][Cin][Cout] (data-gradient B-operand).  Either output may be NULL. */

@@ -276,6 +276,8 @@ def test_winograd_streaming_gemm_equals_tiled_gemm(ops, monkeypatch, case):
         assert torch.equal(ops.conv3d_fwd(x, wf, None, g, False)[0], res["0"][0])
         assert torch.equal(ops.conv3d_bwd_data(gy, wb, g), res["0"][1])
         monkeypatch.delenv("DRAM_NN_STREAM_DB")
+        # ... and a data gradient that says it shares the device with another stream takes the one-workgroup form
+        assert torch.equal(ops.conv3d_bwd_data(gy, wb, g, overlapped=True), res["0"][1])
     ref = F.conv3d(rnd(B, Cin, D, H, W, seed=1).double(), w.cpu().double(), None, 1, dil, dil)
     assert rel_l2(to_ncdhw(res["2"][0]).double(), ref) < 3e-5
 
