@@ -53,6 +53,8 @@ struct IGemmGeom {
   int tiles_per_b;        // lat^3*nz*ny*nx
   int n_tiles;            // N tiles
   int nblk;
+  int ncls;               // MODE 2: classes listed in cls_nib (0: classes in index order)
+  unsigned cls_nib;       // MODE 2, lat = 2: lattice classes (rz*lat + ry)*lat + rx, most taps first, 4 bits each
 };
 
 // MODE 0: forward (any stride/dilation) and MODE 1: data-gradient with stride 1 share
@@ -81,17 +83,40 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
   const int wave = tid >> 6;
 
   // ---- decode the tile --------------------------------------------------------
-  int L = xcd_remap(blockIdx.x, g.nblk);
-  const int n_tile = L % g.n_tiles;
-  int mt = L / g.n_tiles;
-  const int b = mt / g.tiles_per_b;
-  int r = mt - b * g.tiles_per_b;
-  const int txi = r % g.nx; r /= g.nx;
-  const int tyi = r % g.ny; r /= g.ny;
-  const int tzi = r % g.nz; r /= g.nz;
-  const int rx = r % g.lat; r /= g.lat;
-  const int ry = r % g.lat;
-  const int rz = r / g.lat;
+  int n_tile, mt, b, txi, tyi, tzi, rx, ry, rz;
+  if (MODE != 2) {
+    int L = xcd_remap(blockIdx.x, g.nblk);
+    n_tile = L % g.n_tiles;
+    mt = L / g.n_tiles;
+    b = mt / g.tiles_per_b;
+    int r = mt - b * g.tiles_per_b;
+    txi = r % g.nx; r /= g.nx;
+    tyi = r % g.ny; r /= g.ny;
+    tzi = r % g.nz; r /= g.nz;
+    rx = r % g.lat; r /= g.lat;
+    ry = r % g.lat;
+    rz = r / g.lat;
+  } else {
+    // A lattice class owns between 1 and (taps per axis)^3 of the taps (stride 2, k = 3: 1, 2, 4 or 8 of the 27), so its
+    // workgroups differ 8 x in length.  With the class as a slow index of the XCD-remapped tile number one XCD got
+    // the two lightest classes and another the two heaviest (12 tap units against 3 on one launch of 1 024
+    // workgroups).  Here the class is the SLOWEST index of the dispatch order, heaviest class first: the round-robin
+    // dispatch spreads every class over the eight XCDs and the short workgroups fill in behind the long ones.
+    const int ncl = g.lat * g.lat * g.lat;
+    const int per = g.nblk / ncl;
+    const int rank = blockIdx.x / per;
+    int w = xcd_remap(blockIdx.x - rank * per, per);
+    const int c = g.ncls ? (int)((g.cls_nib >> (4 * rank)) & 15u) : rank;
+    rx = c % g.lat;
+    ry = (c / g.lat) % g.lat;
+    rz = c / (g.lat * g.lat);
+    n_tile = w % g.n_tiles; w /= g.n_tiles;
+    txi = w % g.nx; w /= g.nx;
+    tyi = w % g.ny; w /= g.ny;
+    tzi = w % g.nz;
+    b = w / g.nz;
+    mt = b * g.tiles_per_b + ((c * g.nz + tzi) * g.ny + tyi) * g.nx + txi;
+  }
   const int n0 = n_tile * BN;
 
   // ---- per-thread gather rows ---------------------------------------------------
@@ -120,10 +145,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
       }
       rmask[p] = rv ? m : 0;
     } else {
-      rbase[p] = rv ? 1 : 0;
-      rmask[p] = zo + g.pad;
-      rcy[p] = yo + g.pad;
-      rcx[p] = xo + g.pad;
+      // (o + pad) = stride*q + r with the remainder r common to the whole lattice tile: the rows keep q and the element
+      // offset of (b, q), a listed tap adds the tile-uniform u = (r - t*dil)/stride (exact by the divisibility test) --
+      // no per-element division, 32-bit offsets (desc_ok: < 2^31 elements; unsigned, since q may lie one step outside)
+      const int qz = (zo + g.pad) / g.stride, qy = (yo + g.pad) / g.stride, qx = (xo + g.pad) / g.stride;
+      rbase[p] = (int)(((((unsigned)b * g.Di + qz) * g.Hi + qy) * g.Wi + qx) * g.Ci);
+      rmask[p] = rv ? qz : (1 << 28);   // a row outside the tensor fails every range test
+      rcy[p] = qy;
+      rcx[p] = qx;
     }
   }
 
@@ -166,13 +195,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
   ra##P = ((rmask[P] & vb) == vb) ? *reinterpret_cast<const float4*>(in + (long)(rbase[P] + toff)) : zero4;
 #define IG_LOAD_A2(P)                                                                               \
   {                                                                                                 \
-    const int nz_ = rmask[P] - tz * g.dil, ny_ = rcy[P] - ty * g.dil, nx_ = rcx[P] - tx * g.dil;    \
-    const int sz = nz_ / g.stride, sy = ny_ / g.stride, sx = nx_ / g.stride;                        \
-    const bool v = (rbase[P] != 0) & (nz_ >= 0) & (ny_ >= 0) & (nx_ >= 0) & (sz * g.stride == nz_) & \
-                   (sy * g.stride == ny_) & (sx * g.stride == nx_) & (sz < g.Di) & (sy < g.Hi) &     \
-                   (sx < g.Wi);                                                                      \
-    const long o = ((((long)b * g.Di + sz) * g.Hi + sy) * g.Wi + sx) * g.Ci + koff;                  \
-    const float4 t_ = *reinterpret_cast<const float4*>(in + (v ? o : (long)koff));                   \
+    const int sz = rmask[P] + uz, sy = rcy[P] + uy, sx = rcx[P] + ux;                               \
+    const bool v = ((unsigned)sz < (unsigned)g.Di) & ((unsigned)sy < (unsigned)g.Hi) &              \
+                   ((unsigned)sx < (unsigned)g.Wi);                                                  \
+    const int o = (int)((unsigned)rbase[P] + (unsigned)toff);                                       \
+    const float4 t_ = *reinterpret_cast<const float4*>(in + (v ? o : koff));                        \
     ra##P = mask4(t_, v);                                                                            \
   }
 
@@ -190,6 +217,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(
       IG_LOAD_A01(0) IG_LOAD_A01(1) IG_LOAD_A01(2) IG_LOAD_A01(3)
       IG_LOAD_A01(4) IG_LOAD_A01(5) IG_LOAD_A01(6) IG_LOAD_A01(7)
     } else {
+      const int uz = ((rz + g.pad) % g.stride - tz * g.dil) / g.stride;
+      const int uy = ((ry + g.pad) % g.stride - ty * g.dil) / g.stride;
+      const int ux = ((rx + g.pad) % g.stride - tx * g.dil) / g.stride;
+      const int toff = ((uz * g.Hi + uy) * g.Wi + ux) * g.Ci + koff;
       IG_LOAD_A2(0) IG_LOAD_A2(1) IG_LOAD_A2(2) IG_LOAD_A2(3)
       IG_LOAD_A2(4) IG_LOAD_A2(5) IG_LOAD_A2(6) IG_LOAD_A2(7)
     }
@@ -976,6 +1007,29 @@ extern "C" int dram_conv3d_bwd_data(const float* dy, const float* wb, float* dx,
     return launch<1>(pick_bn_for(g), dy, wb, nullptr, dx, nullptr, add, gate, g, (hipStream_t)stream);
   }
   g.lat = d->stride;
+  {  // lattice classes by tap count, most first (ties in index order); listed for stride 2, index order otherwise
+    const int L = g.lat, n = L * L * L;
+    g.ncls = 0;
+    g.cls_nib = 0;
+    if (n <= 8) {
+      int wgt[8], ord[8];
+      auto axis = [&](int r) {
+        int c = 0;
+        for (int t = 0; t < d->k; ++t) c += ((r + d->pad - t * d->dil) % L + L) % L == 0;
+        return c;
+      };
+      for (int c = 0; c < n; ++c) {
+        wgt[c] = axis(c / (L * L)) * axis((c / L) % L) * axis(c % L);
+        ord[c] = c;
+      }
+      for (int i = 1; i < n; ++i)   // insertion sort: stable
+        for (int j = i; j > 0 && wgt[ord[j]] > wgt[ord[j - 1]]; --j) {
+          const int t = ord[j]; ord[j] = ord[j - 1]; ord[j - 1] = t;
+        }
+      for (int c = 0; c < n; ++c) g.cls_nib |= (unsigned)ord[c] << (4 * c);
+      g.ncls = n;
+    }
+  }
   return launch<2>(pick_bn_for(g), dy, wb, nullptr, dx, nullptr, add, gate, g, (hipStream_t)stream);
 }
 

@@ -44,6 +44,8 @@ CONV_CASES = [
     (1, 5, 9, 7, 64, 128, 3, 1, 2),
     (1, 6, 10, 9, 64, 64, 3, 1, 4),
     (1, 8, 12, 10, 64, 128, 3, 2, 1),
+    (2, 10, 18, 34, 128, 64, 3, 2, 1),          # stride 2: several tiles per lattice class, two N tiles in the data gradient
+    (1, 9, 11, 13, 64, 64, 3, 2, 1),            # stride 2 on odd extents (the sub-lattices differ in size)
     (2, 4, 6, 5, 128, 64, 1, 1, 1),
     (1, 8, 16, 16, 96, 32, 3, 1, 1),
     (1, 3, 4, 5, 256, 256, 3, 1, 4),
