@@ -320,7 +320,7 @@ def main():
                     help="capture the train step (fwd + loss + bwd + Adam) in one hipGraph and time its replays "
                          "(bit-identical to eager steps; the number then does not depend on how fast the host issues "
                          "launches): the default for bf16 storage and config 0 on one GPU and for bf16 data-parallel runs; fp32 "
-                         "storage on one GPU picks it when a probe finds the host slow (config.graph_choice); fp32 data-parallel runs, a gloo rehearsal and "
+                         "storage (one GPU, or data parallel over RCCL) picks it when a probe finds the host slow (config.graph_choice); a gloo rehearsal and "
                          "--detail / --predict default to eager steps")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="time eager steps on one GPU too")
     ap.add_argument("--graph-streams", type=int, choices=(1, 2), default=1,
@@ -376,11 +376,14 @@ def main():
         # host's issue time against the step time and picks the replay when the host needs more than 0.4 of the step
         # (`config.graph_choice` in the line says what was measured and picked; --graph / --no-graph override).
         # Data parallel: bf16 storage replays a graph WITH its collectives (RCCL through its C API is plain stream work,
-        # distributed.DistContext.capturable); fp32 data-parallel steps and a gloo rehearsal run eager.
+        # distributed.DistContext.capturable); fp32 data-parallel steps over RCCL take the same probe; a gloo rehearsal runs eager.
         if args.predict or args.detail or (use_dist and args.backend != "nccl"):
             args.graph = False
         elif use_dist:
-            args.graph = args.dtype == "bf16" or args.config == 0
+            # (fp32 data parallel over RCCL: the same probe as on one GPU, the choice agreed over the ranks -- a host that
+            # cannot keep ahead of the GPU left the eager data-parallel step at 42.3 ms of wall clock against a hipEvent
+            # median of 37.1, `profiles/r05_bench_config1_f32_forcedist_slow_host.json.log`)
+            args.graph = True if (args.dtype == "bf16" or args.config == 0) else "auto"
         elif args.dtype == "bf16" or args.config == 0:
             args.graph = True
         else:
@@ -426,6 +429,10 @@ def main():
         torch.cuda.synchronize()
         total_s = time.perf_counter() - t0
         args.graph = issue_s > 0.4 * total_s
+        if use_dist:                         # one form on every rank: the replay if any rank's host is slow
+            flag = torch.tensor([1 if args.graph else 0], device=device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            args.graph = bool(int(flag.item()))
         graph_choice = (f"auto: the host issued {nprobe} untimed eager steps in {issue_s / nprobe * 1e3:.1f} ms/step of "
                         f"{total_s / nprobe * 1e3:.1f} ms/step -> " + ("hipGraph replay" if args.graph else "eager two-stream step"))
     if args.predict:
