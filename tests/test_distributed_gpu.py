@@ -378,6 +378,18 @@ def test_default_bench_line_says_how_the_step_was_timed():
     assert r.returncode == 0, r.stderr[-3000:]
     cfg = json.loads(r.stdout.splitlines()[0])["config"]
     assert cfg["hip_graph"] is True and cfg["graph_choice"] is None and cfg["streams"] == 1
+    # the fp32 data-parallel step over RCCL takes the same probe (agreed over the ranks) and says so
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        env = dict(env, MASTER_PORT=str(sk.getsockname()[1]))
+    r = subprocess.run(base + ["--force-dist"], env=env, capture_output=True, text=True, timeout=420, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads(r.stdout.splitlines()[0])
+    cfg = rec["config"]
+    assert rec["collective_transport"] == "rccl-c-api" and rec["plain_ms_per_step"] > 0
+    assert cfg["graph_choice"].startswith("auto: the host issued 4 untimed eager steps")
+    assert cfg["graph_choice"].endswith("hipGraph replay" if cfg["hip_graph"] else "eager two-stream step")
 
 
 def test_two_rank_bf16_storage_matches_ddp_syncbn_emulation():
